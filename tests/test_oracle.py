@@ -1,0 +1,131 @@
+"""The oracle against the golden vectors made from the reference (CPU only)."""
+import numpy as np
+import pytest
+from scipy.signal import convolve
+
+from oracle import ghost_oracle as orc
+from conftest import rel_err
+
+
+def test_scalars(golden):
+    g = golden("g4_scalars.npz")
+    assert orc.morse_peak_freq(3, 20) == pytest.approx(float(g["morsefreq"]), rel=1e-15)
+    assert orc.morse_high_cutoff(3, 20) == pytest.approx(float(g["morsehigh"]), rel=1e-15)
+    assert orc.morse_peak_freq(2, 8) == pytest.approx(float(g["morsefreq_g2_b8"]), rel=1e-15)
+    assert orc.morse_high_cutoff(2, 8) == pytest.approx(float(g["morsehigh_g2_b8"]), rel=1e-15)
+    for n, key in [(16384, "bounds_16384"), (1000000, "bounds_1e6"),
+                   (18000000, "bounds_18e6"), (4096, "bounds_4096")]:
+        np.testing.assert_allclose(orc.morse_freq_bounds(n), g[key], rtol=1e-15)
+    got = orc.morse_lengths(orc.hz_to_rad(g["len_freqs_hz"], 1000.0))
+    np.testing.assert_array_equal(got, g["lengths_1khz"])
+    got = orc.morse_lengths(orc.hz_to_rad(g["len_freqs_30k"], 30000.0))
+    np.testing.assert_array_equal(got, g["lengths_30khz"])
+    # survey appendix B.1 literals
+    assert orc.morse_high_cutoff() == pytest.approx(2.462940775226778, rel=1e-14)
+    assert orc.morse_base_length() == pytest.approx(46.563365541398426, rel=1e-14)
+
+
+def test_default_grid(golden):
+    g = golden("g4_scalars.npz")
+    f = orc.frequency_grid(1000.0, 16384)
+    np.testing.assert_allclose(f, g["default_grid_16384"], rtol=1e-14)
+    assert f.size == 66
+
+
+def test_kernels(golden):
+    g = golden("g3_kernels.npz")
+    for L in (36, 40, 70, 279, 1163, 1395):
+        psi, psif = orc.morse_kernel(L, float(g["omega_%d" % L]))
+        np.testing.assert_allclose(psif, g["psif_%d" % L], rtol=1e-13, atol=1e-300)
+        scale = np.abs(g["psi_%d" % L]).max()
+        assert np.abs(psi - g["psi_%d" % L]).max() <= 1e-14 * scale
+
+
+def test_two_tone_known_answers(golden):
+    g = golden("g4b_two_tone.npz")
+    fs, n = 1000.0, 4096
+    t = np.arange(n) / fs
+    x = np.sin(2 * np.pi * 50 * t) + 0.5 * np.sin(2 * np.pi * 12 * t)
+    f = orc.frequency_grid(fs, n, freq_limits=[10, 100], voices_per_octave=4)
+    np.testing.assert_allclose(f, g["frequencies"], rtol=1e-14)
+    amp = orc.cwt_amplitude(x, fs, f)
+    np.testing.assert_allclose(amp[:, 2048], g["amplitude_col2048"], rtol=1e-10)
+    assert amp.sum() == pytest.approx(float(g["amplitude_sum"]), rel=1e-12)
+    c = orc.cwt_complex(x, fs, [50.0, 12.0])
+    idx = g["w_idx"]
+    np.testing.assert_allclose(c[0, idx], g["w50"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(c[1, idx], g["w12"], rtol=0, atol=1e-13)
+
+
+def test_config1_driver(golden):
+    g = golden("g1_config1.npz")
+    fs = float(g["fs"])
+    x = g["x"].astype(np.float64)
+    f = orc.frequency_grid(fs, x.size, freq_limits=[5, 200], voices_per_octave=6)
+    np.testing.assert_allclose(f, g["frequencies"], rtol=1e-14)
+    np.testing.assert_array_equal(orc.morse_lengths(orc.hz_to_rad(f, fs)), g["lengths"])
+    c = orc.cwt_complex(x, fs, f)
+    cols = g["cols"]
+    assert rel_err(c[:, cols], g["complex_cols"]).max() < 1e-12
+    assert rel_err(np.abs(c)[:, cols], g["amplitude_cols"]).max() < 1e-12
+    np.testing.assert_allclose(np.abs(c).max(axis=1), g["amplitude_rowmax"], rtol=1e-12)
+    # threaded path = serial path
+    c2 = orc.cwt_complex(x, fs, f[:6], n_threads=3)
+    np.testing.assert_array_equal(c2, c[:6])
+
+
+def test_small_complex_and_parity_of_L(golden):
+    g = golden("g2_complex_small.npz")
+    c = orc.cwt_complex(g["x"].astype(np.float64), float(g["fs"]), g["frequencies"])
+    assert rel_err(c, g["coeffs"]).max() < 1e-12
+
+
+def test_two_epochs(golden):
+    g = golden("g5_two_epochs.npz")
+    fs = float(g["fs"])
+    eb = orc.contiguous_segments(g["timestamps"], fs)
+    np.testing.assert_array_equal(eb, g["epoch_bounds"])
+    np.testing.assert_array_equal(eb, [[0, 6000], [6000, 10000]])
+    f = orc.frequency_grid(fs, np.diff(eb, axis=1).min())
+    np.testing.assert_allclose(f, g["frequencies"], rtol=1e-14)
+    assert f.size == 45
+    c = orc.cwt_complex(g["x"].astype(np.float64), fs, f, eb)
+    assert rel_err(c[:, g["cols"]], g["complex_cols"]).max() < 1e-12
+
+
+def test_near_nyquist(golden):
+    g = golden("g6_near_nyquist.npz")
+    c = orc.cwt_complex(g["x"].astype(np.float64), float(g["fs"]), g["frequencies"])
+    assert rel_err(c, g["coeffs"]).max() < 1e-12
+
+
+def test_config2_reduced(golden):
+    g = golden("g9_config2_reduced.npz")
+    f = g["frequencies"][::9]
+    c = orc.cwt_complex(g["x"].astype(np.float64), float(g["fs"]), f)
+    assert rel_err(c[:, g["cols"]], g["complex_cols"][::9]).max() < 2e-7  # stored as c64
+
+
+def test_overlap_add_matches_direct_convolution():
+    # the reference's own test of this layer: tests/test_convolution.py:6-21
+    rng = np.random.default_rng(0)
+    x = rng.random(10000)
+    y = rng.random(1000)
+    for mode in ("full", "same", "valid"):
+        np.testing.assert_allclose(orc.overlap_add_convolve(x, y, mode=mode, fft_length=2048),
+                                   convolve(x, y, mode=mode), rtol=1e-9, atol=1e-9)
+
+
+def test_spectral_form_matches_literal(golden):
+    """closed form == literal while f < ~0.28 fs."""
+    g = golden("g2_complex_small.npz")
+    x = g["x"].astype(np.float64)
+    fs = float(g["fs"])
+    f = g["frequencies"]
+    lit = orc.cwt_complex(x, fs, f)
+    spe = orc.cwt_complex_spectral(x, fs, f)
+    assert rel_err(spe, lit).max() < 1e-7
+    # and it is NOT valid near Nyquist (this is what the direct path is for)
+    g6 = golden("g6_near_nyquist.npz")
+    spe6 = orc.cwt_complex_spectral(g6["x"].astype(np.float64), fs, g6["frequencies"][:2])
+    assert rel_err(spe6, g6["coeffs"][:2]).min() > 1e-4
