@@ -1,0 +1,576 @@
+// api.cpp -- C ABI of libghostcwt.so (include/ghostcwt.h): plan objects, device
+// workspace, and the orchestration of one transform.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ghostcwt.h"
+#include "../../include/ghostcwt_debug.h"
+#include "kernels.h"
+#include "planner.h"
+
+using namespace gcwt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+int hip_err(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return e == hipErrorOutOfMemory ? GCWT_ERR_NOMEM : GCWT_ERR_HIP;
+}
+
+#define HIP_TRY(call)                                  \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) return hip_err(e_, #call);   \
+  } while (0)
+
+struct EpochDev {
+  SynthItemDev* items = nullptr;
+  SynthLevelDev* levels = nullptr;
+};
+
+enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_COUNT };
+
+}  // namespace
+
+struct gcwt_plan {
+  HostPlan hp;
+  bool uploaded = false;
+  bool profiling = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  // workspace
+  float2* d_x = nullptr;      // [C][max_p]   spectrum (k1-major)
+  float2* d_xr = nullptr;     // [C][max_xr]  decimated analytic signals, all levels
+  float2* d_xb = nullptr;     // [C][max_xb]  block spectra, all levels
+  float2* d_bank = nullptr;   // [S][B]
+  float2* d_psi = nullptr;    // direct kernels
+  float2* d_tw4096 = nullptr; // exp(-2 pi i j/4096), j < 2048
+  float2* d_tw256 = nullptr;  // exp(+2 pi i q/256)
+  float2* d_level_tw = nullptr;
+  double* d_sums = nullptr;   // [C]
+  BankScale* d_bank_sc = nullptr;
+  DirectScale* d_direct_sc = nullptr;
+  std::vector<EpochDev> ep_dev;
+  int64_t max_direct_len = 0;
+  // staging for host-side callers
+  float* d_in = nullptr;
+  size_t d_in_bytes = 0;
+  void* d_out = nullptr;
+  size_t d_out_bytes = 0;
+  // profiling
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct Span { int stage; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  gcwt_timings last{};
+  bool have_timings = false;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+  if (count == 0) count = 1;
+  HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
+  return GCWT_OK;
+}
+
+template <typename T>
+int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
+  int rc = dev_alloc(p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIP_TRY(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  return GCWT_OK;
+}
+
+void free_dev(gcwt_plan* p) {
+  auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
+  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_bank); fr(p->d_psi); fr(p->d_tw4096);
+  fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_bank_sc); fr(p->d_direct_sc);
+  fr(p->d_in);
+  if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
+  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); }
+  p->ep_dev.clear();
+  for (auto e : p->ev_pool) (void)hipEventDestroy(e);
+  p->ev_pool.clear();
+  if (p->stream) { (void)hipStreamDestroy(p->stream); p->stream = nullptr; }
+  p->uploaded = false;
+}
+
+int get_event(gcwt_plan* p, hipEvent_t* e) {
+  if (p->ev_used == p->ev_pool.size()) {
+    hipEvent_t n;
+    HIP_TRY(hipEventCreate(&n));
+    p->ev_pool.push_back(n);
+  }
+  *e = p->ev_pool[p->ev_used++];
+  return GCWT_OK;
+}
+
+// RAII-less span helper: begin/end record events on the plan stream when profiling
+struct SpanGuard {
+  gcwt_plan* p;
+  int stage;
+  hipEvent_t a = nullptr;
+  int rc = GCWT_OK;
+  SpanGuard(gcwt_plan* p_, int st) : p(p_), stage(st) {
+    if (!p->profiling) return;
+    rc = get_event(p, &a);
+    if (rc == GCWT_OK && hipEventRecord(a, p->stream) != hipSuccess) rc = GCWT_ERR_HIP;
+  }
+  int end() {
+    if (!p->profiling || rc) return rc;
+    hipEvent_t b;
+    rc = get_event(p, &b);
+    if (rc) return rc;
+    if (hipEventRecord(b, p->stream) != hipSuccess) return GCWT_ERR_HIP;
+    p->spans.push_back({stage, a, b});
+    return GCWT_OK;
+  }
+};
+
+int banker_round_half(int64_t L) {  // Python round(L/2): half to even (morseutils.py:178)
+  if (L % 2 == 0) return (int)(L / 2);
+  int64_t lo = L / 2;               // L/2 = lo + 0.5
+  return (int)((lo % 2 == 0) ? lo : lo + 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcwt_abi_version(void) { return GCWT_ABI_VERSION; }
+
+const char* gcwt_last_error(void) { return g_err.c_str(); }
+
+int gcwt_device_count(int* count) {
+  if (!count) return set_err(GCWT_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return set_err(GCWT_ERR_NO_DEVICE, hipGetErrorString(e)); }
+  *count = n;
+  return GCWT_OK;
+}
+
+int gcwt_device_name(int device, char* buf, size_t buflen) {
+  if (!buf || buflen == 0) return set_err(GCWT_ERR_INVALID, "buf is NULL");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return GCWT_OK;
+}
+
+int gcwt_set_device(int device) { HIP_TRY(hipSetDevice(device)); return GCWT_OK; }
+int gcwt_device_malloc(void** ptr, size_t bytes) { HIP_TRY(hipMalloc(ptr, bytes ? bytes : 1)); return GCWT_OK; }
+int gcwt_device_free(void* ptr) { HIP_TRY(hipFree(ptr)); return GCWT_OK; }
+int gcwt_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return GCWT_OK;
+}
+int gcwt_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return GCWT_OK;
+}
+int gcwt_device_memset(void* dst, int value, size_t bytes) {
+  HIP_TRY(hipMemset(dst, value, bytes)); return GCWT_OK;
+}
+int gcwt_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return GCWT_OK; }
+
+int gcwt_plan_create(gcwt_plan** out, const gcwt_params* params) {
+  if (!out || !params) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  gcwt_plan* p = new (std::nothrow) gcwt_plan();
+  if (!p) return set_err(GCWT_ERR_NOMEM, "out of host memory");
+  std::string err;
+  int rc = build_host_plan(*params, &p->hp, &err);
+  if (rc != GCWT_OK) { delete p; return set_err(rc, err); }
+  // the plan keeps its own copies of the arrays
+  p->hp.prm.freqs_hz = p->hp.freqs.data();
+  p->hp.prm.epoch_bounds = p->hp.bounds.data();
+  p->hp.prm.n_epochs = (int32_t)p->hp.epochs.size();
+  p->device = params->device;
+  for (const auto& s : p->hp.scales)
+    if (s.method == GCWT_SCALE_DIRECT) p->max_direct_len = std::max(p->max_direct_len, s.length);
+  *out = p;
+  return GCWT_OK;
+}
+
+void gcwt_plan_destroy(gcwt_plan* plan) {
+  if (!plan) return;
+  if (plan->uploaded || plan->stream) {
+    if (plan->device >= 0) (void)hipSetDevice(plan->device);
+    free_dev(plan);
+  }
+  delete plan;
+}
+
+int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info) {
+  if (!plan || !info) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  const HostPlan& hp = plan->hp;
+  info->abi_version = GCWT_ABI_VERSION;
+  info->n_levels = (int32_t)hp.levels.size();
+  info->n_direct = hp.n_direct;
+  info->n_spectral = (int32_t)hp.scales.size() - hp.n_direct;
+  info->block = hp.block;
+  int r = 1;
+  for (const auto& l : hp.levels) r = std::max(r, l.decimation);
+  info->max_decimation = r;
+  info->fft_length = hp.max_p;
+  info->workspace_bytes = hp.workspace_bytes;
+  info->out_bytes = (int64_t)hp.out_elem_bytes * hp.prm.n_channels * hp.prm.n_freqs * hp.prm.n_samples;
+  return GCWT_OK;
+}
+
+int gcwt_plan_scale_info(const gcwt_plan* plan, int32_t* method, int32_t* decimation, int32_t* halo,
+                         int32_t* hop, int64_t* length) {
+  if (!plan) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  const HostPlan& hp = plan->hp;
+  for (size_t i = 0; i < hp.scales.size(); ++i) {
+    const ScalePlan& s = hp.scales[i];
+    if (method) method[i] = s.method;
+    if (decimation) decimation[i] = s.method == GCWT_SCALE_SPECTRAL ? s.decimation : 1;
+    if (halo) halo[i] = s.level >= 0 ? hp.levels[s.level].halo : 0;
+    if (hop) hop[i] = s.level >= 0 ? hp.levels[s.level].hop : 0;
+    if (length) length[i] = s.length;
+  }
+  return GCWT_OK;
+}
+
+int gcwt_plan_set_profiling(gcwt_plan* plan, int enabled) {
+  if (!plan) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  plan->profiling = enabled != 0;
+  return GCWT_OK;
+}
+
+int gcwt_plan_upload(gcwt_plan* p) {
+  if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  if (p->uploaded) return GCWT_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return set_err(GCWT_ERR_NO_DEVICE,
+                   "no HIP device: libghostcwt needs an AMD GPU (gfx950); there is no CPU path");
+  if (p->device >= 0) HIP_TRY(hipSetDevice(p->device));
+  const HostPlan& hp = p->hp;
+  const int64_t C = hp.prm.n_channels;
+  const int S = hp.prm.n_freqs, B = hp.block;
+  int rc;
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  auto bail = [&](int code) { free_dev(p); return code; };
+
+  const bool any_spectral = hp.n_direct < S;
+  if (any_spectral) {
+    if ((rc = dev_alloc(&p->d_x, (size_t)(C * hp.max_p)))) return bail(rc);
+    if ((rc = dev_alloc(&p->d_xr, (size_t)(C * hp.max_xr)))) return bail(rc);
+    if ((rc = dev_alloc(&p->d_xb, (size_t)(C * hp.max_xb)))) return bail(rc);
+  }
+  if ((rc = dev_alloc(&p->d_bank, (size_t)S * B))) return bail(rc);
+  if ((rc = dev_alloc(&p->d_psi, (size_t)hp.direct_total))) return bail(rc);
+  if ((rc = dev_alloc(&p->d_sums, (size_t)C))) return bail(rc);
+
+  // tables, computed in double on the host
+  std::vector<float2> tw4096(kRowLen / 2), tw256(256), ltw((size_t)hp.level_twiddle_total);
+  for (int j = 0; j < kRowLen / 2; ++j) {
+    double a = -2.0 * M_PI * j / kRowLen;
+    tw4096[j] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  for (int q = 0; q < 256; ++q) {
+    double a = 2.0 * M_PI * q / 256.0;
+    tw256[q] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  for (const LevelPlan& lp : hp.levels) {
+    const int64_t n = (int64_t)kSynthCols * lp.decimation;
+    for (int64_t q = 0; q < n; ++q) {
+      double a = 2.0 * M_PI * (double)q / ((double)B * lp.decimation);
+      ltw[lp.twiddle_offset + q] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+  }
+  if ((rc = upload_vec(&p->d_tw4096, tw4096, p->stream))) return bail(rc);
+  if ((rc = upload_vec(&p->d_tw256, tw256, p->stream))) return bail(rc);
+  if ((rc = upload_vec(&p->d_level_tw, ltw, p->stream))) return bail(rc);
+
+  std::vector<BankScale> bsc(S);
+  std::vector<DirectScale> dsc(hp.n_direct);
+  for (int i = 0; i < S; ++i) {
+    const ScalePlan& s = hp.scales[i];
+    bsc[i] = {s.omega, s.half_delay, s.decimation, s.method == GCWT_SCALE_SPECTRAL ? 1 : 0};
+    if (s.method == GCWT_SCALE_DIRECT)
+      dsc[s.direct_index] = {s.omega, s.length, banker_round_half(s.length), s.direct_offset, i, 0};
+  }
+  if ((rc = upload_vec(&p->d_bank_sc, bsc, p->stream))) return bail(rc);
+  if ((rc = upload_vec(&p->d_direct_sc, dsc, p->stream))) return bail(rc);
+
+  p->ep_dev.resize(hp.epochs.size());
+  for (size_t e = 0; e < hp.epochs.size(); ++e) {
+    const EpochPlan& ep = hp.epochs[e];
+    std::vector<SynthItemDev> items(ep.items.size());
+    for (size_t i = 0; i < items.size(); ++i)
+      items[i] = {ep.items[i].level, ep.items[i].scale, ep.items[i].blk0, ep.items[i].nblk};
+    std::vector<SynthLevelDev> lv(hp.levels.size());
+    for (size_t l = 0; l < lv.size(); ++l)
+      lv[l] = {hp.levels[l].decimation, hp.levels[l].hop, hp.levels[l].halo, 0,
+               ep.lv[l].xb_offset, hp.levels[l].twiddle_offset};
+    if ((rc = upload_vec(&p->ep_dev[e].items, items, p->stream))) return bail(rc);
+    if ((rc = upload_vec(&p->ep_dev[e].levels, lv, p->stream))) return bail(rc);
+  }
+
+  hipError_t he = launch_build_bank(p->d_bank, p->d_bank_sc, S, B, hp.prm.gamma, hp.prm.beta, hp.w0,
+                                    p->stream);
+  if (he != hipSuccess) return bail(hip_err(he, "build_bank"));
+  he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, hp.prm.gamma,
+                           hp.prm.beta, hp.w0, p->stream);
+  if (he != hipSuccess) return bail(hip_err(he, "build_direct"));
+  he = hipStreamSynchronize(p->stream);  // host vectors above go out of scope
+  if (he != hipSuccess) return bail(hip_err(he, "plan upload"));
+  p->uploaded = true;
+  return GCWT_OK;
+}
+
+static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
+  const HostPlan& hp = p->hp;
+  const int C = hp.prm.n_channels, S = hp.prm.n_freqs;
+  const int64_t N = hp.prm.n_samples;
+  const int mode = hp.prm.out_mode;
+  const int elem = mode == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
+  const double inv_n = 1.0 / (double)N;
+  hipStream_t st = p->stream;
+  hipError_t he;
+#define RUN(stage_id, call)                         \
+  do {                                              \
+    SpanGuard sg_(p, stage_id);                     \
+    if (sg_.rc) return sg_.rc;                      \
+    he = (call);                                    \
+    if (he != hipSuccess) return hip_err(he, #call);\
+    int rc_ = sg_.end();                            \
+    if (rc_) return rc_;                            \
+  } while (0)
+
+  RUN(ST_MEAN, launch_channel_sum(dx, N, C, p->d_sums, st));
+
+  // samples outside every epoch are zero (transforms.py:185)
+  {
+    int64_t cursor = 0;
+    std::vector<std::pair<int64_t, int64_t>> eps;
+    for (const auto& e : hp.epochs) eps.push_back({e.start, e.stop});
+    std::sort(eps.begin(), eps.end());
+    for (size_t i = 0; i <= eps.size(); ++i) {
+      int64_t gap_end = i < eps.size() ? eps[i].first : N;
+      if (gap_end > cursor) {
+        he = launch_zero_range(dout, N * elem, (int64_t)C * S, cursor * elem, (gap_end - cursor) * elem, st);
+        if (he != hipSuccess) return hip_err(he, "zero_range");
+      }
+      if (i < eps.size()) cursor = std::max(cursor, eps[i].second);
+    }
+  }
+
+  const bool any_spectral = hp.n_direct < S;
+  for (size_t e = 0; e < hp.epochs.size(); ++e) {
+    const EpochPlan& ep = hp.epochs[e];
+    if (any_spectral) {
+      const int64_t P = ep.p;
+      const int P1 = ep.p1;
+      // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
+      RUN(ST_FWD, launch_fft_cols(-1, true, dx + ep.start, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0,
+                                  p->d_tw4096, p->d_sums, inv_n, ep.ne, C, st));
+      // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]
+      RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, P1, kRowLen, kRowLen, P, P, 0,
+                                  p->d_tw4096, 1.0f, C, st));
+      for (size_t l = 0; l < hp.levels.size(); ++l) {
+        const LevelPlan& lp = hp.levels[l];
+        const EpochLevel& el = ep.lv[l];
+        const int Q = kRowLen / lp.decimation;
+        float2* xr = p->d_xr + el.xr_offset;
+        // x_R[Q m1 + m2] = sum_{j1} e^{2 pi i j1 m1/P1} e^{2 pi i j1 m2/M} sum_{j2} X~[j1][j2] e^{2 pi i j2 m2/Q}
+        RUN(ST_DECIM, launch_fft_rows(+1, p->d_x, xr, Q, P1, kRowLen, Q, P, hp.max_xr,
+                                      P1 > 1 ? el.m : 0, p->d_tw4096, 1.0f, C, st));
+        if (P1 > 1)
+          RUN(ST_DECIM, launch_fft_cols(+1, false, xr, xr, P1, Q, hp.max_xr, hp.max_xr, 0,
+                                        p->d_tw4096, p->d_sums, inv_n, 0, C, st));
+        const float scale = (float)(1.0 / ((double)hp.block * (double)P));
+        RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.nblk,
+                                       hp.max_xr, hp.max_xb, p->d_tw256, scale, C, st));
+      }
+      SynthArgs a{};
+      a.xb = p->d_xb;
+      a.bank = p->d_bank;
+      a.tw256 = p->d_tw256;
+      a.level_tw = p->d_level_tw;
+      a.items = p->ep_dev[e].items;
+      a.levels = p->ep_dev[e].levels;
+      a.out = dout;
+      a.xb_cstride = hp.max_xb;
+      a.n_samples = N;
+      a.epoch_start = ep.start;
+      a.epoch_len = ep.ne;
+      a.n_scales = S;
+      RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), C, st));
+      if (p->profiling) p->last.synth_launches++;
+    }
+    if (hp.n_direct > 0)
+      RUN(ST_DIRECT, launch_direct(mode, dx, dout, p->d_psi, p->d_direct_sc, hp.n_direct, p->d_sums,
+                                   inv_n, N, S, ep.start, ep.ne, C, st));
+  }
+#undef RUN
+  return GCWT_OK;
+}
+
+int gcwt_execute(gcwt_plan* p, const void* x, void* out, int flags) {
+  if (!p || !x || !out) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  int rc = gcwt_plan_upload(p);
+  if (rc) return rc;
+  if (p->device >= 0) HIP_TRY(hipSetDevice(p->device));
+  const HostPlan& hp = p->hp;
+  const size_t in_bytes = sizeof(float) * (size_t)hp.prm.n_channels * (size_t)hp.prm.n_samples;
+  const size_t out_bytes = hp.out_elem_bytes * (size_t)hp.prm.n_channels * (size_t)hp.prm.n_freqs *
+                           (size_t)hp.prm.n_samples;
+  const float* dx;
+  float* dout;
+  if (flags & GCWT_X_ON_DEVICE) {
+    dx = (const float*)x;
+  } else {
+    if (p->d_in_bytes < in_bytes) {
+      if (p->d_in) { (void)hipFree(p->d_in); p->d_in = nullptr; p->d_in_bytes = 0; }
+      HIP_TRY(hipMalloc((void**)&p->d_in, in_bytes));
+      p->d_in_bytes = in_bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(p->d_in, x, in_bytes, hipMemcpyHostToDevice, p->stream));
+    dx = p->d_in;
+  }
+  if (flags & GCWT_OUT_ON_DEVICE) {
+    dout = (float*)out;
+  } else {
+    if (p->d_out_bytes < out_bytes) {
+      if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; p->d_out_bytes = 0; }
+      HIP_TRY(hipMalloc(&p->d_out, out_bytes));
+      p->d_out_bytes = out_bytes;
+    }
+    dout = (float*)p->d_out;
+  }
+  p->ev_used = 0;
+  p->spans.clear();
+  if (p->profiling) { p->last = gcwt_timings{}; }
+  rc = run_pipeline(p, dx, dout);
+  if (rc) { (void)hipStreamSynchronize(p->stream); return rc; }
+  if (!(flags & GCWT_OUT_ON_DEVICE))
+    HIP_TRY(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->profiling) {
+    float acc[ST_COUNT] = {0};
+    for (const auto& s : p->spans) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+      acc[s.stage] += ms;
+    }
+    if (!p->spans.empty()) {
+      float tot = 0;
+      HIP_TRY(hipEventElapsedTime(&tot, p->spans.front().a, p->spans.back().b));
+      p->last.total_ms = tot;
+    }
+    p->last.mean_ms = acc[ST_MEAN];
+    p->last.fwd_fft_ms = acc[ST_FWD];
+    p->last.decimate_ms = acc[ST_DECIM];
+    p->last.block_fft_ms = acc[ST_BLOCK];
+    p->last.synth_ms = acc[ST_SYNTH];
+    p->last.direct_ms = acc[ST_DIRECT];
+    p->have_timings = true;
+  }
+  return GCWT_OK;
+}
+
+int gcwt_filter_bank(gcwt_plan* p, float* bank) {
+  if (!p || !bank) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  int rc = gcwt_plan_upload(p);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(bank, p->d_bank, sizeof(float2) * (size_t)p->hp.prm.n_freqs * p->hp.block,
+                    hipMemcpyDeviceToHost));
+  return GCWT_OK;
+}
+
+int gcwt_direct_kernel(gcwt_plan* p, int scale, float* psi) {
+  if (!p || !psi) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  if (scale < 0 || scale >= p->hp.prm.n_freqs) return set_err(GCWT_ERR_INVALID, "scale out of range");
+  const ScalePlan& s = p->hp.scales[scale];
+  if (s.method != GCWT_SCALE_DIRECT) return set_err(GCWT_ERR_INVALID, "not a direct scale");
+  int rc = gcwt_plan_upload(p);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(psi, p->d_psi + s.direct_offset, sizeof(float2) * (size_t)s.length,
+                    hipMemcpyDeviceToHost));
+  return GCWT_OK;
+}
+
+int gcwt_get_timings(const gcwt_plan* p, gcwt_timings* t) {
+  if (!p || !t) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  if (!p->have_timings) return set_err(GCWT_ERR_INVALID, "no profiled execute yet");
+  *t = p->last;
+  return GCWT_OK;
+}
+
+// ---- debug hooks (include/ghostcwt_debug.h) --------------------------------
+int gcwt_debug_level_count(const gcwt_plan* p) { return p ? (int)p->hp.levels.size() : -1; }
+
+int gcwt_debug_level_info(const gcwt_plan* p, int epoch, int level, int32_t* decimation,
+                          int32_t* halo, int32_t* hop, int32_t* nblk, int64_t* m) {
+  if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  if (epoch < 0 || epoch >= (int)p->hp.epochs.size() || level < 0 ||
+      level >= (int)p->hp.levels.size())
+    return set_err(GCWT_ERR_INVALID, "epoch/level out of range");
+  const LevelPlan& lp = p->hp.levels[level];
+  const EpochLevel& el = p->hp.epochs[epoch].lv[level];
+  if (decimation) *decimation = lp.decimation;
+  if (halo) *halo = lp.halo;
+  if (hop) *hop = lp.hop;
+  if (nblk) *nblk = el.nblk;
+  if (m) *m = el.m;
+  return GCWT_OK;
+}
+
+int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, float* dst,
+                     int64_t max_complex) {
+  if (!p || !dst) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  if (!p->uploaded) return set_err(GCWT_ERR_INVALID, "plan has not run");
+  const HostPlan& hp = p->hp;
+  if (epoch < 0 || epoch >= (int)hp.epochs.size() || channel < 0 || channel >= hp.prm.n_channels)
+    return set_err(GCWT_ERR_INVALID, "epoch/channel out of range");
+  const EpochPlan& ep = hp.epochs[epoch];
+  const float2* src = nullptr;
+  int64_t n = 0;
+  if (what == GCWT_DEBUG_SPECTRUM) {
+    src = p->d_x + (int64_t)channel * ep.p;
+    n = ep.p;
+  } else {
+    if (level < 0 || level >= (int)hp.levels.size()) return set_err(GCWT_ERR_INVALID, "level out of range");
+    if (what == GCWT_DEBUG_DECIMATED) {
+      src = p->d_xr + (int64_t)channel * hp.max_xr + ep.lv[level].xr_offset;
+      n = ep.lv[level].m;
+    } else if (what == GCWT_DEBUG_BLOCK_SPECTRA) {
+      src = p->d_xb + (int64_t)channel * hp.max_xb + ep.lv[level].xb_offset;
+      n = (int64_t)ep.lv[level].nblk * hp.block;
+    } else {
+      return set_err(GCWT_ERR_INVALID, "unknown buffer");
+    }
+  }
+  if (n > max_complex) return set_err(GCWT_ERR_INVALID, "destination too small");
+  HIP_TRY(hipMemcpy(dst, src, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost));
+  return (int)0;
+}
+
+}  // extern "C"
+
+// accessors for comm.cpp
+int gcwt_internal_set_error(int code, const char* msg) { return set_err(code, msg); }
+float2* gcwt_internal_bank_ptr(gcwt_plan* p, size_t* bytes) {
+  *bytes = sizeof(float2) * (size_t)p->hp.prm.n_freqs * p->hp.block;
+  return p->d_bank;
+}
+hipStream_t gcwt_internal_stream(gcwt_plan* p) { return p->stream; }
+int gcwt_internal_device(gcwt_plan* p) { return p->device; }

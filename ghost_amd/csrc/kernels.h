@@ -1,0 +1,81 @@
+// kernels.h -- device-side argument structs and launch wrappers (see kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "../../include/ghostcwt.h"
+
+namespace gcwt {
+
+constexpr int kRowLenDev = 4096;
+
+struct BankScale {
+  double omega;
+  double half_delay;
+  int32_t decimation;
+  int32_t spectral;
+};
+
+struct DirectScale {
+  double omega;
+  int64_t length;
+  int64_t n_bins;   // round-half-even(L/2): bins kept by the reference (morseutils.py:178)
+  int64_t offset;   // into the psi buffer
+  int32_t scale;    // output row
+  int32_t pad;
+};
+
+struct SynthItemDev {
+  int32_t level, scale, blk0, nblk;
+};
+
+struct SynthLevelDev {
+  int32_t decimation, hop, halo, pad;
+  int64_t xb_offset;   // per-channel offset of this level's block spectra (complex elems)
+  int64_t tw_offset;   // into level_tw
+};
+
+struct SynthArgs {
+  const float2* xb;
+  const float2* bank;
+  const float2* tw256;
+  const float2* level_tw;
+  const SynthItemDev* items;
+  const SynthLevelDev* levels;
+  float* out;
+  int64_t xb_cstride;
+  int64_t n_samples;     // N, row length of out in samples
+  int64_t epoch_start;
+  int64_t epoch_len;
+  int32_t n_scales;
+  int32_t pad;
+};
+
+hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,
+                              hipStream_t st);
+hipError_t launch_build_bank(float2* bank, const BankScale* sc, int n_scales, int B, double gamma,
+                             double beta, double w0, hipStream_t st);
+hipError_t launch_build_direct(float2* psi, const DirectScale* sc, int n_direct, int64_t max_len,
+                               double gamma, double beta, double w0, hipStream_t st);
+hipError_t launch_fft_cols(int sign, bool real_in, const void* in, float2* out, int len, int ld,
+                           int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
+                           const float2* tw4096, const double* sums, double inv_n, int64_t n_valid,
+                           int n_channels, hipStream_t st);
+hipError_t launch_fft_rows(int sign, const float2* in, float2* out, int len, int64_t n_rows,
+                           int64_t in_ld, int64_t out_ld, int64_t in_cstride, int64_t out_cstride,
+                           int64_t tw_n, const float2* tw4096, float scale, int n_channels,
+                           hipStream_t st);
+hipError_t launch_block_fft(const float2* xr, float2* xb, int64_t m, int hop, int halo, int nblk,
+                            int64_t xr_cstride, int64_t xb_cstride, const float2* tw256, float scale,
+                            int n_channels, hipStream_t st);
+hipError_t launch_synth(int mode, const SynthArgs& a, int n_items, int n_channels, hipStream_t st);
+hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi,
+                         const DirectScale* sc, int n_direct, const double* sums, double inv_n,
+                         int64_t n_samples, int n_scales, int64_t epoch_start, int64_t epoch_len,
+                         int n_channels, hipStream_t st);
+hipError_t launch_zero_range(float* out, int64_t row_len_floats, int64_t n_rows, int64_t start,
+                             int64_t len, hipStream_t st);
+
+}  // namespace gcwt

@@ -1,0 +1,612 @@
+// kernels.hip -- gfx950 device code of the CWT engine and its launch wrappers.
+//
+// Stages:
+//   k_channel_sum      per-channel sum for the global mean     (transforms.py:143)
+//   k_build_bank       Morse one-sided filter bank, fp64 -> fp32 (morseutils.py:115-131)
+//   k_build_direct     literal L-tap kernels for scales that reach Nyquist
+//                                                              (morseutils.py:117-149)
+//   k_fft_cols/rows    two-pass radix-2 LDS FFT used for the per-epoch forward
+//                      FFT and the per-level inverse FFTs (replaces the per-chunk
+//                      FFTs of convolution.py:74-76)
+//   k_block_fft        256-point spectra of overlapping decimated blocks
+//   k_synth            filter * polyphase twiddle * 256-point IFFT * |.| * store
+//                                                              (transforms.py:203-204)
+//   k_direct           time-domain convolution for direct scales
+//   k_zero_gaps        zero samples outside every epoch        (transforms.py:185)
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace gcwt {
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by SIGN * i
+template <int SIGN>
+__device__ __forceinline__ cf mul_si(cf a) {
+  return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+// ---------------------------------------------------------------------------
+// 16-point DFT in registers, natural order in and out.
+//   X[k] = sum_n x[n] exp(SIGN 2 pi i n k / 16)
+// n = n1 + 4 n2, k = 4 k1 + k2: DFT4 over n2, twiddle W16^(n1 k2), DFT4 over n1.
+// ---------------------------------------------------------------------------
+template <int SIGN>
+__device__ __forceinline__ void dft4(cf& a, cf& b, cf& c, cf& d) {
+  cf s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = mul_si<SIGN>(csub(b, d));
+  a = cadd(s0, s2);
+  c = csub(s0, s2);
+  b = cadd(s1, s3);
+  d = csub(s1, s3);
+}
+
+template <int SIGN>
+__device__ __forceinline__ void dft16(cf v[16]) {
+  const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;  // cos, sin(pi/8)
+  const float h = 0.70710678118654752f;
+#pragma unroll
+  for (int n1 = 0; n1 < 4; ++n1) dft4<SIGN>(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+  // v[n1 + 4 k2] *= W16^(n1 k2)
+  const float sg = (float)SIGN;
+  v[5] = cmul(v[5], make_float2(c1, sg * s1));     // q = 1
+  v[9] = cmul(v[9], make_float2(h, sg * h));       // q = 2
+  v[13] = cmul(v[13], make_float2(s1, sg * c1));   // q = 3
+  v[6] = cmul(v[6], make_float2(h, sg * h));       // q = 2
+  v[10] = mul_si<SIGN>(v[10]);                     // q = 4
+  v[14] = cmul(v[14], make_float2(-h, sg * h));    // q = 6
+  v[7] = cmul(v[7], make_float2(s1, sg * c1));     // q = 3
+  v[11] = cmul(v[11], make_float2(-h, sg * h));    // q = 6
+  v[15] = cmul(v[15], make_float2(-c1, -sg * s1)); // q = 9
+#pragma unroll
+  for (int k2 = 0; k2 < 4; ++k2)
+    dft4<SIGN>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
+  // now v[k1 + 4 k2] holds X[4 k1 + k2]: transpose the 4x4 index
+  cf t;
+#define GCWT_SWAP(a, b) t = v[a]; v[a] = v[b]; v[b] = t;
+  GCWT_SWAP(1, 4) GCWT_SWAP(2, 8) GCWT_SWAP(3, 12) GCWT_SWAP(6, 9) GCWT_SWAP(7, 13) GCWT_SWAP(11, 14)
+#undef GCWT_SWAP
+}
+
+// ---------------------------------------------------------------------------
+// 256-point FFT by 16 threads (one "column"), 16 points per thread.
+//   in : v[j] = in[t + 16 j]       out: v[j] = out[t + 16 j]
+// k = k1 + 16 k2 (k1 = t), m = 16 m1 + m2:  DFT16 over k2, twiddle W256^(k1 m2),
+// exchange through LDS, DFT16 over k1.  tw[m2] = exp(SIGN 2 pi i t m2 / 256).
+// ex_re/ex_im: this column's 16 x 17 float planes.  Contains one __syncthreads.
+// ---------------------------------------------------------------------------
+constexpr int kExPitch = 17;
+constexpr int kExCol = 16 * kExPitch;  // floats per column per plane
+
+template <int SIGN>
+__device__ __forceinline__ void fft256_16t(cf v[16], const cf tw[16], float* ex_re, float* ex_im,
+                                           int t) {
+  dft16<SIGN>(v);
+#pragma unroll
+  for (int m2 = 0; m2 < 16; ++m2) {
+    cf u = cmul(v[m2], tw[m2]);
+    ex_re[t * kExPitch + m2] = u.x;
+    ex_im[t * kExPitch + m2] = u.y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1)
+    v[k1] = make_float2(ex_re[k1 * kExPitch + t], ex_im[k1 * kExPitch + t]);
+  dft16<SIGN>(v);
+}
+
+// ---------------------------------------------------------------------------
+// per-channel sum (fp64 accumulate), partial sums combined with one atomic per
+// workgroup.  grid (parts, C)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_channel_sum(const float* __restrict__ x, int64_t n,
+                                                     double* __restrict__ sums) {
+  const int c = blockIdx.y;
+  const float* xc = x + (int64_t)c * n;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    acc += (double)xc[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&sums[c], part[0] + part[1] + part[2] + part[3]);
+}
+
+// ---------------------------------------------------------------------------
+// filter bank: H[s][k] = 2 exp(-b ln w0 + w0^g + b ln w - w^g) exp(-i theta d)
+//   theta = 2 pi k / (B R_s), w = theta w0 / omega_s   (morseutils.py:116-117, 130-131)
+// grid (S), block (B)
+// ---------------------------------------------------------------------------
+__global__ void k_build_bank(cf* __restrict__ bank, const BankScale* __restrict__ sc, int B,
+                             double gamma, double beta, double w0) {
+  const int s = blockIdx.x;
+  const int k = threadIdx.x;
+  const BankScale p = sc[s];
+  cf h = make_float2(0.f, 0.f);
+  if (p.spectral && k > 0) {
+    const double theta = 2.0 * M_PI * (double)k / ((double)B * (double)p.decimation);
+    const double w = theta * (w0 / p.omega);
+    const double ln = -beta * log(w0) + pow(w0, gamma) + beta * log(w) - pow(w, gamma);
+    const double amp = 2.0 * exp(ln);
+    double sn, cs;
+    sincos(-theta * p.half_delay, &sn, &cs);
+    h = make_float2((float)(amp * cs), (float)(amp * sn));
+  }
+  bank[(int64_t)s * B + k] = h;
+}
+
+// ---------------------------------------------------------------------------
+// literal kernels for direct scales: psi[n] = (1/L) sum_{k<K} A(k) e^{i pi k (L+1)/L}
+//   e^{2 pi i k n / L},  K = round-half-even(L/2)            (morseutils.py:117-149)
+// grid (n_direct, ceil(Lmax/256))
+// ---------------------------------------------------------------------------
+__global__ void k_build_direct(cf* __restrict__ psi, const DirectScale* __restrict__ sc,
+                               double gamma, double beta, double w0) {
+  const DirectScale p = sc[blockIdx.x];
+  const int64_t n = (int64_t)blockIdx.y * 256 + threadIdx.x;
+  if (n >= p.length) return;
+  const int64_t L = p.length;
+  const double fact = p.omega / w0;
+  double re = 0.0, im = 0.0;
+  for (int64_t k = 1; k < p.n_bins; ++k) {
+    const double w = 2.0 * M_PI * ((double)k / (double)L) / fact;
+    const double amp = 2.0 * exp(-beta * log(w0) + pow(w0, gamma) + beta * log(w) - pow(w, gamma));
+    // phase = pi k (L+1)/L + 2 pi k n / L, reduced exactly: (k (L+1 + 2n)) mod 2L over L
+    const int64_t q = (k * ((L + 1 + 2 * n) % (2 * L))) % (2 * L);
+    double sn, cs;
+    sincospi((double)q / (double)L, &sn, &cs);
+    re += amp * cs;
+    im += amp * sn;
+  }
+  psi[p.offset + n] = make_float2((float)(re / (double)L), (float)(im / (double)L));
+}
+
+// ---------------------------------------------------------------------------
+// In-LDS radix-2 decimation-in-frequency FFT of `nfft` independent transforms
+// of length `len`; element i of transform f lives at buf[f*fstride + i*istride].
+// Result k ends up at element bitrev(k).  All 256 threads take part.
+// tw4096[j] = exp(-2 pi i j / 4096), j < 2048 (conjugated for SIGN > 0).
+// ---------------------------------------------------------------------------
+template <int SIGN>
+__device__ __forceinline__ void lds_fft_radix2(cf* buf, int len, int log2len, int nfft,
+                                               int fstride, int istride,
+                                               const cf* __restrict__ tw4096) {
+  const int half_total = nfft * (len >> 1);
+  const bool f_fast = fstride < istride;  // column tiles: neighbouring threads take neighbouring f
+  for (int h = len >> 1, st = 0; h >= 1; h >>= 1, ++st) {
+    for (int b = threadIdx.x; b < half_total; b += 256) {
+      int f, j;
+      if (f_fast) { f = b % nfft; j = b / nfft; } else { f = b / (len >> 1); j = b % (len >> 1); }
+      const int pos = j & (h - 1);
+      const int i0 = ((j - pos) << 1) + pos;
+      cf* p0 = buf + f * fstride + i0 * istride;
+      cf* p1 = p0 + h * istride;
+      const cf a = *p0, c = *p1;
+      cf w = tw4096[(pos << st) * (kRowLenDev >> log2len)];
+      if (SIGN > 0) w.y = -w.y;
+      *p0 = cadd(a, c);
+      *p1 = cmul(csub(a, c), w);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ int bitrev(int v, int bits) {
+  return bits ? (int)(__brev((unsigned)v) >> (32 - bits)) : 0;
+}
+
+// ---------------------------------------------------------------------------
+// Column pass: for a tile of 16 adjacent columns, FFT over the row index.
+//   in  element (i, col) at in[i*ld + col],  i < len (= P1), col < ld
+//   out element (k, col) at out[k*ld + col], multiplied by
+//       exp(SIGN 2 pi i k col / tw_n) when tw_n > 0.
+// REAL_IN: input is the float32 signal: element (i, col) is sample i*ld + col of
+// the epoch, minus the channel mean, zero beyond n_valid.  (transforms.py:142-143)
+// grid (ld/16, C), dynamic LDS len*16*8 bytes
+// ---------------------------------------------------------------------------
+template <int SIGN, bool REAL_IN>
+__global__ void __launch_bounds__(256) k_fft_cols(const void* __restrict__ in_, cf* __restrict__ out,
+                                                  int len, int log2len, int ld, int64_t in_cstride,
+                                                  int64_t out_cstride, int64_t tw_n,
+                                                  const cf* __restrict__ tw4096,
+                                                  const double* __restrict__ sums, double inv_n,
+                                                  int64_t n_valid) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* buf = reinterpret_cast<cf*>(smem);
+  const int c = blockIdx.y;
+  const int col0 = blockIdx.x * 16;
+  const int total = len * 16;
+  if (REAL_IN) {
+    const float* x = reinterpret_cast<const float*>(in_) + (int64_t)c * in_cstride;
+    const float mean = (float)(sums[c] * inv_n);
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int i = e >> 4, cc = e & 15;
+      const int64_t n = (int64_t)i * ld + col0 + cc;
+      buf[e] = make_float2(n < n_valid ? x[n] - mean : 0.f, 0.f);
+    }
+  } else {
+    const cf* x = reinterpret_cast<const cf*>(in_) + (int64_t)c * in_cstride;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int i = e >> 4, cc = e & 15;
+      buf[e] = x[(int64_t)i * ld + col0 + cc];
+    }
+  }
+  __syncthreads();
+  if (len > 1) lds_fft_radix2<SIGN>(buf, len, log2len, 16, 1, 16, tw4096);
+  cf* o = out + (int64_t)c * out_cstride;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int k = e >> 4, cc = e & 15;
+    cf v = buf[bitrev(k, log2len) * 16 + cc];
+    if (tw_n > 0) {
+      const int64_t q = ((int64_t)k * (col0 + cc)) % tw_n;
+      float sn, cs;
+      sincospif(2.0f * (float)q / (float)tw_n, &sn, &cs);
+      v = cmul(v, make_float2(cs, SIGN > 0 ? sn : -sn));
+    }
+    o[(int64_t)k * ld + col0 + cc] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Row pass: contiguous FFTs of length len <= 4096; one workgroup transforms
+// 4096/len rows.  Row r reads in[r*in_ld .. +len) and writes out[r*out_ld .. +len),
+// multiplied by exp(SIGN 2 pi i r k / tw_n) when tw_n > 0, times `scale`.
+// grid (n_rows / (4096/len), C), LDS 32 KiB
+// ---------------------------------------------------------------------------
+template <int SIGN>
+__global__ void __launch_bounds__(256) k_fft_rows(const cf* __restrict__ in, cf* __restrict__ out,
+                                                  int len, int log2len, int64_t in_ld,
+                                                  int64_t out_ld, int64_t in_cstride,
+                                                  int64_t out_cstride, int64_t tw_n,
+                                                  const cf* __restrict__ tw4096, float scale,
+                                                  int n_rows) {
+  __shared__ __attribute__((aligned(16))) cf buf[kRowLenDev];
+  const int c = blockIdx.y;
+  const int rows = kRowLenDev >> log2len;
+  const int row0 = blockIdx.x * rows;
+  const cf* x = in + (int64_t)c * in_cstride;
+  for (int e = threadIdx.x; e < kRowLenDev; e += 256) {
+    const int r = e >> log2len, i = e & (len - 1);
+    buf[e] = row0 + r < n_rows ? x[(int64_t)(row0 + r) * in_ld + i] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  lds_fft_radix2<SIGN>(buf, len, log2len, rows, len, 1, tw4096);
+  cf* o = out + (int64_t)c * out_cstride;
+  for (int e = threadIdx.x; e < kRowLenDev; e += 256) {
+    const int r = e >> log2len, k = e & (len - 1);
+    if (row0 + r >= n_rows) continue;
+    cf v = buf[(r << log2len) + bitrev(k, log2len)];
+    if (tw_n > 0) {
+      const int64_t q = ((int64_t)(row0 + r) * k) % tw_n;
+      float sn, cs;
+      sincospif(2.0f * (float)q / (float)tw_n, &sn, &cs);
+      v = cmul(v, make_float2(cs, SIGN > 0 ? sn : -sn));
+    }
+    o[(int64_t)(row0 + r) * out_ld + k] = make_float2(v.x * scale, v.y * scale);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Block spectra: XB[blk][k] = scale * FFT_256(x_R[(blk*hop - halo + n) mod M])
+// 16 blocks per workgroup, 16 threads per block.  grid (ceil(nblk/16), C)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_block_fft(const cf* __restrict__ xr, cf* __restrict__ xb,
+                                                   int64_t m_mask, int hop, int halo, int nblk,
+                                                   int64_t xr_cstride, int64_t xb_cstride,
+                                                   const cf* __restrict__ tw256, float scale) {
+  __shared__ float ex_re[16 * kExCol];
+  __shared__ float ex_im[16 * kExCol];
+  const int c = blockIdx.y;
+  const int colw = threadIdx.x >> 4, t = threadIdx.x & 15;
+  const int blk = blockIdx.x * 16 + colw;
+  const bool valid = blk < nblk;
+  cf tw[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    cf w = tw256[(t * j) & 255];
+    tw[j] = make_float2(w.x, -w.y);  // table holds exp(+2 pi i q/256)
+  }
+  cf v[16];
+  const cf* x = xr + (int64_t)c * xr_cstride;
+  const int64_t base = (int64_t)blk * hop - halo + t;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    v[j] = valid ? x[(base + 16 * j) & m_mask] : make_float2(0.f, 0.f);
+  fft256_16t<-1>(v, tw, ex_re + colw * kExCol, ex_im + colw * kExCol, t);
+  if (valid) {
+    cf* o = xb + (int64_t)c * xb_cstride + (int64_t)blk * 256 + t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[16 * j] = make_float2(v[j].x * scale, v[j].y * scale);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Synthesis (the hot kernel).  One workgroup = one (channel, scale, group of
+// blocks).  Columns are (block, r) pairs, r in [0, R): column (blk, r) is
+//   y[R (blk*hop + m - halo) + r] = IFFT_256( XB_blk[k] H_s[k] W_{256 R}^{k r} )[m]
+// kept for halo <= m < halo + hop.  16 columns per batch, 16 threads per column;
+// amplitudes are staged in LDS and stored as contiguous runs.
+// grid (n_items, C)
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
+  __shared__ float ex_re[16 * kExCol];
+  __shared__ float ex_im[16 * kExCol];
+  __shared__ __attribute__((aligned(16))) float tile[(MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1) * 16 * 256];
+  constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;  // floats per output sample
+
+  const SynthItemDev it = a.items[blockIdx.x];
+  const SynthLevelDev lv = a.levels[it.level];
+  const int c = blockIdx.y;
+  const int R = lv.decimation, hop = lv.hop, halo = lv.halo;
+  const int colw = threadIdx.x >> 4, t = threadIdx.x & 15;
+
+  cf tw[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tw[j] = a.tw256[(t * j) & 255];
+
+  cf hk[16];
+  const cf* bank = a.bank + (int64_t)it.scale * 256 + t;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) hk[j] = bank[16 * j];
+
+  const cf* xb = a.xb + (int64_t)c * a.xb_cstride + lv.xb_offset;
+  const cf* ltw = a.level_tw + lv.tw_offset;
+  float* out = a.out + ((int64_t)c * a.n_scales + it.scale) * a.n_samples * kElem +
+               a.epoch_start * kElem;
+
+  const int ncols = it.nblk * R;
+  // per batch geometry of the staged tile
+  const int row_stride = R <= 16 ? 16 : R;  // global distance (samples) between tile rows of 16
+  for (int col0 = 0; col0 < ncols; col0 += 16) {
+    const int col = col0 + colw;
+    const bool valid = col < ncols;
+    const int blk_l = col / R;           // block within the item
+    const int r = col - blk_l * R;
+    const int blk = it.blk0 + blk_l;
+
+    cf v[16];
+    if (valid) {
+      const cf* xbp = xb + (int64_t)blk * 256 + t;
+      // W^{(t + 16 j) r} = W^{t r} (W^{16 r})^j, W = exp(2 pi i/(256 R)); both factors
+      // come from the level table (indices t r and 16 r are below 16 R)
+      cf wcur = ltw[t * r];
+      const cf wstep = ltw[16 * r];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        v[j] = cmul(cmul(xbp[16 * j], hk[j]), wcur);
+        wcur = cmul(wcur, wstep);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = make_float2(0.f, 0.f);
+    }
+    fft256_16t<1>(v, tw, ex_re + colw * kExCol, ex_im + colw * kExCol, t);
+
+    // stage: sample (m = t + 16 j, r) -> tile
+    const int blk_b = (col0 / R);        // first block (within item) of this batch when R <= 16
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int m = t + 16 * j - halo;
+        if (m >= 0 && m < hop) {
+          int q;
+          if (R <= 16) q = ((blk_l - blk_b) * hop + m) * R + r;
+          else q = m * 16 + (r & 15);
+          if (MODE == GCWT_OUT_AMPLITUDE_F32) tile[q] = sqrtf(v[j].x * v[j].x + v[j].y * v[j].y);
+          else if (MODE == GCWT_OUT_POWER_F32) tile[q] = v[j].x * v[j].x + v[j].y * v[j].y;
+          else { tile[2 * q] = v[j].x; tile[2 * q + 1] = v[j].y; }
+        }
+      }
+    }
+    __syncthreads();
+    // copy out: tile element q lives at global sample n(q) = n0 + (q/16)*row_stride + q%16
+    {
+      int64_t n0;
+      int count;  // staged samples
+      if (R <= 16) {
+        const int nb = min(16 / R, it.nblk - blk_b);
+        n0 = (int64_t)(it.blk0 + blk_b) * hop * R;
+        count = nb * hop * R;
+      } else {
+        const int blk_cur = it.blk0 + col0 / R;
+        const int r0 = col0 % R;
+        n0 = (int64_t)blk_cur * hop * R + r0;
+        count = hop * 16;
+      }
+      for (int q = threadIdx.x; q < count; q += 256) {
+        const int64_t n = n0 + (int64_t)(q >> 4) * row_stride + (q & 15);
+        if (n < a.epoch_len) {
+          if (kElem == 1) out[n] = tile[q];
+          else { out[2 * n] = tile[2 * q]; out[2 * n + 1] = tile[2 * q + 1]; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Direct scales: W[n] = sum_j (x[n + (L-1)/2 - j] - mean) psi[j] inside the epoch
+// (convolution.py:68-87 'same' crop; transforms.py:202-204).  grid (ceil(ne/256), n_direct, C)
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, float* __restrict__ out,
+                                                const cf* __restrict__ psi,
+                                                const DirectScale* __restrict__ sc,
+                                                const double* __restrict__ sums, double inv_n,
+                                                int64_t n_samples, int n_scales,
+                                                int64_t epoch_start, int64_t epoch_len) {
+  constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
+  const DirectScale p = sc[blockIdx.y];
+  const int c = blockIdx.z;
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= epoch_len) return;
+  const float mean = (float)(sums[c] * inv_n);
+  const float* xe = x + (int64_t)c * n_samples + epoch_start;
+  const cf* k = psi + p.offset;
+  const int64_t top = n + (p.length - 1) / 2;
+  float re = 0.f, im = 0.f;
+  for (int64_t j = 0; j < p.length; ++j) {
+    const int64_t m = top - j;
+    if (m >= 0 && m < epoch_len) {
+      const float xv = xe[m] - mean;
+      re += xv * k[j].x;
+      im += xv * k[j].y;
+    }
+  }
+  float* o = out + ((int64_t)c * n_scales + p.scale) * n_samples * kElem + (epoch_start + n) * kElem;
+  if (MODE == GCWT_OUT_AMPLITUDE_F32) o[0] = sqrtf(re * re + im * im);
+  else if (MODE == GCWT_OUT_POWER_F32) o[0] = re * re + im * im;
+  else { o[0] = re; o[1] = im; }
+}
+
+// zero [start, stop) of every (channel, scale) row.  grid (ceil(len/256), C*S)
+__global__ void k_zero_range(float* __restrict__ out, int64_t row_len_floats, int64_t start,
+                             int64_t len) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < len) out[(int64_t)blockIdx.y * row_len_floats + start + i] = 0.f;
+}
+
+// ===========================================================================
+// launch wrappers
+// ===========================================================================
+#define GCWT_LAUNCH_CHECK()                      \
+  do {                                           \
+    hipError_t e_ = hipGetLastError();           \
+    if (e_ != hipSuccess) return e_;             \
+  } while (0)
+
+static int ilog2(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return l; }
+
+hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,
+                              hipStream_t st) {
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * n_channels, st);
+  if (e != hipSuccess) return e;
+  int parts = (int)std::min<int64_t>(64, (n + 256 * 16 - 1) / (256 * 16));
+  if (parts < 1) parts = 1;
+  hipLaunchKernelGGL(k_channel_sum, dim3(parts, n_channels), dim3(256), 0, st, x, n, sums);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_build_bank(cf* bank, const BankScale* sc, int n_scales, int B, double gamma,
+                             double beta, double w0, hipStream_t st) {
+  hipLaunchKernelGGL(k_build_bank, dim3(n_scales), dim3(B), 0, st, bank, sc, B, gamma, beta, w0);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_build_direct(cf* psi, const DirectScale* sc, int n_direct, int64_t max_len,
+                               double gamma, double beta, double w0, hipStream_t st) {
+  if (n_direct == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_build_direct, dim3(n_direct, (unsigned)((max_len + 255) / 256)), dim3(256),
+                     0, st, psi, sc, gamma, beta, w0);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int len, int ld,
+                           int64_t in_cstride, int64_t out_cstride, int64_t tw_n, const cf* tw4096,
+                           const double* sums, double inv_n, int64_t n_valid, int n_channels,
+                           hipStream_t st) {
+  const size_t lds = (size_t)len * 16 * sizeof(cf);
+  dim3 grid(ld / 16, n_channels), block(256);
+  const int l2 = ilog2(len);
+#define GCWT_COLS(S, RI)                                                                          \
+  {                                                                                               \
+    if (lds > 48 * 1024) {                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void*)k_fft_cols<S, RI>,                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+      if (e != hipSuccess) return e;                                                              \
+    }                                                                                             \
+    hipLaunchKernelGGL((k_fft_cols<S, RI>), grid, block, lds, st, in, out, len, l2, ld,           \
+                       in_cstride, out_cstride, tw_n, tw4096, sums, inv_n, n_valid);              \
+  }
+  if (sign < 0 && real_in) GCWT_COLS(-1, true)
+  else if (sign < 0) GCWT_COLS(-1, false)
+  else if (real_in) GCWT_COLS(1, true)
+  else GCWT_COLS(1, false)
+#undef GCWT_COLS
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_fft_rows(int sign, const cf* in, cf* out, int len, int64_t n_rows, int64_t in_ld,
+                           int64_t out_ld, int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
+                           const cf* tw4096, float scale, int n_channels, hipStream_t st) {
+  const int l2 = ilog2(len);
+  const int rows = kRowLenDev / len;
+  dim3 grid((unsigned)((n_rows + rows - 1) / rows), n_channels), block(256);
+  if (sign < 0)
+    hipLaunchKernelGGL((k_fft_rows<-1>), grid, block, 0, st, in, out, len, l2, in_ld, out_ld,
+                       in_cstride, out_cstride, tw_n, tw4096, scale, (int)n_rows);
+  else
+    hipLaunchKernelGGL((k_fft_rows<1>), grid, block, 0, st, in, out, len, l2, in_ld, out_ld,
+                       in_cstride, out_cstride, tw_n, tw4096, scale, (int)n_rows);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_block_fft(const cf* xr, cf* xb, int64_t m, int hop, int halo, int nblk,
+                            int64_t xr_cstride, int64_t xb_cstride, const cf* tw256, float scale,
+                            int n_channels, hipStream_t st) {
+  dim3 grid((nblk + 15) / 16, n_channels), block(256);
+  hipLaunchKernelGGL(k_block_fft, grid, block, 0, st, xr, xb, m - 1, hop, halo, nblk, xr_cstride,
+                     xb_cstride, tw256, scale);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_synth(int mode, const SynthArgs& a, int n_items, int n_channels, hipStream_t st) {
+  if (n_items == 0) return hipSuccess;
+  dim3 grid(n_items, n_channels), block(256);
+  if (mode == GCWT_OUT_AMPLITUDE_F32)
+    hipLaunchKernelGGL((k_synth<GCWT_OUT_AMPLITUDE_F32>), grid, block, 0, st, a);
+  else if (mode == GCWT_OUT_POWER_F32)
+    hipLaunchKernelGGL((k_synth<GCWT_OUT_POWER_F32>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((k_synth<GCWT_OUT_COMPLEX_C64>), grid, block, 0, st, a);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, const DirectScale* sc,
+                         int n_direct, const double* sums, double inv_n, int64_t n_samples,
+                         int n_scales, int64_t epoch_start, int64_t epoch_len, int n_channels,
+                         hipStream_t st) {
+  if (n_direct == 0) return hipSuccess;
+  dim3 grid((unsigned)((epoch_len + 255) / 256), n_direct, n_channels), block(256);
+#define GCWT_DIRECT(M)                                                                       \
+  hipLaunchKernelGGL((k_direct<M>), grid, block, 0, st, x, out, psi, sc, sums, inv_n,        \
+                     n_samples, n_scales, epoch_start, epoch_len)
+  if (mode == GCWT_OUT_AMPLITUDE_F32) GCWT_DIRECT(GCWT_OUT_AMPLITUDE_F32);
+  else if (mode == GCWT_OUT_POWER_F32) GCWT_DIRECT(GCWT_OUT_POWER_F32);
+  else GCWT_DIRECT(GCWT_OUT_COMPLEX_C64);
+#undef GCWT_DIRECT
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_zero_range(float* out, int64_t row_len_floats, int64_t n_rows, int64_t start,
+                             int64_t len, hipStream_t st) {
+  if (len <= 0) return hipSuccess;
+  // n_rows can exceed 65535: split over calls
+  for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
+    const int64_t nr = std::min<int64_t>(65535, n_rows - r0);
+    dim3 grid((unsigned)((len + 255) / 256), (unsigned)nr), block(256);
+    hipLaunchKernelGGL(k_zero_range, grid, block, 0, st, out + r0 * row_len_floats, row_len_floats,
+                       start, len);
+    GCWT_LAUNCH_CHECK();
+  }
+  return hipSuccess;
+}
+
+}  // namespace gcwt

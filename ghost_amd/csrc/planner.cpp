@@ -1,0 +1,188 @@
+// planner.cpp -- see planner.h
+#include "planner.h"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+
+namespace gcwt {
+
+double morse_log_gain(double u, double gamma, double beta) {
+  return beta * std::log(u) - (beta / gamma) * (std::pow(u, gamma) - 1.0);
+}
+
+static void band_edges(double gamma, double beta, double eps, double* u_lo, double* u_hi) {
+  const double target = std::log(eps);
+  double lo = 1e-9, hi = 1.0;
+  for (int i = 0; i < 200; ++i) {
+    double mid = 0.5 * (lo + hi);
+    if (morse_log_gain(mid, gamma, beta) < target) lo = mid; else hi = mid;
+  }
+  *u_lo = lo;
+  lo = 1.0; hi = 64.0;
+  for (int i = 0; i < 200; ++i) {
+    double mid = 0.5 * (lo + hi);
+    if (morse_log_gain(mid, gamma, beta) < target) hi = mid; else lo = mid;
+  }
+  *u_hi = hi;
+}
+
+static int64_t next_pow2(int64_t v) {
+  int64_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
+  auto fail = [&](int code, const std::string& msg) { *err = msg; return code; };
+
+  if (prm.n_samples <= 0) return fail(GCWT_ERR_INVALID, "n_samples must be positive");
+  if (prm.n_channels <= 0) return fail(GCWT_ERR_INVALID, "n_channels must be positive");
+  if (prm.n_channels > 65535) return fail(GCWT_ERR_UNSUPPORTED, "n_channels > 65535 per plan");
+  if (prm.n_freqs <= 0 || !prm.freqs_hz) return fail(GCWT_ERR_INVALID, "no analysis frequencies");
+  if (!(prm.fs > 0)) return fail(GCWT_ERR_INVALID, "Sampling rate must be positive");
+  if (!(prm.gamma > 0)) return fail(GCWT_ERR_INVALID, "gamma must be positive");
+  if (!(prm.beta > 0)) return fail(GCWT_ERR_INVALID, "beta must be positive");
+  if (prm.out_mode < 0 || prm.out_mode > 2) return fail(GCWT_ERR_INVALID, "bad out_mode");
+  if (prm.block != 0 && prm.block != 256)
+    return fail(GCWT_ERR_UNSUPPORTED, "only block = 256 is built");
+
+  hp->prm = prm;
+  hp->block = 256;
+  hp->band_eps = prm.band_eps > 0 ? prm.band_eps : 1e-9;
+  if (hp->band_eps > 1e-3) return fail(GCWT_ERR_INVALID, "band_eps too large");
+  hp->freqs.assign(prm.freqs_hz, prm.freqs_hz + prm.n_freqs);
+  hp->out_elem_bytes = prm.out_mode == GCWT_OUT_COMPLEX_C64 ? 8 : 4;
+
+  // epochs
+  if (prm.n_epochs <= 0 || !prm.epoch_bounds) {
+    hp->bounds = {0, prm.n_samples};
+  } else {
+    hp->bounds.assign(prm.epoch_bounds, prm.epoch_bounds + 2 * (size_t)prm.n_epochs);
+  }
+  const int n_ep = (int)hp->bounds.size() / 2;
+  for (int e = 0; e < n_ep; ++e) {
+    int64_t s = hp->bounds[2 * e], t = hp->bounds[2 * e + 1];
+    if (s < 0 || t > prm.n_samples || t <= s)
+      return fail(GCWT_ERR_INVALID, "epoch bounds outside the data or empty");
+  }
+
+  const double g = prm.gamma, b = prm.beta;
+  hp->w0 = std::exp((std::log(b) - std::log(g)) / g);                 // morseutils.py:315
+  hp->base_length = (2.0 * std::sqrt(2.0) * std::sqrt(g * b)) / hp->w0 * 4.0;  // morse.py:115
+  band_edges(g, b, hp->band_eps, &hp->u_lo, &hp->u_hi);
+
+  const int B = hp->block;
+  hp->scales.resize(prm.n_freqs);
+  int64_t lmax_spec = 1;
+  for (int i = 0; i < prm.n_freqs; ++i) {
+    ScalePlan& sp = hp->scales[i];
+    sp.freq_hz = hp->freqs[i];
+    if (!(sp.freq_hz > 0)) return fail(GCWT_ERR_INVALID, "analysis frequencies must be positive");
+    sp.omega = sp.freq_hz / (prm.fs / 2.0) * M_PI;                    // transforms.py:408-410
+    sp.length = (int64_t)std::ceil(hp->w0 / sp.omega * hp->base_length);  // morse.py:118-122
+    if (sp.length < 1) sp.length = 1;
+    sp.half_delay = (double)(sp.length - 1) / 2.0 - (double)((sp.length - 1) / 2);
+    if (hp->u_hi * sp.omega > M_PI) {
+      sp.method = GCWT_SCALE_DIRECT;
+      sp.direct_index = hp->n_direct++;
+      sp.direct_offset = hp->direct_total;
+      hp->direct_total += sp.length;
+      if (sp.length > 65536)
+        return fail(GCWT_ERR_UNSUPPORTED, "a scale whose filter reaches Nyquist has a kernel "
+                                          "longer than 65536 taps");
+    } else {
+      sp.method = GCWT_SCALE_SPECTRAL;
+      lmax_spec = std::max(lmax_spec, sp.length);
+    }
+  }
+
+  // per-epoch FFT length
+  hp->epochs.resize(n_ep);
+  int64_t pmin = INT64_MAX;
+  for (int e = 0; e < n_ep; ++e) {
+    EpochPlan& ep = hp->epochs[e];
+    ep.start = hp->bounds[2 * e];
+    ep.stop = hp->bounds[2 * e + 1];
+    ep.ne = ep.stop - ep.start;
+    ep.p = std::max<int64_t>(kRowLen, next_pow2(ep.ne + lmax_spec));
+    if (ep.p > (int64_t)kRowLen * kMaxP1)
+      return fail(GCWT_ERR_UNSUPPORTED,
+                  "epoch + kernel longer than 2^22 samples: split the recording into "
+                  "time blocks (streaming front end is not built yet)");
+    ep.p1 = (int)(ep.p / kRowLen);
+    pmin = std::min(pmin, ep.p);
+    hp->max_p = std::max(hp->max_p, ep.p);
+  }
+
+  // decimation factor per spectral scale, levels
+  const int r_cap = (int)std::min<int64_t>(kMaxDecimation, pmin / B);
+  std::map<int, int> level_of_r;
+  for (int i = 0; i < prm.n_freqs; ++i) {
+    ScalePlan& sp = hp->scales[i];
+    if (sp.method != GCWT_SCALE_SPECTRAL) continue;
+    int r = 2;  // u_hi*omega <= pi holds here, so R = 2 always fits
+    while (2 * r <= r_cap && hp->u_hi * sp.omega * (2.0 * r) <= 2.0 * M_PI) r *= 2;
+    sp.decimation = r;
+    auto it = level_of_r.find(r);
+    if (it == level_of_r.end()) {
+      LevelPlan lp;
+      lp.decimation = r;
+      level_of_r[r] = (int)hp->levels.size();
+      hp->levels.push_back(lp);
+      it = level_of_r.find(r);
+    }
+    sp.level = it->second;
+    LevelPlan& lp = hp->levels[sp.level];
+    lp.scales.push_back(i);
+    int halo = (int)((sp.length + 2 * r - 1) / (2 * r)) + 2;
+    lp.halo = std::max(lp.halo, halo);
+  }
+  for (LevelPlan& lp : hp->levels) {
+    lp.hop = B - 2 * lp.halo;
+    if (lp.hop < 32)
+      return fail(GCWT_ERR_UNSUPPORTED,
+                  "a wavelet is too long for the 256-sample decimated block at the largest "
+                  "decimation this build supports (256): lowest frequency too low for fs");
+    lp.twiddle_offset = hp->level_twiddle_total;
+    hp->level_twiddle_total += (int64_t)kSynthCols * lp.decimation;
+  }
+
+  // per-epoch level grids and synthesis work items
+  for (EpochPlan& ep : hp->epochs) {
+    ep.lv.resize(hp->levels.size());
+    int64_t xr = 0, xb = 0;
+    for (size_t l = 0; l < hp->levels.size(); ++l) {
+      const LevelPlan& lp = hp->levels[l];
+      EpochLevel& el = ep.lv[l];
+      el.m = ep.p / lp.decimation;
+      int64_t n_dec = (ep.ne + lp.decimation - 1) / lp.decimation;
+      el.nblk = (int)((n_dec + lp.hop - 1) / lp.hop);
+      el.xr_offset = xr;
+      el.xb_offset = xb;
+      xr += el.m;
+      xb += (int64_t)el.nblk * B;
+      const int group = std::max(1, 64 / lp.decimation);
+      for (int b0 = 0; b0 < el.nblk; b0 += group) {
+        for (int s : lp.scales) {
+          SynthItem it{(int32_t)l, (int32_t)s, (int32_t)b0,
+                       (int32_t)std::min(group, el.nblk - b0)};
+          ep.items.push_back(it);
+        }
+      }
+    }
+    ep.xr_total = xr;
+    ep.xb_total = xb;
+    hp->max_xr = std::max(hp->max_xr, xr);
+    hp->max_xb = std::max(hp->max_xb, xb);
+  }
+
+  const int64_t C = prm.n_channels;
+  hp->workspace_bytes = 8 * C * (hp->max_p + hp->max_xr + hp->max_xb)   // X, x_R, XB
+                        + 8 * (int64_t)prm.n_freqs * B                  // bank
+                        + 8 * (hp->direct_total + hp->level_twiddle_total + kRowLen + 256)
+                        + 16 * C;
+  return GCWT_OK;
+}
+
+}  // namespace gcwt

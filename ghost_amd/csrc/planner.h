@@ -1,0 +1,89 @@
+// planner.h -- host-side planning for the CWT engine (no device code).
+//
+// Decides, for every analysis frequency, how it is evaluated (closed-form
+// spectral filter on a decimated block grid, or literal time-domain kernel),
+// and lays out the per-epoch FFT sizes, decimation levels and block grids.
+// Mirrors the set-up part of ghost/wave/transforms.py:179-185 and the length
+// rule of ghost/wave/morse.py:108-122; the block/decimation layout is this
+// engine's own.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ghostcwt.h"
+
+namespace gcwt {
+
+constexpr int kRowLen = 4096;      // row length of the two-pass big FFT (P = P1 * 4096)
+constexpr int kMaxP1 = 1024;       // P <= 2^22
+constexpr int kMaxDecimation = 256;
+constexpr int kSynthCols = 16;     // columns (block, r) per synthesis batch
+
+struct ScalePlan {
+  double freq_hz = 0, omega = 0;   // omega = f / (fs/2) * pi   (transforms.py:408-410)
+  int64_t length = 0;              // L = ceil(w0/omega * base) (morse.py:108-122)
+  int method = GCWT_SCALE_SPECTRAL;
+  int decimation = 1;              // R
+  int level = -1;                  // index into HostPlan::levels
+  double half_delay = 0;           // d = (L-1)/2 - (L-1)//2
+  int direct_index = -1;           // index among direct scales
+  int64_t direct_offset = 0;       // offset of psi in the direct-kernel buffer (complex elems)
+};
+
+struct LevelPlan {
+  int decimation = 1;              // R
+  int halo = 0;                    // Lh, decimated samples discarded at each block edge
+  int hop = 0;                     // B - 2*Lh valid decimated samples per block
+  std::vector<int> scales;         // scale indices evaluated on this level
+  int64_t twiddle_offset = 0;      // offset into the level twiddle table (complex elems)
+};
+
+struct EpochLevel {
+  int64_t m = 0;                   // decimated length M = P / R
+  int nblk = 0;
+  int64_t xr_offset = 0;           // per-channel offsets, complex elements
+  int64_t xb_offset = 0;
+};
+
+struct SynthItem {                 // one workgroup of the synthesis kernel
+  int32_t level, scale, blk0, nblk;
+};
+
+struct EpochPlan {
+  int64_t start = 0, stop = 0, ne = 0;
+  int64_t p = 0;                   // FFT length of this epoch
+  int p1 = 0;                      // p = p1 * kRowLen
+  std::vector<EpochLevel> lv;      // one per HostPlan::levels
+  std::vector<SynthItem> items;
+  int64_t xr_total = 0, xb_total = 0;  // per-channel complex elements
+};
+
+struct HostPlan {
+  gcwt_params prm{};
+  std::vector<double> freqs;
+  std::vector<int64_t> bounds;
+  int block = 256;                 // B
+  double band_eps = 1e-9;
+  double w0 = 0;                   // (beta/gamma)^(1/gamma)          (morseutils.py:315)
+  double base_length = 0;          // 2 sqrt2 sqrt(gamma beta)/w0 * 4 (morse.py:115-116)
+  double u_lo = 0, u_hi = 0;       // filter support [u_lo, u_hi] * omega at band_eps
+  std::vector<ScalePlan> scales;
+  std::vector<LevelPlan> levels;
+  std::vector<EpochPlan> epochs;
+  int n_direct = 0;
+  int64_t direct_total = 0;        // complex elements of all direct kernels
+  int64_t level_twiddle_total = 0;
+  int64_t max_p = 0, max_xr = 0, max_xb = 0;
+  size_t out_elem_bytes = 4;
+  int64_t workspace_bytes = 0;
+};
+
+// Returns GCWT_OK or a negative status with *err filled.
+int build_host_plan(const gcwt_params& prm, HostPlan* plan, std::string* err);
+
+// Relative gain of the Morse filter at u times its peak frequency, as a log:
+// beta ln u - (beta/gamma)(u^gamma - 1).
+double morse_log_gain(double u, double gamma, double beta);
+
+}  // namespace gcwt

@@ -1,0 +1,199 @@
+"""Thin Python handle on a libghostcwt plan (host side of the C ABI).
+
+``CwtPlan`` is what ``ContinuousWaveletTransform.transform`` drives; bench.py
+and the tests use it directly for device-resident runs.  All arithmetic happens
+in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+__all__ = ["CwtPlan", "DeviceBuffer", "device_count", "device_name"]
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib.gcwt_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    check(lib.gcwt_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes owned by Python."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        check(lib.gcwt_device_malloc(C.byref(self.ptr), self.nbytes))
+
+    def upload(self, array, offset_bytes=0):
+        a = np.ascontiguousarray(array)
+        assert offset_bytes + a.nbytes <= self.nbytes
+        dst = C.c_void_p(self.ptr.value + offset_bytes)
+        check(lib.gcwt_memcpy_h2d(dst, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def download(self, shape, dtype, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        src = C.c_void_p(self.ptr.value + offset_bytes)
+        check(lib.gcwt_memcpy_d2h(out.ctypes.data_as(C.c_void_p), src, out.nbytes))
+        return out
+
+    def zero(self):
+        check(lib.gcwt_device_memset(self.ptr, 0, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            lib.gcwt_device_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+_OUT_DTYPE = {_lib.OUT_AMPLITUDE: np.float32, _lib.OUT_POWER: np.float32,
+              _lib.OUT_COMPLEX: np.complex64}
+_OUT_MODES = {"amplitude": _lib.OUT_AMPLITUDE, "power": _lib.OUT_POWER,
+              "complex": _lib.OUT_COMPLEX}
+
+
+class CwtPlan:
+    """One (n_channels, n_samples, frequencies, epochs) transform layout.
+
+    Parameters mirror ``gcwt_params``; ``freqs_hz`` are the Morse peak
+    frequencies in the order the output rows are wanted."""
+
+    def __init__(self, n_samples, n_channels, fs, freqs_hz, *, gamma=3.0, beta=20.0,
+                 epoch_bounds=None, output="amplitude", device=-1, band_eps=0.0, block=0):
+        self._handle = C.c_void_p()
+        self.freqs = np.ascontiguousarray(freqs_hz, dtype=np.float64)
+        if epoch_bounds is None:
+            epoch_bounds = [[0, n_samples]]
+        self.bounds = np.ascontiguousarray(epoch_bounds, dtype=np.int64).reshape(-1, 2)
+        self.out_mode = _OUT_MODES[output] if isinstance(output, str) else int(output)
+        p = _lib.Params()
+        p.n_samples = int(n_samples)
+        p.n_channels = int(n_channels)
+        p.n_freqs = int(self.freqs.size)
+        p.fs = float(fs)
+        p.gamma = float(gamma)
+        p.beta = float(beta)
+        p.freqs_hz = self.freqs.ctypes.data_as(C.POINTER(C.c_double))
+        p.n_epochs = int(self.bounds.shape[0])
+        p.out_mode = self.out_mode
+        p.epoch_bounds = self.bounds.ctypes.data_as(C.POINTER(C.c_int64))
+        p.device = int(device)
+        p.block = int(block)
+        p.band_eps = float(band_eps)
+        check(lib.gcwt_plan_create(C.byref(self._handle), C.byref(p)))
+        self.n_samples, self.n_channels = int(n_samples), int(n_channels)
+        self.n_freqs = int(self.freqs.size)
+        self.out_shape = (self.n_channels, self.n_freqs, self.n_samples)
+        self.out_dtype = _OUT_DTYPE[self.out_mode]
+
+    # -- description ------------------------------------------------------
+    @property
+    def info(self):
+        i = _lib.PlanInfo()
+        check(lib.gcwt_plan_get_info(self._handle, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in _lib.PlanInfo._fields_}
+
+    def scale_info(self):
+        s = self.n_freqs
+        method = np.zeros(s, np.int32)
+        dec = np.zeros(s, np.int32)
+        halo = np.zeros(s, np.int32)
+        hop = np.zeros(s, np.int32)
+        length = np.zeros(s, np.int64)
+        i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        check(lib.gcwt_plan_scale_info(self._handle, method.ctypes.data_as(i32p),
+                                       dec.ctypes.data_as(i32p), halo.ctypes.data_as(i32p),
+                                       hop.ctypes.data_as(i32p), length.ctypes.data_as(i64p)))
+        return {"method": method, "decimation": dec, "halo": halo, "hop": hop, "length": length}
+
+    # -- device -----------------------------------------------------------
+    def upload(self):
+        check(lib.gcwt_plan_upload(self._handle))
+
+    def set_profiling(self, on=True):
+        check(lib.gcwt_plan_set_profiling(self._handle, 1 if on else 0))
+
+    def timings(self):
+        t = _lib.Timings()
+        check(lib.gcwt_get_timings(self._handle, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _lib.Timings._fields_}
+
+    def execute(self, x):
+        """x: array-like (C, N) -> ndarray out_shape (host in, host out)."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.n_channels, self.n_samples)
+        out = np.empty(self.out_shape, dtype=self.out_dtype)
+        check(lib.gcwt_execute(self._handle, x.ctypes.data_as(C.c_void_p),
+                               out.ctypes.data_as(C.c_void_p), 0))
+        return out
+
+    def execute_device(self, x_buf, out_buf):
+        """Both buffers are DeviceBuffer (or raw c_void_p); returns when done."""
+        xp = x_buf.ptr if isinstance(x_buf, DeviceBuffer) else x_buf
+        op = out_buf.ptr if isinstance(out_buf, DeviceBuffer) else out_buf
+        check(lib.gcwt_execute(self._handle, xp, op, _lib.X_ON_DEVICE | _lib.OUT_ON_DEVICE))
+
+    def filter_bank(self):
+        b = self.info["block"]
+        out = np.empty((self.n_freqs, b), dtype=np.complex64)
+        check(lib.gcwt_filter_bank(self._handle, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def direct_kernel(self, scale):
+        n = int(self.scale_info()["length"][scale])
+        out = np.empty(n, dtype=np.complex64)
+        check(lib.gcwt_direct_kernel(self._handle, int(scale),
+                                     out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    # -- test hooks ---------------------------------------------------------
+    def debug_levels(self, epoch=0):
+        n = lib.gcwt_debug_level_count(self._handle)
+        res = []
+        for l in range(n):
+            d, h, hp, nb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            m = C.c_int64()
+            check(lib.gcwt_debug_level_info(self._handle, epoch, l, C.byref(d), C.byref(h),
+                                            C.byref(hp), C.byref(nb), C.byref(m)))
+            res.append({"decimation": d.value, "halo": h.value, "hop": hp.value,
+                        "nblk": nb.value, "m": m.value})
+        return res
+
+    def debug_fetch(self, what, channel=0, epoch=0, level=0):
+        lv = self.debug_levels(epoch)
+        if what == 0:
+            n = self.info["fft_length"]
+        elif what == 1:
+            n = lv[level]["m"]
+        else:
+            n = lv[level]["nblk"] * self.info["block"]
+        out = np.empty(n, dtype=np.complex64)
+        check(lib.gcwt_debug_fetch(self._handle, what, channel, epoch, level,
+                                   out.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return out
+
+    def close(self):
+        if self._handle:
+            lib.gcwt_plan_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

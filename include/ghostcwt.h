@@ -1,0 +1,166 @@
+/* ghostcwt.h -- C ABI of libghostcwt.so, the MI355X (gfx950) engine behind
+ * ghost_amd.wave.ContinuousWaveletTransform.transform().
+ *
+ * The reference (nelpy/ghost) has no FFI of its own: it is pure Python.  The
+ * seam this library replaces is the body of
+ *   ghost/wave/transforms.py:142-231   (mean removal, per-scale loop, abs)
+ * including everything that loop calls:
+ *   ghost/wave/morse.py:84-91, ghost/wave/morseutils.py:93-198   (Morse kernel)
+ *   ghost/sigtools/convolution.py:16-87 / 89-216                 (FFT convolution)
+ * Each entry point below names the reference lines whose work it does.  The
+ * Python class in ghost_amd/wave/transforms.py binds these with ctypes;
+ * INTEGRATION.md shows the stub a ghost maintainer would add.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a
+ * negative gcwt_status; nothing throws across the boundary; the message for the
+ * last failure on the calling thread is gcwt_last_error().  The caller owns all
+ * buffers it passes in.  A plan owns its device workspace and stream and must be
+ * used from one host thread at a time; different plans are independent.
+ */
+#ifndef GHOSTCWT_H
+#define GHOSTCWT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCWT_ABI_VERSION 1
+
+typedef enum {
+  GCWT_OK = 0,
+  GCWT_ERR_INVALID = -1,     /* bad argument (the reference raises ValueError)   */
+  GCWT_ERR_UNSUPPORTED = -2, /* valid request outside what this build handles     */
+  GCWT_ERR_NO_DEVICE = -3,   /* no HIP device / HIP runtime failure at init       */
+  GCWT_ERR_HIP = -4,         /* a HIP call failed; text in gcwt_last_error()      */
+  GCWT_ERR_NOMEM = -5,
+  GCWT_ERR_COMM = -6         /* RCCL unavailable or a collective failed           */
+} gcwt_status;
+
+/* What transform() keeps per coefficient.  The reference keeps abs() only
+ * (transforms.py:204); power is np.square of it (transforms.py:510). */
+typedef enum {
+  GCWT_OUT_AMPLITUDE_F32 = 0, /* |W|       float32 [C][S][N]                     */
+  GCWT_OUT_POWER_F32 = 1,     /* |W|^2     float32 [C][S][N]                     */
+  GCWT_OUT_COMPLEX_C64 = 2    /* W         float32 pairs (re,im) [C][S][N]       */
+} gcwt_out_mode;
+
+/* How a scale is evaluated (reported by gcwt_plan_scale_info). */
+typedef enum {
+  GCWT_SCALE_SPECTRAL = 0, /* closed-form one-sided filter, decimated block IFFT */
+  GCWT_SCALE_DIRECT = 1    /* literal L-tap kernel, time-domain (filter not
+                              negligible at Nyquist: SURVEY.md A.3)              */
+} gcwt_scale_method;
+
+enum {
+  GCWT_X_ON_DEVICE = 1,   /* gcwt_execute: x is a device pointer                 */
+  GCWT_OUT_ON_DEVICE = 2  /* gcwt_execute: out is a device pointer               */
+};
+
+typedef struct gcwt_plan gcwt_plan;
+
+typedef struct {
+  int64_t n_samples;           /* N, samples per channel                          */
+  int32_t n_channels;          /* C                                               */
+  int32_t n_freqs;             /* S                                               */
+  double fs;                   /* Hz                                              */
+  double gamma, beta;          /* Morse parameters (morse.py:45-51)               */
+  const double* freqs_hz;      /* [S] analysis (peak) frequencies, any order      */
+  int32_t n_epochs;            /* E >= 1                                          */
+  int32_t out_mode;            /* gcwt_out_mode                                   */
+  const int64_t* epoch_bounds; /* [2E] start,stop index pairs (transforms.py:202) */
+  int32_t device;              /* HIP ordinal; -1 = leave the current device      */
+  int32_t block;               /* decimated block length B; 0 = default (256)     */
+  double band_eps;             /* filter treated as 0 below eps*peak; 0 = 1e-9    */
+} gcwt_params;
+
+typedef struct {
+  int32_t abi_version;
+  int32_t n_levels;            /* distinct decimation factors in use              */
+  int32_t n_spectral, n_direct;
+  int32_t block;               /* B                                               */
+  int32_t max_decimation;      /* largest R                                       */
+  int64_t fft_length;          /* P of the longest epoch                          */
+  int64_t workspace_bytes;     /* device workspace the plan will allocate         */
+  int64_t out_bytes;           /* size of the out buffer gcwt_execute fills       */
+} gcwt_plan_info;
+
+/* Stage timings of the last gcwt_execute on a plan created with profiling on,
+ * in milliseconds, measured with HIP events on the plan's stream. */
+typedef struct {
+  float mean_ms;        /* per-channel mean (transforms.py:143)                   */
+  float fwd_fft_ms;     /* forward FFT of every epoch                             */
+  float decimate_ms;    /* per-level inverse FFTs producing x_R                   */
+  float block_fft_ms;   /* block spectra                                          */
+  float synth_ms;       /* fused filter * twiddle * IFFT * |.| * store  (dominant)*/
+  float direct_ms;      /* time-domain scales                                     */
+  float total_ms;       /* first kernel start to last kernel end                  */
+  int32_t synth_launches;
+  int32_t reserved;
+} gcwt_timings;
+
+/* Library / device ------------------------------------------------------- */
+int gcwt_abi_version(void);
+const char* gcwt_last_error(void);
+int gcwt_device_count(int* count);
+int gcwt_device_name(int device, char* buf, size_t buflen);
+int gcwt_set_device(int device);
+int gcwt_device_malloc(void** ptr, size_t bytes);
+int gcwt_device_free(void* ptr);
+int gcwt_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int gcwt_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int gcwt_device_memset(void* dst, int value, size_t bytes);
+int gcwt_device_synchronize(void);
+
+/* Planning: host only, touches no device.  Replaces the per-call setup of
+ * transforms.py:179-185 (wavelet lengths, output allocation) and decides, per
+ * scale, the decimation factor and block layout. */
+int gcwt_plan_create(gcwt_plan** out, const gcwt_params* params);
+void gcwt_plan_destroy(gcwt_plan* plan);
+int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info);
+/* Per-scale arrays of length S; any pointer may be NULL.  length[] is the
+ * reference kernel length L of morse.py:108-122. */
+int gcwt_plan_scale_info(const gcwt_plan* plan, int32_t* method, int32_t* decimation,
+                         int32_t* halo, int32_t* hop, int64_t* length);
+int gcwt_plan_set_profiling(gcwt_plan* plan, int enabled);
+
+/* Device side ------------------------------------------------------------ */
+/* Allocate workspace, build the Morse filter bank and FFT tables on the
+ * device.  Called implicitly by the first gcwt_execute.  Replaces the kernel
+ * construction of morse.py:84-91 / morseutils.py:93-198 for every scale. */
+int gcwt_plan_upload(gcwt_plan* plan);
+
+/* The transform: transforms.py:142-143 (global mean), :187-204 (per scale, per
+ * epoch convolution + abs) for every channel.  x: float32 [C][N] row-major.
+ * out: per out_mode, [C][S][N] row-major, scales in the order of freqs_hz.
+ * Samples outside every epoch are written as 0 (transforms.py:185). */
+int gcwt_execute(gcwt_plan* plan, const void* x, void* out, int flags);
+
+/* Filter bank as held on the device, for parity tests of the bank builder:
+ * bank: float32 (re,im) [S][B], H_s(2 pi k / (B R_s)), zero rows for direct
+ * scales.  Compare with the spectrum of morseutils.py:130-131. */
+int gcwt_filter_bank(gcwt_plan* plan, float* bank);
+/* Literal kernel of a direct scale: float32 (re,im) [L].  Compare with psi of
+ * morseutils.py:149. */
+int gcwt_direct_kernel(gcwt_plan* plan, int scale, float* psi);
+
+int gcwt_get_timings(const gcwt_plan* plan, gcwt_timings* t);
+
+/* Multi-GPU control plane (one process per GPU; RCCL over xGMI).  The data path
+ * has no collective: channels are sharded.  The filter bank is broadcast once
+ * from rank 0 as BASELINE.json asks; barrier/all-reduce exist for bench timing. */
+typedef struct gcwt_comm gcwt_comm;
+#define GCWT_COMM_ID_BYTES 128
+int gcwt_comm_unique_id(void* id128);
+int gcwt_comm_create(gcwt_comm** out, int rank, int n_ranks, const void* id128);
+void gcwt_comm_destroy(gcwt_comm* comm);
+int gcwt_comm_barrier(gcwt_comm* comm);
+int gcwt_comm_allreduce_max(gcwt_comm* comm, double* value);
+int gcwt_comm_broadcast_bank(gcwt_comm* comm, gcwt_plan* plan, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GHOSTCWT_H */

@@ -1,0 +1,27 @@
+/* ghostcwt_debug.h -- test-only hooks of libghostcwt.so: read back the
+ * intermediate buffers of the last gcwt_execute so each stage can be checked
+ * against the NumPy model in tests/decimated_model.py.  Not part of the drop-in
+ * surface. */
+#ifndef GHOSTCWT_DEBUG_H
+#define GHOSTCWT_DEBUG_H
+#include "ghostcwt.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  GCWT_DEBUG_SPECTRUM = 0,      /* X~[k1][k2] = X[k1 + P1 k2], P complex values          */
+  GCWT_DEBUG_DECIMATED = 1,     /* x_R of one level, M = P/R complex values (times P)    */
+  GCWT_DEBUG_BLOCK_SPECTRA = 2  /* XB[blk][k] of one level, nblk*B complex values        */
+};
+
+int gcwt_debug_level_count(const gcwt_plan* plan);
+int gcwt_debug_level_info(const gcwt_plan* plan, int epoch, int level, int32_t* decimation,
+                          int32_t* halo, int32_t* hop, int32_t* nblk, int64_t* m);
+int gcwt_debug_fetch(gcwt_plan* plan, int what, int channel, int epoch, int level, float* dst,
+                     int64_t max_complex);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
