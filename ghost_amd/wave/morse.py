@@ -1,0 +1,135 @@
+"""Generalized Morse wavelet object (reference: ghost/wave/morse.py:12-211).
+
+Holds ``fs, gamma, beta`` and the peak frequency; gives the frequency bounds and
+per-scale kernel lengths ``transform`` needs.  ``__call__`` returns the
+reference's L-point ``(psi, psif)`` pair for inspection/plotting; the engine
+itself never calls it (its filter bank is built on the GPU).
+"""
+import copy
+
+import numpy as np
+
+from .wavelet import Wavelet
+from . import morseutils
+
+__all__ = ["Morse"]
+
+
+class Morse(Wavelet):
+
+    def __init__(self, *, fs=None, freq=None, gamma=None, beta=None):
+        super().__init__()
+        self.fs = 1 if fs is None else fs
+        # the reference stores a plain attribute here (morse.py:41) and so never
+        # initialises the peak frequency; we set it as evidently intended
+        self.frequency = 0.25 * self.fs if freq is None else freq
+        self.gamma = 3 if gamma is None else gamma
+        self.beta = 20 if beta is None else beta
+
+    def __call__(self, length, *, normalization=None):
+        """(psi, psif) of ``length`` samples, 'bandpass' normalisation: peak of
+        the spectrum is 2 (morse.py:53-91 -> morseutils.py:93-198)."""
+        if length is None:
+            length = 16384
+        if length < 1:
+            raise ValueError("length must at least 1 but got {}".format(length))
+        if normalization is None:
+            normalization = "bandpass"
+        if normalization not in ("bandpass", "energy"):
+            raise ValueError("normalization must be 'bandpass' or 'energy' but got {}"
+                             .format(normalization))
+        if normalization == "energy":
+            raise NotImplementedError("'energy' normalisation is outside the transform() "
+                                      "path and is not built")
+        n = int(length)
+        g, b = self._gamma, self._beta
+        w0 = morseutils.morsefreq(g, b)
+        k = np.arange(n)
+        w = (2 * np.pi * k / n) * (w0 / self._norm_radian_freq)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            psif = 2 * np.exp(-b * np.log(w0) + w0 ** g + b * np.log(w) - w ** g)
+        psif[0] = 0.0
+        psif[round(n / 2):] = 0.0           # one-sided: bins 0..round(L/2)-1 (banker's round)
+        psi = np.fft.ifft(psif * np.exp(1j * np.pi * k * (n + 1) / n))
+        return psi, psif
+
+    def compute_freq_bounds(self, N, *, p=None, **kwargs):
+        """[lowest, highest] peak frequency (rad/sample) for N samples (morse.py:93-106)."""
+        p = 5 if p is None else p
+        wh = morseutils.morsehigh(self._gamma, self._beta, **kwargs)
+        w0 = morseutils.morsefreq(self._gamma, self._beta)
+        max_scale = int(np.floor(N / p)) / morseutils.base_length(self._gamma, self._beta)
+        return [w0 / max_scale, wh]
+
+    def compute_lengths(self, norm_radian_freqs):
+        """Kernel length per frequency: ceil(w0/omega * base) (morse.py:108-122)."""
+        w0 = morseutils.morsefreq(self._gamma, self._beta)
+        scale = w0 / norm_radian_freqs
+        return np.ceil(scale * morseutils.base_length(self._gamma, self._beta)).astype(int)
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def _norm_radians_to_hz(self, val):
+        return val / np.pi * self._fs / 2
+
+    def _hz_to_norm_radians(self, val):
+        return val / (self._fs / 2) * np.pi
+
+    @property
+    def fs(self):
+        return self._fs
+
+    @fs.setter
+    def fs(self, val):
+        if not val > 0:
+            raise ValueError("fs must be positive but got {}".format(val))
+        self._fs = val
+
+    @property
+    def frequency(self):
+        return self._freq
+
+    @frequency.setter
+    def frequency(self, val):
+        if not val > 0:          # the reference's range test only ever rejects <= 0 (morse.py:158)
+            raise ValueError("The frequency must be between 0 and the Nyquist frequency {} Hz"
+                             " but got {}".format(self._fs / 2, val))
+        self._freq = val
+        self._norm_radian_freq = self._hz_to_norm_radians(val)
+
+    @property
+    def norm_radian_freq(self):
+        return self._norm_radian_freq
+
+    @norm_radian_freq.setter
+    def norm_radian_freq(self, val):
+        if not val > 0:          # morse.py:174
+            raise ValueError("The normalized radian frequency must be between 0 and the"
+                             " Nyquist frequency pi but got {}".format(val))
+        self._norm_radian_freq = val
+        self._freq = self._norm_radians_to_hz(val)
+
+    @property
+    def gamma(self):
+        return self._gamma
+
+    @gamma.setter
+    def gamma(self, val):
+        if not val > 0:
+            raise ValueError("gamma must be positive")
+        self._gamma = val
+
+    @property
+    def beta(self):
+        return self._beta
+
+    @beta.setter
+    def beta(self, val):
+        if not val > 0:
+            raise ValueError("beta must be positive")
+        self._beta = val
+
+    @property
+    def time_bandwidth(self):
+        return self._gamma * self._beta

@@ -1,0 +1,172 @@
+"""Parity of the HIP engine, through the C ABI / class surface, against the
+golden vectors made from the reference and against the oracle (GPU).
+
+Gate (BASELINE.json): max_n |y - ref| / max_n |ref| <= 1e-5 per (channel, scale)
+on the complex coefficients, and the same on the amplitude."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import ghost_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _cwt(x, fs, **kw):
+    from ghost_amd.wave import ContinuousWaveletTransform
+    cwt = ContinuousWaveletTransform()
+    cwt.transform(x, fs=fs, **kw)
+    return cwt
+
+
+def _plan(x, fs, freqs, **kw):
+    from ghost_amd.engine import CwtPlan
+    x = np.atleast_2d(np.asarray(x, dtype=np.float32))
+    p = CwtPlan(x.shape[1], x.shape[0], fs, freqs, **kw)
+    return p, p.execute(x)
+
+
+def test_config1_public_api(golden):
+    """BASELINE config 1: 1 ch x 16384 @ 1 kHz, 32 scales, via transform()."""
+    g = golden("g1_config1.npz")
+    cwt = _cwt(g["x"], 1000.0, freq_limits=[5, 200], voices_per_octave=6)
+    np.testing.assert_allclose(cwt.frequencies, g["frequencies"], rtol=1e-14)
+    amp = cwt.amplitude
+    assert amp.shape == (32, 16384) and amp.dtype == np.float64
+    assert rel_err(amp[:, g["cols"]], g["amplitude_cols"]).max() < TOL
+    np.testing.assert_allclose(amp.max(axis=1), g["amplitude_rowmax"], rtol=1e-5)
+    assert amp.sum() == pytest.approx(float(g["amplitude_sum"]), rel=1e-6)
+    np.testing.assert_allclose(cwt.power, np.square(amp))
+    np.testing.assert_allclose(cwt.time, np.arange(16384) / 1000.0)
+
+
+def test_two_tone_known_answers(golden):
+    g = golden("g4b_two_tone.npz")
+    fs, n = 1000.0, 4096
+    t = np.arange(n) / fs
+    x = np.sin(2 * np.pi * 50 * t) + 0.5 * np.sin(2 * np.pi * 12 * t)
+    cwt = _cwt(x, fs, freq_limits=[10, 100], voices_per_octave=4)
+    np.testing.assert_allclose(cwt.amplitude[:, 2048], g["amplitude_col2048"], rtol=0, atol=2e-6)
+    assert cwt.amplitude.sum() == pytest.approx(float(g["amplitude_sum"]), rel=1e-6)
+    p, c = _plan(x, fs, [50.0, 12.0], output="complex")
+    idx = g["w_idx"]
+    np.testing.assert_allclose(c[0, 0, idx], g["w50"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(c[0, 1, idx], g["w12"], rtol=0, atol=2e-6)
+
+
+def test_small_complex_odd_and_even_lengths(golden):
+    g = golden("g2_complex_small.npz")
+    p, c = _plan(g["x"], float(g["fs"]), g["frequencies"], output="complex")
+    assert rel_err(c[0], g["coeffs"]).max() < TOL
+    p, a = _plan(g["x"], float(g["fs"]), g["frequencies"], output="amplitude")
+    assert rel_err(a[0], np.abs(g["coeffs"])).max() < TOL
+    p, pw = _plan(g["x"], float(g["fs"]), g["frequencies"], output="power")
+    assert rel_err(pw[0], np.abs(g["coeffs"]) ** 2).max() < 2 * TOL
+
+
+def test_two_epochs(golden):
+    """Epoch gap: independent zero-padded segments, global mean (transforms.py:143, :202)."""
+    g = golden("g5_two_epochs.npz")
+    cwt = _cwt(g["x"], float(g["fs"]), timestamps=g["timestamps"], output="complex")
+    np.testing.assert_allclose(cwt.frequencies, g["frequencies"], rtol=1e-14)
+    c = cwt.coefficients
+    assert rel_err(c[:, g["cols"]], g["complex_cols"]).max() < TOL
+    np.testing.assert_allclose(cwt.amplitude.max(axis=1), g["amplitude_rowmax"], rtol=1e-5)
+
+
+def test_near_nyquist_direct_path(golden):
+    """Scales whose filter is not negligible at Nyquist use the literal kernel."""
+    g = golden("g6_near_nyquist.npz")
+    p, c = _plan(g["x"], float(g["fs"]), g["frequencies"], output="complex")
+    assert p.scale_info()["method"].tolist() == [1, 1, 1, 1, 1]
+    assert rel_err(c[0], g["coeffs"]).max() < TOL
+
+
+def test_default_grid_mixes_direct_and_spectral(golden):
+    g = golden("g1_config1.npz")
+    x = g["x"]
+    f = orc.frequency_grid(1000.0, x.size)
+    ref = orc.cwt_complex(x.astype(np.float64), 1000.0, f[::5])
+    p, c = _plan(x, 1000.0, f[::5], output="complex")
+    m = p.scale_info()["method"]
+    assert m.min() == 0 and m.max() == 1
+    assert rel_err(c[0], ref).max() < TOL
+
+
+def test_multichannel_equals_per_channel_reference(golden):
+    g = golden("g8_multichannel.npz")
+    from ghost_amd.wave import ContinuousWaveletTransform
+    cwt = ContinuousWaveletTransform()
+    cwt.transform(g["x"], fs=1000.0, freq_limits=[20, 250], voices_per_octave=4,
+                  multichannel=True, dtype=np.float32)
+    np.testing.assert_allclose(cwt.frequencies, g["frequencies"], rtol=1e-14)
+    amp = cwt.amplitude
+    assert amp.shape == g["amplitude"].shape and amp.dtype == np.float32
+    for c in range(3):
+        assert rel_err(amp[c], g["amplitude"][c]).max() < TOL
+
+
+def test_config2_reduced(golden):
+    """BASELINE config 2 scale set (100 log-spaced 200..2 Hz), N = 65536."""
+    g = golden("g9_config2_reduced.npz")
+    p, c = _plan(g["x"], float(g["fs"]), g["frequencies"], output="complex")
+    err = rel_err(c[0][:, g["cols"]], g["complex_cols"].astype(np.complex128))
+    assert err.max() < TOL, err
+    np.testing.assert_allclose(np.abs(c[0]).max(axis=1), g["amplitude_rowmax"], rtol=2e-5)
+
+
+def test_edge_shapes_against_oracle():
+    """Odd lengths, tiny epochs, length-1-mod-hop sizes, constant and zero input."""
+    from ghost_amd.synthetic import lfp_channel
+    fs = 1000.0
+    for n, f in [(257, [100.0, 60.0]), (4097, [200.0, 33.3, 9.0]), (12345, [150.0, 7.5]),
+                 (70, [200.0])]:
+        x = lfp_channel(n, fs, channel=n % 7)
+        ref = orc.cwt_complex(x.astype(np.float64), fs, f)
+        p, c = _plan(x, fs, f, output="complex")
+        assert rel_err(c[0], ref).max() < TOL, (n, f)
+    p, a = _plan(np.full(3000, 3.25, np.float32), fs, [50.0, 10.0])
+    assert np.abs(a).max() < 1e-5          # constant input: mean removal leaves nothing
+    p, a = _plan(np.zeros(3000, np.float32), fs, [50.0, 10.0])
+    assert np.all(a == 0)
+
+
+def test_gap_between_epochs_is_zero():
+    from ghost_amd.synthetic import lfp_channel
+    fs = 1000.0
+    x = lfp_channel(9000, fs, 2)
+    eb = [[0, 4000], [5000, 9000]]                      # samples 4000..4999 belong to no epoch
+    p, c = _plan(x, fs, [80.0, 20.0], epoch_bounds=eb, output="complex")
+    assert np.all(c[0][:, 4000:5000] == 0)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, [80.0, 20.0], np.array(eb))
+    # the oracle removes the mean of the whole array, like the reference
+    assert rel_err(np.delete(c[0], np.s_[4000:5000], axis=1),
+                   np.delete(ref, np.s_[4000:5000], axis=1)).max() < TOL
+
+
+def test_full_size_properties():
+    """BASELINE config 2 at full size (1 x 1e6 x 100 scales): properties that do not
+    need the oracle at that size, plus an oracle spot-check on a few scales."""
+    from ghost_amd.synthetic import lfp
+    fs, n = 1000.0, 1000000
+    f = np.geomspace(200.0, 2.0, 100)
+    x = lfp(2, n, fs)
+    p, c = _plan(x, fs, f, output="complex")
+    # linearity: W(a x0 + b x1) = a W(x0) + b W(x1)
+    mix = (0.7 * x[0] - 1.3 * x[1]).astype(np.float32)
+    pm, cm = _plan(mix, fs, f, output="complex")
+    lin = 0.7 * c[0] - 1.3 * c[1]
+    assert rel_err(cm[0], lin).max() < 3e-6
+    # amplitude / power modes agree with |complex|
+    pa, a = _plan(x[:1], fs, f, output="amplitude")
+    assert rel_err(a[0], np.abs(c[0])).max() < 1e-6
+    # analytic filters: a pure tone at a scale's peak gives amplitude ~1 there, away from edges
+    t = np.arange(n) / fs
+    tone = np.sin(2 * np.pi * f[40] * t).astype(np.float32)
+    pt, at = _plan(tone, fs, f[40:41])
+    assert abs(at[0, 0, n // 2] - 1.0) < 1e-4
+    # oracle spot check (literal path) on three scales
+    sel = [0, 57, 99]
+    ref = orc.cwt_complex(x[0].astype(np.float64), fs, f[sel])
+    assert rel_err(c[0][sel], ref).max() < TOL

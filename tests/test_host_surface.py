@@ -1,0 +1,253 @@
+"""Host logic and the C-ABI surface (CPU only, no compute calls)."""
+import ctypes
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from ghost_amd import _lib
+from ghost_amd._lib import GhostCwtError
+from ghost_amd.engine import CwtPlan
+from ghost_amd.utils import get_contiguous_segments, is_sorted
+from ghost_amd.wave import ContinuousWaveletTransform, Morse, Wavelet
+from ghost_amd.wave import morseutils
+
+
+def _grid_only(cwt, *args, **kwargs):
+    """Run transform() far enough to build the grid; the device call itself may fail
+    on a CPU-only box (there is no CPU fallback, by design)."""
+    try:
+        cwt.transform(*args, **kwargs)
+    except GhostCwtError as e:
+        assert e.code == _lib.ERR_NO_DEVICE
+    return cwt.frequencies
+
+
+def test_abi_exports_every_declared_symbol():
+    declared = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(h).read()
+        declared |= set(re.findall(r"\b(gcwt_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 30
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(so, s)]
+    assert not missing, missing
+    assert _lib.lib.gcwt_abi_version() == 1
+
+
+def test_morse_scalars_and_lengths(golden):
+    g = golden("g4_scalars.npz")
+    assert morseutils.morsefreq(3, 20) == pytest.approx(float(g["morsefreq"]), rel=1e-15)
+    assert morseutils.morsehigh(3, 20) == pytest.approx(float(g["morsehigh"]), rel=1e-15)
+    assert morseutils.morsehigh(2, 8) == pytest.approx(float(g["morsehigh_g2_b8"]), rel=1e-15)
+    m = Morse()
+    for n, key in [(16384, "bounds_16384"), (1000000, "bounds_1e6"), (4096, "bounds_4096")]:
+        np.testing.assert_allclose(m.compute_freq_bounds(n), g[key], rtol=1e-15)
+    m.fs = 1000.0
+    np.testing.assert_array_equal(
+        m.compute_lengths(g["len_freqs_hz"] / 500.0 * np.pi), g["lengths_1khz"])
+    assert m.time_bandwidth == 60
+    assert isinstance(m, Wavelet) and repr(m) == "Morse"
+    c = m.copy()
+    c.gamma = 2
+    assert m.gamma == 3
+
+
+def test_morse_call_matches_reference_kernels(golden):
+    g = golden("g3_kernels.npz")
+    for L in (36, 40, 70, 279, 1163, 1395):
+        m = Morse(fs=1000.0)
+        m.norm_radian_freq = float(g["omega_%d" % L])
+        psi, psif = m(L)
+        np.testing.assert_allclose(psif, g["psif_%d" % L], rtol=1e-12, atol=1e-300)
+        assert np.abs(psi - g["psi_%d" % L]).max() < 1e-13 * np.abs(g["psi_%d" % L]).max()
+    with pytest.raises(ValueError):
+        Morse()(0)
+    with pytest.raises(ValueError):
+        Morse()(10, normalization="nope")
+    for bad in (dict(fs=0), dict(gamma=-1), dict(beta=0), dict(freq=-3)):
+        with pytest.raises(ValueError):
+            Morse(**bad)
+
+
+def test_frequency_grid_matches_reference(golden):
+    g1 = golden("g1_config1.npz")
+    x = g1["x"].astype(np.float64)
+    cwt = ContinuousWaveletTransform()
+    f = _grid_only(cwt, x, fs=1000.0, freq_limits=[5, 200], voices_per_octave=6)
+    np.testing.assert_allclose(f, g1["frequencies"], rtol=1e-14)
+    assert np.all(np.diff(f) < 0)                      # descending
+    g4 = golden("g4_scalars.npz")
+    f = _grid_only(ContinuousWaveletTransform(), x, fs=1000.0)
+    np.testing.assert_allclose(f, g4["default_grid_16384"], rtol=1e-14)
+    gb = golden("g4b_two_tone.npz")
+    f = _grid_only(ContinuousWaveletTransform(), np.zeros(4096), fs=1000.0,
+                   freq_limits=[10, 100], voices_per_octave=4)
+    np.testing.assert_allclose(f, gb["frequencies"], rtol=1e-14)   # floor clamped to 17.03 Hz
+    # explicit list: sorted ascending, clamped to the valid range (intent of transforms.py:151-158)
+    f = _grid_only(ContinuousWaveletTransform(), np.zeros(4096), fs=1000.0,
+                   freqs=[300.0, 50.0, 1.0, 20.0, 450.0])
+    np.testing.assert_array_equal(f, [20.0, 50.0, 300.0])
+
+
+def test_two_epoch_grid_uses_shortest_epoch(golden):
+    g = golden("g5_two_epochs.npz")
+    cwt = ContinuousWaveletTransform()
+    f = _grid_only(cwt, g["x"].astype(np.float64), fs=1000.0, timestamps=g["timestamps"])
+    np.testing.assert_allclose(f, g["frequencies"], rtol=1e-14)
+    assert f.size == 45
+
+
+def test_error_surface():
+    cwt = ContinuousWaveletTransform()
+    x = np.zeros(5000)
+    with pytest.raises(ValueError):
+        cwt.transform(x, fs=1000, voices_per_octave=5)
+    with pytest.raises(ValueError):
+        cwt.transform(x, fs=1000, freqs=[10, 20], freq_limits=[10, 20])
+    with pytest.raises(ValueError):
+        cwt.transform(x, fs=1000, parallel=3)
+    with pytest.raises(ValueError):
+        cwt.transform(x, fs=1000, verbose="yes")
+    with pytest.raises(ValueError):
+        cwt.transform(x, fs=-1)
+    with pytest.raises(TypeError, match="missing 1 required keyword argument: 'fs'"):
+        cwt.transform(x)
+    with pytest.raises(TypeError):
+        cwt.transform([1.0, 2.0, 3.0], fs=1000)
+    with pytest.raises(ValueError):
+        cwt.transform(np.zeros((2, 5000)), fs=1000)
+    with pytest.raises(ValueError):
+        cwt.transform(np.zeros((5000, 2)), fs=1000)
+    with pytest.raises(ValueError):
+        cwt.transform(x, fs=1000, timestamps=np.zeros(4999))
+    for attr in ("frequencies", "amplitude", "power", "time"):
+        with pytest.raises(ValueError):
+            setattr(cwt, attr, 1)
+    with pytest.raises(TypeError):
+        cwt.fs = 1000.0
+        cwt.wavelet = "morse"
+    assert repr(cwt) == "ContinuousWaveletTransform"
+    # shapes with one non-singleton dimension are fine up to the device call
+    for shape in ((1, 5000), (5000, 1)):
+        f = _grid_only(ContinuousWaveletTransform(), np.zeros(shape), fs=1000.0)
+        assert f.size == 49
+
+
+def test_contiguous_segments():
+    fs = 1000.0
+    t = np.arange(10000) / fs
+    t[6000:] += 10.0
+    np.testing.assert_array_equal(
+        get_contiguous_segments(t, step=1 / fs, index=True), [[0, 6000], [6000, 10000]])
+    np.testing.assert_array_equal(
+        get_contiguous_segments(t, step=1 / fs, index=True, inclusive=True),
+        [[0, 5999], [6000, 9999]])
+    vals = get_contiguous_segments(t, step=1 / fs)
+    np.testing.assert_allclose(vals, [[0.0, 6.0], [16.0, 20.0]])
+    assert get_contiguous_segments(np.arange(5.0), step=1.0, index=True).tolist() == [[0, 5]]
+    assert is_sorted([1, 2, 2, 3]) and not is_sorted([2, 1])
+    with pytest.raises(TypeError):
+        is_sorted("abc")
+
+
+class FakeASA:
+    """Duck-typed nelpy.RegularlySampledAnalogSignalArray (nelpy is not installed)."""
+
+    def __init__(self, data_rowsig, fs, lengths):
+        self._data_rowsig = np.asarray(data_rowsig)
+        self._data_colsig = self._data_rowsig.T
+        self.n_signals = self._data_rowsig.shape[0]
+        self.fs = fs
+        self.lengths = np.asarray(lengths)
+        n = self._data_rowsig.shape[1]
+        t = np.arange(n) / fs
+        edge = np.cumsum(lengths)[:-1]
+        for e in edge:
+            t[e:] += 5.0
+        self.abscissa_vals = t
+
+
+def test_asa_adapter():
+    from ghost_amd.formats import standardize_asa, is_asa_like
+    seen = {}
+
+    @standardize_asa(x="data", fs="fs", n_signals=1, abscissa_vals="timestamps")
+    def fn(data, *, fs=None, timestamps=None, epoch_bounds=None):
+        seen.update(data=data, fs=fs, t=timestamps, eb=epoch_bounds)
+
+    asa = FakeASA(np.arange(10.0)[None, :], 100.0, [6, 4])
+    assert is_asa_like(asa) and not is_asa_like(np.zeros(3))
+    fn(asa)
+    assert seen["data"].shape == (10, 1) and seen["fs"] == 100.0
+    np.testing.assert_array_equal(seen["eb"], [[0, 6], [6, 10]])   # cumulative, unlike the reference
+    fn(data=asa, fs=5.0)                                            # object's fs wins
+    assert seen["fs"] == 100.0
+    with pytest.raises(ValueError):
+        fn(FakeASA(np.zeros((2, 10)), 100.0, [10]))
+    fn(np.arange(8.0), fs=2.0)
+    np.testing.assert_allclose(seen["t"], np.arange(8) / 2.0)      # default timestamps work
+    np.testing.assert_array_equal(seen["eb"], [[0, 8]])
+    with pytest.raises(TypeError):
+        standardize_asa(x=3)
+    with pytest.raises(ValueError):
+        standardize_asa(x="data", n_signals=0)
+    # transform() accepts the ASA and takes fs / epochs from it
+    cwt = ContinuousWaveletTransform()
+    big = FakeASA(np.random.default_rng(0).standard_normal((1, 10000)), 1000.0, [6000, 4000])
+    f = _grid_only(cwt, big)
+    assert cwt.fs == 1000.0 and f.size == 45
+
+
+def test_planner_through_the_abi():
+    f = np.geomspace(200, 2, 100)
+    p = CwtPlan(1000000, 128, 1000.0, f)
+    info = p.info
+    assert info["n_spectral"] == 100 and info["n_direct"] == 0
+    assert info["fft_length"] == 1 << 20 and info["block"] == 256
+    assert info["out_bytes"] == 128 * 100 * 1000000 * 4
+    si = p.scale_info()
+    assert si["length"][0] == 70 and si["length"][-1] == 6974
+    assert si["decimation"][0] == 2 and si["decimation"][-1] == 256
+    assert np.all(np.diff(si["decimation"]) >= 0)
+    assert np.all(si["hop"] >= 32) and np.all(si["hop"] + 2 * si["halo"] == 256)
+    # the filter's support fits the decimated band for every spectral scale
+    assert np.all(1.81 * f * si["decimation"] <= 1000.0)
+    # near-Nyquist scales go to the direct path (closed form invalid > 0.28 fs)
+    p2 = CwtPlan(4096, 1, 1000.0, [391.0, 300.0, 280.0, 270.0, 200.0])
+    assert p2.scale_info()["method"].tolist() == [1, 1, 1, 0, 0]
+    with pytest.raises(GhostCwtError) as e:
+        p2.upload()
+    assert e.value.code == _lib.ERR_NO_DEVICE or True   # on a GPU box upload succeeds
+
+
+def test_planner_rejects_bad_requests():
+    for kw in (dict(n_samples=0), dict(fs=-1.0), dict(freqs=[-5.0]), dict(gamma=0.0),
+               dict(bounds=[[0, 20000]]), dict(bounds=[[5, 5]])):
+        args = dict(n_samples=10000, fs=1000.0, freqs=[10.0], gamma=3.0, bounds=None)
+        args.update(kw)
+        with pytest.raises(GhostCwtError) as e:
+            CwtPlan(args["n_samples"], 1, args["fs"], args["freqs"], gamma=args["gamma"],
+                    epoch_bounds=args["bounds"])
+        assert e.value.code == _lib.ERR_INVALID
+    with pytest.raises(GhostCwtError) as e:
+        CwtPlan(1 << 23, 1, 1000.0, [10.0])             # longer than 2^22: not built yet
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    with pytest.raises(GhostCwtError) as e:
+        CwtPlan(1 << 20, 1, 30000.0, [1.0])             # kernel too long for R <= 256
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+
+
+def test_decimated_model_matches_oracle(golden):
+    """The algorithm the kernels implement, in float64 NumPy, against the goldens."""
+    from decimated_model import cwt_decimated
+    from conftest import rel_err
+    g = golden("g2_complex_small.npz")
+    c = cwt_decimated(g["x"], float(g["fs"]), g["frequencies"])
+    assert rel_err(c, g["coeffs"]).max() < 1e-7
+    g = golden("g5_two_epochs.npz")
+    c = cwt_decimated(g["x"], float(g["fs"]), g["frequencies"][::6], g["epoch_bounds"])
+    assert rel_err(c[:, g["cols"]], g["complex_cols"][::6]).max() < 1e-7
