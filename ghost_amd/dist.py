@@ -1,0 +1,149 @@
+"""Multi-GPU control plane: one process per GPU on one node.
+
+The data path has no collective -- channels are sharded in contiguous blocks and
+each rank transforms its own block.  What ranks share is
+  * the Morse filter bank, broadcast once from rank 0 with RCCL over xGMI, and
+  * barriers / a max-reduce, used only to time runs.
+Rendezvous (the 128-byte RCCL id) goes through a file in /tmp keyed by the
+launcher's pid and MASTER_PORT, so nothing here needs torch.  If RCCL cannot be
+initialised the same interface is served by files (and every rank builds its own
+bank); ``Comm.backend`` says which one is live.
+"""
+import ctypes as C
+import os
+import tempfile
+import time
+
+__all__ = ["Comm", "shard_channels", "env_rank"]
+
+
+def env_rank():
+    """(rank, world_size, local_rank) from the torchrun-style environment."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    return rank, world, local
+
+
+def shard_channels(n_channels, rank, world):
+    """Contiguous block [start, stop) of rank's channels; sizes differ by at most 1."""
+    base, extra = divmod(n_channels, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def _session_dir():
+    key = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(),
+                        os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+    d = os.path.join(os.environ.get("GHOSTCWT_RDZV_DIR", tempfile.gettempdir()),
+                     "ghostcwt_" + key)
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _publish(path, data):
+    tmp = path + ".tmp.%d" % os.getpid()
+    with open(tmp, "wb") as fh:
+        fh.write(data)
+    os.replace(tmp, path)
+
+
+def _wait_for(path, timeout):
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise TimeoutError("rendezvous file %s did not appear" % path)
+        time.sleep(0.0005)
+    with open(path, "rb") as fh:
+        return fh.read()
+
+
+class Comm:
+    """barrier(), allreduce_max(x), broadcast_bank(plan) over ``world`` ranks."""
+
+    def __init__(self, rank=None, world=None, *, use_rccl=True, timeout=120.0, session=None):
+        if rank is None:
+            rank, world, _ = env_rank()
+        self.rank, self.world, self.timeout = rank, world, timeout
+        self.dir = session or _session_dir()
+        self._seq = 0
+        self._handle = None
+        self.backend = "single" if world == 1 else "file"
+        self.rccl_error = None
+        if world > 1 and use_rccl:
+            self._try_rccl()
+        if world > 1:
+            # all ranks must agree on the backend
+            ok = self._file_allreduce_max(1.0 if self._handle else 0.0, "agree_min", negate=True)
+            if ok < 1.0 and self._handle:
+                self._drop_rccl()
+            self.backend = "rccl" if self._handle else "file"
+
+    # -- RCCL ---------------------------------------------------------------
+    def _try_rccl(self):
+        try:
+            from ._lib import lib, check, COMM_ID_BYTES
+            path = os.path.join(self.dir, "rccl_id")
+            if self.rank == 0:
+                buf = C.create_string_buffer(COMM_ID_BYTES)
+                check(lib.gcwt_comm_unique_id(buf))
+                _publish(path, buf.raw)
+                ident = buf.raw
+            else:
+                ident = _wait_for(path, self.timeout)
+            h = C.c_void_p()
+            check(lib.gcwt_comm_create(C.byref(h), self.rank, self.world,
+                                       C.create_string_buffer(ident, COMM_ID_BYTES)))
+            self._handle = h
+        except Exception as e:            # RCCL missing / init failed: fall back to files
+            self.rccl_error = "%s: %s" % (type(e).__name__, e)
+            self._handle = None
+
+    def _drop_rccl(self):
+        from ._lib import lib
+        lib.gcwt_comm_destroy(self._handle)
+        self._handle = None
+
+    # -- file backend ---------------------------------------------------------
+    def _file_allreduce_max(self, value, tag, negate=False):
+        self._seq += 1
+        stem = os.path.join(self.dir, "%s_%06d" % (tag, self._seq))
+        _publish("%s.%d" % (stem, self.rank), repr(float(value)).encode())
+        vals = [float(_wait_for("%s.%d" % (stem, r), self.timeout)) for r in range(self.world)]
+        return min(vals) if negate else max(vals)
+
+    # -- interface ------------------------------------------------------------
+    def barrier(self):
+        if self.world == 1:
+            return
+        if self._handle:
+            from ._lib import lib, check
+            check(lib.gcwt_comm_barrier(self._handle))
+        else:
+            self._file_allreduce_max(0.0, "barrier")
+
+    def allreduce_max(self, value):
+        if self.world == 1:
+            return float(value)
+        if self._handle:
+            from ._lib import lib, check
+            v = C.c_double(float(value))
+            check(lib.gcwt_comm_allreduce_max(self._handle, C.byref(v)))
+            return v.value
+        return self._file_allreduce_max(value, "max")
+
+    def broadcast_bank(self, plan, root=0):
+        """RCCL broadcast of rank ``root``'s filter bank into every rank's plan.
+        Returns how the bank got there: 'rccl_broadcast' or 'local_build'."""
+        plan.upload()                     # every rank builds its bank with the HIP kernel
+        if self._handle:
+            from ._lib import lib, check
+            check(lib.gcwt_comm_broadcast_bank(self._handle, plan._handle, root))
+            return "rccl_broadcast"
+        return "local_build"
+
+    def close(self):
+        if self._handle:
+            self._drop_rccl()
+        if self.world > 1:
+            self.backend = "closed"

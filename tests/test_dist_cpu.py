@@ -1,0 +1,81 @@
+"""The N > 1 path on CPU: channel sharding and the control plane, world_size 2.
+
+Two spawned processes run the file-backed Comm (what bench.py falls back to when
+RCCL is unavailable) and, beside it, torch.distributed/gloo doing the same
+reductions, and must agree."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from ghost_amd.dist import Comm, shard_channels
+
+
+def test_shards_partition_the_channels():
+    for n, w in [(1024, 8), (128, 1), (130, 8), (7, 8), (384, 5)]:
+        spans = [shard_channels(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_channels(1024, 3, 8) == (384, 512)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, session, port, q):
+    try:
+        import torch.distributed as td
+        import torch
+        comm = Comm(rank, world, use_rccl=False, session=session, timeout=60)
+        assert comm.backend == "file"
+        comm.barrier()
+        mine = 10.0 + 3.0 * rank
+        got = comm.allreduce_max(mine)
+        # cross-check with gloo
+        td.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                              world_size=world)
+        t = torch.tensor([mine], dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        td.barrier()
+        td.destroy_process_group()
+        # each rank's shard of a synthetic job: weak scaling keeps per-rank work fixed
+        a, b = shard_channels(16 * world, rank, world)
+        comm.barrier()
+        q.put((rank, got, float(t[0]), b - a))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "error", repr(e), 0))
+
+
+def test_world_size_two_control_plane():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    session = tempfile.mkdtemp(prefix="ghostcwt_test_")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, session, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(r[1] != "error" for r in res), res
+    assert [r[1] for r in res] == [13.0, 13.0]          # file backend
+    assert [r[2] for r in res] == [13.0, 13.0]          # gloo agrees
+    assert [r[3] for r in res] == [16, 16]
+
+
+def test_single_rank_comm_is_a_noop():
+    c = Comm(0, 1)
+    assert c.backend == "single"
+    c.barrier()
+    assert c.allreduce_max(2.5) == 2.5
