@@ -11,7 +11,8 @@ __all__ = ["lib", "GhostCwtError", "check", "Params", "PlanInfo", "Timings", "LI
            "OUT_AMPLITUDE", "OUT_POWER", "OUT_COMPLEX", "X_ON_DEVICE", "OUT_ON_DEVICE",
            "SCALE_SPECTRAL", "SCALE_DIRECT", "ERR_INVALID", "ERR_UNSUPPORTED", "ERR_NO_DEVICE"]
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libghostcwt.so")
+LIB_PATH = os.environ.get("GHOSTCWT_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "libghostcwt.so")
 
 OUT_AMPLITUDE, OUT_POWER, OUT_COMPLEX = 0, 1, 2
 X_ON_DEVICE, OUT_ON_DEVICE = 1, 2

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -19,6 +20,9 @@ using namespace gcwt;
 namespace {
 
 thread_local std::string g_err;
+#ifdef GCWT_DIAG
+unsigned long long* g_diag = nullptr;
+#endif
 
 int set_err(int code, const std::string& msg) {
   g_err = msg;
@@ -39,6 +43,9 @@ int hip_err(hipError_t e, const char* what) {
 struct EpochDev {
   SynthItemDev* items = nullptr;
   SynthLevelDev* levels = nullptr;
+  Synth2Item* items2 = nullptr;
+  Synth2Item* items16 = nullptr;
+  Synth2Level* levels2 = nullptr;
 };
 
 enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_COUNT };
@@ -49,6 +56,8 @@ struct gcwt_plan {
   HostPlan hp;
   bool uploaded = false;
   bool profiling = false;
+  int synth_variant = 416;      // GHOSTCWT_SYNTH=2|3 selects the 32-column kernel variant (A/B tests)
+  bool use_synth16 = false;   // GHOSTCWT_SYNTH16=1: 16-column kernel for real outputs too (A/B tests)
   int device = -1;
   hipStream_t stream = nullptr;
   // workspace
@@ -102,7 +111,7 @@ void free_dev(gcwt_plan* p) {
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
-  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); }
+  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items2); fr(e.items16); fr(e.levels2); }
   p->ep_dev.clear();
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
   p->ev_pool.clear();
@@ -200,6 +209,8 @@ int gcwt_plan_create(gcwt_plan** out, const gcwt_params* params) {
   p->hp.prm.epoch_bounds = p->hp.bounds.data();
   p->hp.prm.n_epochs = (int32_t)p->hp.epochs.size();
   p->device = params->device;
+  if (const char* e = getenv("GHOSTCWT_SYNTH16")) p->use_synth16 = e[0] == '1';
+  if (const char* e = getenv("GHOSTCWT_SYNTH")) p->synth_variant = atoi(e);
   for (const auto& s : p->hp.scales)
     if (s.method == GCWT_SCALE_DIRECT) p->max_direct_len = std::max(p->max_direct_len, s.length);
   *out = p;
@@ -322,6 +333,24 @@ int gcwt_plan_upload(gcwt_plan* p) {
                ep.lv[l].xb_offset, hp.levels[l].twiddle_offset};
     if ((rc = upload_vec(&p->ep_dev[e].items, items, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels, lv, p->stream))) return bail(rc);
+    std::vector<Synth2Item> items2(ep.items2.size());
+    for (size_t i = 0; i < items2.size(); ++i)
+      items2[i] = {ep.items2[i].level, ep.items2[i].scale, ep.items2[i].blk0, ep.items2[i].nbatch,
+                   ep.items2[i].rtile, 0, 0, 0};
+    std::vector<Synth2Level> lv2(hp.levels.size());
+    for (size_t l = 0; l < lv2.size(); ++l) {
+      int lg = 0;
+      while ((1 << lg) < hp.levels[l].decimation) ++lg;
+      lv2[l] = {hp.levels[l].decimation, lg, hp.levels[l].hop, hp.levels[l].halo, ep.lv[l].nblk, 0,
+                ep.lv[l].xb_offset, hp.levels[l].twiddle_offset};
+    }
+    if ((rc = upload_vec(&p->ep_dev[e].items2, items2, p->stream))) return bail(rc);
+    std::vector<Synth2Item> items16(ep.items16.size());
+    for (size_t i = 0; i < items16.size(); ++i)
+      items16[i] = {ep.items16[i].level, ep.items16[i].scale, ep.items16[i].blk0,
+                    ep.items16[i].nbatch, ep.items16[i].rtile, 0, 0, 0};
+    if ((rc = upload_vec(&p->ep_dev[e].items16, items16, p->stream))) return bail(rc);
+    if ((rc = upload_vec(&p->ep_dev[e].levels2, lv2, p->stream))) return bail(rc);
   }
 
   hipError_t he = launch_build_bank(p->d_bank, p->d_bank_sc, S, B, hp.prm.gamma, hp.prm.beta, hp.w0,
@@ -413,7 +442,50 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
       a.epoch_start = ep.start;
       a.epoch_len = ep.ne;
       a.n_scales = S;
-      RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), C, st));
+      if (mode == GCWT_OUT_COMPLEX_C64 || p->use_synth16) {
+        RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), C, st));
+      } else {
+        Synth2Args a2{};
+        a2.xb = p->d_xb;
+        a2.bank = p->d_bank;
+        a2.tw256 = p->d_tw256;
+        a2.level_tw = p->d_level_tw;
+        a2.items = p->ep_dev[e].items2;
+        a2.levels = p->ep_dev[e].levels2;
+        a2.out = dout;
+        a2.xb_cstride = hp.max_xb;
+        a2.n_samples = N;
+        a2.epoch_start = ep.start;
+        a2.epoch_len = ep.ne;
+        a2.n_scales = S;
+        if (const char* e = getenv("GHOSTCWT_DEBUG_FLAGS")) a2.pad = atoi(e);
+#ifdef GCWT_DIAG
+        if (!g_diag) { hipMalloc((void**)&g_diag, 16 * 8); }
+        hipMemsetAsync(g_diag, 0, 16 * 8, st);
+        a2.diag = g_diag;
+#endif
+        if (p->synth_variant == 2) {
+          RUN(ST_SYNTH, launch_synth2(mode, a2, (int)ep.items2.size(), C, st));
+        } else if (p->synth_variant == 3) {
+          RUN(ST_SYNTH, launch_synth3(mode, a2, (int)ep.items2.size(), C, st));
+        } else if (p->synth_variant == 432) {
+          RUN(ST_SYNTH, launch_synth4(mode, 32, a2, (int)ep.items2.size(), C, st));
+        } else {
+          a2.items = p->ep_dev[e].items16;
+          RUN(ST_SYNTH, launch_synth4(mode, 16, a2, (int)ep.items16.size(), C, st));
+        }
+      }
+#ifdef GCWT_DIAG
+      if (g_diag) {
+        unsigned long long h[16];
+        hipStreamSynchronize(st);
+        hipMemcpy(h, g_diag, sizeof(h), hipMemcpyDeviceToHost);
+        double w = (double)h[8];
+        fprintf(stderr, "[diag] waves %.0f; cycles/wave by phase:", w);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %d:%.0f", i, h[i] / w);
+        fprintf(stderr, "\n");
+      }
+#endif
       if (p->profiling) p->last.synth_launches++;
     }
     if (hp.n_direct > 0)
