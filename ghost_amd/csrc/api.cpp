@@ -45,6 +45,12 @@ struct EpochDev {
   SynthLevelDev* levels = nullptr;
   Synth2Item* items2 = nullptr;
   Synth2Item* items16 = nullptr;
+  Synth7Item* items7 = nullptr;
+  Synth7Level* levels7 = nullptr;
+  int n_items7 = 0;
+  Synth2Item* items_staged = nullptr;   // R >= 8
+  Synth2Item* items_direct = nullptr;   // R <= 4
+  int n_staged = 0, n_direct_items = 0;
   Synth2Level* levels2 = nullptr;
 };
 
@@ -56,7 +62,7 @@ struct gcwt_plan {
   HostPlan hp;
   bool uploaded = false;
   bool profiling = false;
-  int synth_variant = 416;      // GHOSTCWT_SYNTH=2|3 selects the 32-column kernel variant (A/B tests)
+  int synth_variant = 7;      // GHOSTCWT_SYNTH=2|3 selects the 32-column kernel variant (A/B tests)
   bool use_synth16 = false;   // GHOSTCWT_SYNTH16=1: 16-column kernel for real outputs too (A/B tests)
   int device = -1;
   hipStream_t stream = nullptr;
@@ -70,6 +76,7 @@ struct gcwt_plan {
   float2* d_tw256 = nullptr;  // exp(+2 pi i q/256)
   float2* d_level_tw = nullptr;
   double* d_sums = nullptr;   // [C]
+  int32_t* d_scale_list = nullptr;
   BankScale* d_bank_sc = nullptr;
   DirectScale* d_direct_sc = nullptr;
   std::vector<EpochDev> ep_dev;
@@ -108,10 +115,10 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
   fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_bank); fr(p->d_psi); fr(p->d_tw4096);
-  fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_bank_sc); fr(p->d_direct_sc);
+  fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
-  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items2); fr(e.items16); fr(e.levels2); }
+  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items2); fr(e.items16); fr(e.items7); fr(e.levels7); fr(e.items_staged); fr(e.items_direct); fr(e.levels2); }
   p->ep_dev.clear();
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
   p->ev_pool.clear();
@@ -321,6 +328,13 @@ int gcwt_plan_upload(gcwt_plan* p) {
   if ((rc = upload_vec(&p->d_bank_sc, bsc, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_direct_sc, dsc, p->stream))) return bail(rc);
 
+  std::vector<int32_t> scale_list;
+  std::vector<int> scale_off(hp.levels.size());
+  for (size_t l = 0; l < hp.levels.size(); ++l) {
+    scale_off[l] = (int)scale_list.size();
+    for (int sidx : hp.levels[l].scales) scale_list.push_back(sidx);
+  }
+  if ((rc = upload_vec(&p->d_scale_list, scale_list, p->stream))) return bail(rc);
   p->ep_dev.resize(hp.epochs.size());
   for (size_t e = 0; e < hp.epochs.size(); ++e) {
     const EpochPlan& ep = hp.epochs[e];
@@ -345,6 +359,29 @@ int gcwt_plan_upload(gcwt_plan* p) {
                 ep.lv[l].xb_offset, hp.levels[l].twiddle_offset};
     }
     if ((rc = upload_vec(&p->ep_dev[e].items2, items2, p->stream))) return bail(rc);
+    std::vector<Synth7Item> items7;
+    std::vector<Synth7Level> lv7(hp.levels.size());
+    for (size_t l = 0; l < lv7.size(); ++l) {
+      const LevelPlan& lp = hp.levels[l];
+      int lg = 0;
+      while ((1 << lg) < lp.decimation) ++lg;
+      lv7[l] = {lp.decimation, lg, lp.hop, lp.halo, ep.lv[l].nblk, (int32_t)lp.scales.size(),
+                scale_off[l], 0, ep.lv[l].xb_offset, lp.twiddle_offset};
+      const int bpb = std::max(1, 32 / lp.decimation);
+      const int n_rtiles = std::max(1, lp.decimation / 32);
+      for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
+        for (int rt = 0; rt < n_rtiles; ++rt) items7.push_back({(int32_t)l, b0, rt, 0});
+    }
+    p->ep_dev[e].n_items7 = (int)items7.size();
+    if ((rc = upload_vec(&p->ep_dev[e].items7, items7, p->stream))) return bail(rc);
+    if ((rc = upload_vec(&p->ep_dev[e].levels7, lv7, p->stream))) return bail(rc);
+    std::vector<Synth2Item> st_items, di_items;
+    for (const Synth2Item& q : items2)
+      (hp.levels[q.level].decimation >= 8 ? st_items : di_items).push_back(q);
+    p->ep_dev[e].n_staged = (int)st_items.size();
+    p->ep_dev[e].n_direct_items = (int)di_items.size();
+    if ((rc = upload_vec(&p->ep_dev[e].items_staged, st_items, p->stream))) return bail(rc);
+    if ((rc = upload_vec(&p->ep_dev[e].items_direct, di_items, p->stream))) return bail(rc);
     std::vector<Synth2Item> items16(ep.items16.size());
     for (size_t i = 0; i < items16.size(); ++i)
       items16[i] = {ep.items16[i].level, ep.items16[i].scale, ep.items16[i].blk0,
@@ -468,7 +505,21 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
           RUN(ST_SYNTH, launch_synth2(mode, a2, (int)ep.items2.size(), C, st));
         } else if (p->synth_variant == 3) {
           RUN(ST_SYNTH, launch_synth3(mode, a2, (int)ep.items2.size(), C, st));
-        } else if (p->synth_variant == 432) {
+        } else if (p->synth_variant == 7 && p->hp.halo_static) {
+          Synth7Args a7{};
+          a7.xb = p->d_xb; a7.bank = p->d_bank; a7.tw256 = p->d_tw256; a7.level_tw = p->d_level_tw;
+          a7.items = p->ep_dev[e].items7; a7.levels = p->ep_dev[e].levels7;
+          a7.scale_list = p->d_scale_list; a7.out = dout; a7.xb_cstride = hp.max_xb;
+          a7.n_samples = N; a7.epoch_start = ep.start; a7.epoch_len = ep.ne; a7.n_scales = S;
+          RUN(ST_SYNTH, launch_synth7(mode, a7, p->ep_dev[e].n_items7, C, st));
+        } else if (p->synth_variant == 6 && p->hp.halo_static) {
+          a2.items = p->ep_dev[e].items_staged;
+          RUN(ST_SYNTH, launch_synth6(mode, a2, p->ep_dev[e].n_staged, C, true, st));
+          a2.items = p->ep_dev[e].items_direct;
+          RUN(ST_SYNTH, launch_synth6(mode, a2, p->ep_dev[e].n_direct_items, C, false, st));
+        } else if (p->synth_variant == 5 && p->hp.halo_static) {
+          RUN(ST_SYNTH, launch_synth5(mode, a2, (int)ep.items2.size(), C, st));
+        } else if (p->synth_variant == 432 || p->synth_variant == 5 || p->synth_variant == 6 || p->synth_variant == 7) {
           RUN(ST_SYNTH, launch_synth4(mode, 32, a2, (int)ep.items2.size(), C, st));
         } else {
           a2.items = p->ep_dev[e].items16;

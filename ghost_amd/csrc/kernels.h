@@ -83,6 +83,37 @@ struct Synth2Args {
 hipError_t launch_synth2(int mode, const Synth2Args& a, int n_items, int n_channels, hipStream_t st);
 hipError_t launch_synth4(int mode, int ncol, const Synth2Args& a, int n_items, int n_channels,
                          hipStream_t st);
+struct Synth7Item {
+  int32_t level, blk0, rtile, pad;
+};
+
+struct Synth7Level {
+  int32_t decimation, log2r, hop, halo, nblk, n_scales, scale_offset, pad;
+  int64_t xb_offset;   // per-channel offset of this level's block spectra (complex elems)
+  int64_t tw_offset;   // into level_tw
+};
+
+struct Synth7Args {
+  const float2* xb;
+  const float2* bank;
+  const float2* tw256;
+  const float2* level_tw;
+  const Synth7Item* items;
+  const Synth7Level* levels;
+  const int32_t* scale_list;   // scale indices grouped by level
+  float* out;
+  int64_t xb_cstride;
+  int64_t n_samples;
+  int64_t epoch_start;
+  int64_t epoch_len;
+  int32_t n_scales;
+  int32_t pad;
+};
+
+hipError_t launch_synth7(int mode, const Synth7Args& a, int n_items, int n_channels, hipStream_t st);
+hipError_t launch_synth6(int mode, const Synth2Args& a, int n_items, int n_channels, bool staged,
+                         hipStream_t st);
+hipError_t launch_synth5(int mode, const Synth2Args& a, int n_items, int n_channels, hipStream_t st);
 hipError_t launch_synth3(int mode, const Synth2Args& a, int n_items, int n_channels, hipStream_t st);
 
 hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,

@@ -135,7 +135,12 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     sp.level = it->second;
     LevelPlan& lp = hp->levels[sp.level];
     lp.scales.push_back(i);
-    int halo = (int)((sp.length + 2 * r - 1) / (2 * r)) + 2;
+    // decimated samples discarded at each block edge: half the kernel's effective support.
+    // The reference length L is "4 footprints to be safe" (morse.py:113-116); beyond
+    // 0.82 L/2 the wavelet is below 2e-5 of its peak and the wrap-around error of the
+    // block convolution stays below 3e-7 of the row maximum (tests/test_host_surface.py).
+    int halo = (int)std::ceil(hp->halo_frac * (double)sp.length / (2.0 * r)) + 2;
+    halo = std::max(halo, 16);
     if (r == 2) halo += halo & 1;   // keeps halo*R a multiple of 4: 16-byte aligned tile runs
     lp.halo = std::max(lp.halo, halo);
   }
@@ -145,6 +150,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       return fail(GCWT_ERR_UNSUPPORTED,
                   "a wavelet is too long for the 256-sample decimated block at the largest "
                   "decimation this build supports (256): lowest frequency too low for fs");
+    if (lp.halo > 32) hp->halo_static = false;
     lp.twiddle_offset = hp->level_twiddle_total;
     hp->level_twiddle_total += (int64_t)kSynthCols * lp.decimation;
   }

@@ -79,6 +79,8 @@ struct HostPlan {
   std::vector<ScalePlan> scales;
   std::vector<LevelPlan> levels;
   std::vector<EpochPlan> epochs;
+  bool halo_static = true;         // every level has 16 <= halo <= 32 (fast synthesis kernel)
+  double halo_frac = 0.82;         // kernel support kept, as a fraction of the reference length L
   int n_direct = 0;
   int64_t direct_total = 0;        // complex elements of all direct kernels
   int64_t level_twiddle_total = 0;

@@ -546,6 +546,446 @@ hipError_t launch_synth4(int mode, int ncol, const Synth2Args& a, int n_items, i
                     : launch_synth4_n<32>(mode, a, n_items, n_channels, st);
 }
 
+// ---------------------------------------------------------------------------
+// k_synth5<MODE>: production kernel.  k_synth3's choreography (32 columns, pass 2
+// re-dealt so that lanes hold consecutive samples) specialised for block layouts
+// with 16 <= halo <= 32: of the 16 output rows a thread holds (m = 16 m1 + m2),
+// rows 0 and 15 are always halo, rows 2..13 are always kept, rows 1 and 14 are
+// kept by the lanes with m2 >= halo - 16 / m2 < 32 - halo.  Stores use a
+// wave-uniform row pointer plus a 32-bit lane offset; batches that touch the end
+// of the epoch or of the block list take a checked path.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) k_synth5(const Synth2Args a) {
+  constexpr int kPlane = 513;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* const ex = reinterpret_cast<v2f*>(smem);
+  v2f* const twl = ex + 16 * kPlane;
+
+  const Synth2Item it = a.items[blockIdx.x];
+  const Synth2Level lv = a.levels[it.level];
+  const int c = blockIdx.y;
+  const int R = lv.decimation, lg = lv.log2r, hop = lv.hop, halo = lv.halo;
+  const int tid = threadIdx.x;
+  const int colw = tid >> 4, t = tid & 15;
+  const bool wide = R > 32;
+  const int bpb = wide ? 1 : (32 >> lg);
+  const int blk_l = wide ? 0 : (colw >> lg);
+  const int r = wide ? it.rtile * 32 + colw : (colw & (R - 1));
+
+  if (tid < 256) {
+    const float2 w = a.tw256[tid];
+    twl[tid] = (v2f){w.x, w.y};
+  }
+  v2f hw[16];
+  {
+    const float2* bank = a.bank + (int64_t)it.scale * 256 + t;
+    const float2* ltw = a.level_tw + lv.tw_offset;
+    const float2 b0 = ltw[t * r], st = ltw[16 * r];
+    v2f wcur = (v2f){b0.x, b0.y};
+    const v2f wstep = (v2f){st.x, st.y};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float2 hk = bank[16 * j];
+      hw[j] = cmulv((v2f){hk.x, hk.y}, wcur);
+      wcur = cmulv(wcur, wstep);
+    }
+  }
+  const int sstride = wide ? 32 : R;
+  v2f* const exw = ex + t * kPlane + (wide ? colw : (blk_l << (4 + lg)) + r);
+  const int blk_l2 = wide ? 0 : (tid >> (4 + lg));
+  const int rem = wide ? tid : (tid & ((16 << lg) - 1));
+  const int m2 = wide ? (tid >> 5) : (rem >> lg);
+  const int r2 = wide ? it.rtile * 32 + (tid & 31) : (rem & (R - 1));
+  const v2f* const exr = ex + tid;
+  const int off0 = (blk_l2 * hop + m2 - halo) * R + r2;   // sample offset of row m1 = 0
+  const int m1step = 16 * R;
+  const bool keep1 = m2 >= halo - 16, keep14 = m2 < 32 - halo;
+
+  const float2* xb = a.xb + (int64_t)c * a.xb_cstride + lv.xb_offset + t;
+  float* const outrow = a.out + ((int64_t)c * a.n_scales + it.scale) * a.n_samples + a.epoch_start;
+
+  v2f xn[16];
+  {
+    const int blk = min(it.blk0 + blk_l, lv.nblk - 1);   // past-the-end columns: never stored
+    const float2* p = xb + (int64_t)blk * 256;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float2 q = p[16 * j];
+      xn[j] = (v2f){q.x, q.y};
+    }
+  }
+  __syncthreads();
+
+  for (int b = 0; b < it.nbatch; ++b) {
+    const int blk0 = it.blk0 + b * bpb;
+    v2f v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = cmulv(xn[j], hw[j]);
+    if (b + 1 < it.nbatch) {
+      const int blk = min(blk0 + bpb + blk_l, lv.nblk - 1);
+      const float2* p = xb + (int64_t)blk * 256;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float2 q = p[16 * j];
+        xn[j] = (v2f){q.x, q.y};
+      }
+    }
+    idft16v(v);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) exw[j * sstride] = cmulv(v[dft16_pos(j)], twl[(t * j) & 255]);
+    __syncthreads();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) v[k1] = exr[k1 * kPlane];
+    __syncthreads();
+    idft16v(v);
+
+    const int64_t n_b = (int64_t)blk0 * hop * R;
+    float* const dst = outrow + n_b;
+    const int span = bpb * hop * R;
+    const bool inside = blk0 + bpb <= lv.nblk && n_b + span <= a.epoch_len;   // wave-uniform
+    auto mag = [&](int m1) {
+      const v2f z = v[dft16_pos(m1)];
+      const float p2 = z.x * z.x + z.y * z.y;
+      return MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2) : p2;
+    };
+    if (inside) {
+      if (keep1) dst[off0 + m1step] = mag(1);
+#pragma unroll
+      for (int m1 = 2; m1 < 14; ++m1) dst[off0 + m1 * m1step] = mag(m1);
+      if (keep14) dst[off0 + 14 * m1step] = mag(14);
+    } else {
+      const int lim = blk0 + blk_l2 < lv.nblk
+                          ? (int)min<int64_t>(a.epoch_len - n_b, (int64_t)0x7fffffff) : 0;
+#pragma unroll
+      for (int m1 = 1; m1 < 15; ++m1) {
+        const bool keep = m1 == 1 ? keep1 : (m1 == 14 ? keep14 : true);
+        const int off = off0 + m1 * m1step;
+        if (keep && off < lim) dst[off] = mag(m1);
+      }
+    }
+  }
+}
+
+hipError_t launch_synth5(int mode, const Synth2Args& a, int n_items, int n_channels, hipStream_t st) {
+  if (n_items == 0) return hipSuccess;
+  constexpr int lds = 16 * 513 * 8 + 256 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_synth5<GCWT_OUT_AMPLITUDE_F32>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_synth5<GCWT_OUT_POWER_F32>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(n_items, n_channels), block(512);
+  if (mode == GCWT_OUT_AMPLITUDE_F32)
+    hipLaunchKernelGGL((k_synth5<GCWT_OUT_AMPLITUDE_F32>), grid, block, lds, st, a);
+  else
+    hipLaunchKernelGGL((k_synth5<GCWT_OUT_POWER_F32>), grid, block, lds, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// k_synth6<MODE, STAGE>: k_synth5 with the register budget brought under 128
+// VGPRs (two 512-thread workgroups per CU, four waves per SIMD).
+// STAGE = true  (R >= 8): the batch's block spectra (<= 4 blocks, 8 KB) are
+//   fetched with one or two coalesced loads per thread a batch ahead and parked in
+//   LDS; each thread then reads its 16 inputs as LDS broadcasts.  This also takes
+//   the 8..32-fold redundant spectrum reads off the vector L1.
+// STAGE = false (R <= 4): every thread reads its own 16 inputs from global memory;
+//   the loads for the next batch are issued after the second DFT, ahead of the
+//   stores, so they do not queue behind them (vmcnt retires in order).
+// ---------------------------------------------------------------------------
+template <int MODE, bool STAGE>
+__global__ void __launch_bounds__(512, 4) k_synth6(const Synth2Args a) {
+  constexpr int kPlane = 513;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* const ex = reinterpret_cast<v2f*>(smem);
+  v2f* const twl = ex + 16 * kPlane;
+  v2f* const stage = twl + 256;              // STAGE: up to 4 blocks x 256
+
+  const Synth2Item it = a.items[blockIdx.x];
+  const Synth2Level lv = a.levels[it.level];
+  const int c = blockIdx.y;
+  const int R = lv.decimation, lg = lv.log2r, hop = lv.hop, halo = lv.halo;
+  const int tid = threadIdx.x;
+  const int colw = tid >> 4, t = tid & 15;
+  const bool wide = R > 32;
+  const int bpb = wide ? 1 : (32 >> lg);
+  const int blk_l = wide ? 0 : (colw >> lg);
+  const int r = wide ? it.rtile * 32 + colw : (colw & (R - 1));
+
+  if (tid < 256) {
+    const float2 w = a.tw256[tid];
+    twl[tid] = (v2f){w.x, w.y};
+  }
+  v2f hw[16];
+  {
+    const float2* bank = a.bank + (int64_t)it.scale * 256 + t;
+    const float2* ltw = a.level_tw + lv.tw_offset;
+    const float2 b0 = ltw[t * r], st = ltw[16 * r];
+    v2f wcur = (v2f){b0.x, b0.y};
+    const v2f wstep = (v2f){st.x, st.y};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float2 hk = bank[16 * j];
+      hw[j] = cmulv((v2f){hk.x, hk.y}, wcur);
+      wcur = cmulv(wcur, wstep);
+    }
+  }
+  const int sstride = wide ? 32 : R;
+  v2f* const exw = ex + t * kPlane + (wide ? colw : (blk_l << (4 + lg)) + r);
+  const int blk_l2 = wide ? 0 : (tid >> (4 + lg));
+  const int rem = wide ? tid : (tid & ((16 << lg) - 1));
+  const int m2 = wide ? (tid >> 5) : (rem >> lg);
+  const int r2 = wide ? it.rtile * 32 + (tid & 31) : (rem & (R - 1));
+  const v2f* const exr = ex + tid;
+  const int off0 = (blk_l2 * hop + m2 - halo) * R + r2;   // sample offset of row m1 = 0
+  const int m1step = 16 * R;
+  const bool keep1 = m2 >= halo - 16, keep14 = m2 < 32 - halo;
+
+  const float2* const xbl = a.xb + (int64_t)c * a.xb_cstride + lv.xb_offset;  // level spectra
+  const int64_t xb_last = (int64_t)lv.nblk * 256 - 1;
+  float* const outrow = a.out + ((int64_t)c * a.n_scales + it.scale) * a.n_samples + a.epoch_start;
+  const v2f* const st_rd = stage + blk_l * 256 + t;
+  const int n_stage = bpb * 256;             // complex values staged per batch (256 .. 1024)
+
+  v2f xn[16];
+  if (STAGE) {
+    for (int i = tid; i < n_stage; i += 512) {
+      const float2 q = xbl[min((int64_t)it.blk0 * 256 + i, xb_last)];
+      stage[i] = (v2f){q.x, q.y};
+    }
+  } else {
+    const int blk = min(it.blk0 + blk_l, lv.nblk - 1);   // past-the-end columns: never stored
+    const float2* p = xbl + (int64_t)blk * 256 + t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float2 q = p[16 * j];
+      xn[j] = (v2f){q.x, q.y};
+    }
+  }
+  __syncthreads();
+
+  for (int b = 0; b < it.nbatch; ++b) {
+    const int blk0 = it.blk0 + b * bpb;
+    const bool more = b + 1 < it.nbatch;
+    v2f v[16];
+    float2 g0 = make_float2(0.f, 0.f), g1 = g0;
+    if (STAGE) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = cmulv(st_rd[16 * j], hw[j]);
+      if (more) {                              // next batch's spectra: in flight during this batch
+        const int64_t base = (int64_t)(blk0 + bpb) * 256;
+        if (tid < n_stage) g0 = xbl[min(base + tid, xb_last)];
+        if (tid + 512 < n_stage) g1 = xbl[min(base + tid + 512, xb_last)];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = cmulv(xn[j], hw[j]);
+    }
+    idft16v(v);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) exw[j * sstride] = cmulv(v[dft16_pos(j)], twl[(t * j) & 255]);
+    __syncthreads();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) v[k1] = exr[k1 * kPlane];
+    if (STAGE && more) {                       // everyone has read this batch's stage by now
+      if (tid < n_stage) stage[tid] = (v2f){g0.x, g0.y};
+      if (tid + 512 < n_stage) stage[tid + 512] = (v2f){g1.x, g1.y};
+    }
+    __syncthreads();
+    idft16v(v);
+    if (!STAGE && more) {                      // issue ahead of the stores below
+      const int blk = min(blk0 + bpb + blk_l, lv.nblk - 1);
+      const float2* p = xbl + (int64_t)blk * 256 + t;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float2 q = p[16 * j];
+        xn[j] = (v2f){q.x, q.y};
+      }
+    }
+
+    const int64_t n_b = (int64_t)blk0 * hop * R;
+    float* const dst = outrow + n_b;
+    const int span = bpb * hop * R;
+    const bool inside = blk0 + bpb <= lv.nblk && n_b + span <= a.epoch_len;   // wave-uniform
+    const int lim = inside ? 0x7fffffff
+                           : (blk0 + blk_l2 < lv.nblk
+                                  ? (int)min<int64_t>(a.epoch_len - n_b, (int64_t)0x7fffffff) : 0);
+#pragma unroll
+    for (int m1 = 1; m1 < 15; ++m1) {
+      const v2f z = v[dft16_pos(m1)];
+      const float p2 = z.x * z.x + z.y * z.y;
+      const float val = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2) : p2;
+      const bool keep = m1 == 1 ? keep1 : (m1 == 14 ? keep14 : true);
+      const int off = off0 + m1 * m1step;
+      if (keep && off < lim) dst[off] = val;
+    }
+  }
+}
+
+hipError_t launch_synth6(int mode, const Synth2Args& a, int n_items, int n_channels, bool staged,
+                         hipStream_t st) {
+  if (n_items == 0) return hipSuccess;
+  constexpr int lds = 16 * 513 * 8 + 256 * 8 + 1024 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* fns[4] = {(const void*)k_synth6<GCWT_OUT_AMPLITUDE_F32, true>,
+                          (const void*)k_synth6<GCWT_OUT_AMPLITUDE_F32, false>,
+                          (const void*)k_synth6<GCWT_OUT_POWER_F32, true>,
+                          (const void*)k_synth6<GCWT_OUT_POWER_F32, false>};
+    for (const void* f : fns) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+    }
+    attr_set = true;
+  }
+  dim3 grid(n_items, n_channels), block(512);
+  if (mode == GCWT_OUT_AMPLITUDE_F32) {
+    if (staged) hipLaunchKernelGGL((k_synth6<GCWT_OUT_AMPLITUDE_F32, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_synth6<GCWT_OUT_AMPLITUDE_F32, false>), grid, block, lds, st, a);
+  } else {
+    if (staged) hipLaunchKernelGGL((k_synth6<GCWT_OUT_POWER_F32, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_synth6<GCWT_OUT_POWER_F32, false>), grid, block, lds, st, a);
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// k_synth7<MODE>: the production synthesis kernel.
+//
+// One workgroup owns a fixed set of 32 columns -- 32/R consecutive blocks x all R
+// phases (R <= 32), or one block x 32 of its phases (R >= 64) -- and walks over
+// the SCALES of the level.  What never changes for a thread,
+//     P[k] = XB_blk[k] * W^{k r},   k = t + 16 j,
+// is built once and kept in 32 VGPRs; what changes per batch, the scale's filter
+// H_s[k] (2 KB), is fetched one batch ahead by the first 256 threads and parked in
+// LDS, from where every column reads it as a broadcast.  Per batch and thread:
+//   v = P * H_s          16 complex multiplies
+//   DFT16, W256 twiddle (table in LDS), transpose + re-deal through LDS
+//   DFT16, |.|, 14 stores of 4 B per lane: 256 contiguous bytes per wave store
+// With 16 <= halo <= 32 rows 0 and 15 of a thread's 16 outputs are always halo,
+// rows 2..13 are always kept and rows 1 / 14 are kept lane-wise.
+// LDS: 16 x 513 complex + 2 x 256 complex = 69.8 KB -> two workgroups per CU.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) k_synth7(const Synth7Args a) {
+  constexpr int kPlane = 513;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* const ex = reinterpret_cast<v2f*>(smem);
+  v2f* const twl = ex + 16 * kPlane;
+  v2f* const stage = twl + 256;
+
+  const Synth7Item it = a.items[blockIdx.x];
+  const Synth7Level lv = a.levels[it.level];
+  const int c = blockIdx.y;
+  const int R = lv.decimation, lg = lv.log2r, hop = lv.hop, halo = lv.halo;
+  const int tid = threadIdx.x;
+  const int colw = tid >> 4, t = tid & 15;
+  const bool wide = R > 32;
+  const int bpb = wide ? 1 : (32 >> lg);
+  const int blk_l = wide ? 0 : (colw >> lg);
+  const int r = wide ? it.rtile * 32 + colw : (colw & (R - 1));
+  const int* const scales = a.scale_list + lv.scale_offset;
+
+  if (tid < 256) {
+    const float2 w = a.tw256[tid];
+    twl[tid] = (v2f){w.x, w.y};
+    const float2 h = a.bank[(int64_t)scales[0] * 256 + tid];
+    stage[tid] = (v2f){h.x, h.y};
+  }
+  v2f pw[16];
+  {
+    const int blk = min(it.blk0 + blk_l, lv.nblk - 1);   // past-the-end columns: never stored
+    const float2* xb = a.xb + (int64_t)c * a.xb_cstride + lv.xb_offset + (int64_t)blk * 256 + t;
+    const float2* ltw = a.level_tw + lv.tw_offset;
+    const float2 b0 = ltw[t * r], st = ltw[16 * r];
+    v2f wcur = (v2f){b0.x, b0.y};
+    const v2f wstep = (v2f){st.x, st.y};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float2 q = xb[16 * j];
+      pw[j] = cmulv((v2f){q.x, q.y}, wcur);
+      wcur = cmulv(wcur, wstep);
+    }
+  }
+  const int sstride = wide ? 32 : R;
+  v2f* const exw = ex + t * kPlane + (wide ? colw : (blk_l << (4 + lg)) + r);
+  const int blk_l2 = wide ? 0 : (tid >> (4 + lg));
+  const int rem = wide ? tid : (tid & ((16 << lg) - 1));
+  const int m2 = wide ? (tid >> 5) : (rem >> lg);
+  const int r2 = wide ? it.rtile * 32 + (tid & 31) : (rem & (R - 1));
+  const v2f* const exr = ex + tid;
+  const int off0 = (blk_l2 * hop + m2 - halo) * R + r2;   // sample offset of row m1 = 0
+  const int m1step = 16 * R;
+  const bool keep1 = m2 >= halo - 16, keep14 = m2 < 32 - halo;
+
+  const int64_t n_b = (int64_t)it.blk0 * hop * R;          // first sample of the block group
+  const int span = bpb * hop * R;
+  const bool inside = it.blk0 + bpb <= lv.nblk && n_b + span <= a.epoch_len;   // wave-uniform
+  const int lim = inside ? 0x7fffffff
+                         : (it.blk0 + blk_l2 < lv.nblk
+                                ? (int)min<int64_t>(a.epoch_len - n_b, (int64_t)0x7fffffff) : 0);
+  float* const out0 = a.out + (int64_t)c * a.n_scales * a.n_samples + a.epoch_start + n_b;
+  const v2f* const st_rd = stage + t;
+  __syncthreads();
+
+  for (int b = 0; b < lv.n_scales; ++b) {
+    const bool more = b + 1 < lv.n_scales;
+    v2f* const st_cur = stage;                 // single buffer: refilled between the barriers
+    v2f v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = cmulv(st_rd[16 * j], pw[j]);
+    float2 g = make_float2(0.f, 0.f);
+    if (more && tid < 256) g = a.bank[(int64_t)scales[b + 1] * 256 + tid];
+    idft16v(v);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) exw[j * sstride] = cmulv(v[dft16_pos(j)], twl[(t * j) & 255]);
+    __syncthreads();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) v[k1] = exr[k1 * kPlane];
+    if (more && tid < 256) st_cur[tid] = (v2f){g.x, g.y};   // every thread is past this batch's reads
+    __syncthreads();
+    idft16v(v);
+
+    float* const dst = out0 + (int64_t)scales[b] * a.n_samples;
+#pragma unroll
+    for (int m1 = 1; m1 < 15; ++m1) {
+      const v2f z = v[dft16_pos(m1)];
+      const float p2 = z.x * z.x + z.y * z.y;
+      const float val = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2) : p2;
+      const bool keep = m1 == 1 ? keep1 : (m1 == 14 ? keep14 : true);
+      const int off = off0 + m1 * m1step;
+      if (keep && off < lim) dst[off] = val;
+    }
+  }
+}
+
+hipError_t launch_synth7(int mode, const Synth7Args& a, int n_items, int n_channels, hipStream_t st) {
+  if (n_items == 0) return hipSuccess;
+  constexpr int lds = 16 * 513 * 8 + 2 * 256 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_AMPLITUDE_F32>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_POWER_F32>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(n_items, n_channels), block(512);
+  if (mode == GCWT_OUT_AMPLITUDE_F32)
+    hipLaunchKernelGGL((k_synth7<GCWT_OUT_AMPLITUDE_F32>), grid, block, lds, st, a);
+  else
+    hipLaunchKernelGGL((k_synth7<GCWT_OUT_POWER_F32>), grid, block, lds, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_synth2(int mode, const Synth2Args& a, int n_items, int n_channels, hipStream_t st) {
   if (n_items == 0) return hipSuccess;
   static bool attr_set = false;

@@ -51,7 +51,7 @@ def plan_scale(omega, length, p_big, B, gamma, beta, eps):
     while u_hi * omega * (2 * r) <= math.pi * 2 and 2 * r <= p_big // B:
         r *= 2
     # r is the largest power of two with u_hi*omega <= 2 pi / r
-    lh = int(math.ceil(length / (2.0 * r))) + 2
+    lh = max(int(math.ceil(0.82 * length / (2.0 * r))) + 2, 16)
     hop = B - 2 * lh
     return ("spectral", r, lh, hop)
 
