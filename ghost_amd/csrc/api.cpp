@@ -440,6 +440,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
   }
 
   const bool any_spectral = hp.n_direct < S;
+  const bool fast_fft = !getenv("GHOSTCWT_SLOW_FFT");
   for (size_t e = 0; e < hp.epochs.size(); ++e) {
     const EpochPlan& ep = hp.epochs[e];
     if (any_spectral) {
@@ -447,10 +448,10 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
       const int P1 = ep.p1;
       // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
       RUN(ST_FWD, launch_fft_cols(-1, true, dx + ep.start, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0,
-                                  p->d_tw4096, p->d_sums, inv_n, ep.ne, C, st));
+                                  p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n, ep.ne, C, st));
       // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]
       RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, P1, kRowLen, kRowLen, P, P, 0,
-                                  p->d_tw4096, 1.0f, C, st));
+                                  p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st));
       for (size_t l = 0; l < hp.levels.size(); ++l) {
         const LevelPlan& lp = hp.levels[l];
         const EpochLevel& el = ep.lv[l];
@@ -458,10 +459,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
         float2* xr = p->d_xr + el.xr_offset;
         // x_R[Q m1 + m2] = sum_{j1} e^{2 pi i j1 m1/P1} e^{2 pi i j1 m2/M} sum_{j2} X~[j1][j2] e^{2 pi i j2 m2/Q}
         RUN(ST_DECIM, launch_fft_rows(+1, p->d_x, xr, Q, P1, kRowLen, Q, P, hp.max_xr,
-                                      P1 > 1 ? el.m : 0, p->d_tw4096, 1.0f, C, st));
+                                      P1 > 1 ? el.m : 0, p->d_tw4096, fast_fft ? p->d_tw256 : nullptr,
+                                      1.0f, C, st));
         if (P1 > 1)
           RUN(ST_DECIM, launch_fft_cols(+1, false, xr, xr, P1, Q, hp.max_xr, hp.max_xr, 0,
-                                        p->d_tw4096, p->d_sums, inv_n, 0, C, st));
+                                        p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n, 0, C, st));
         const float scale = (float)(1.0 / ((double)hp.block * (double)P));
         RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.nblk,
                                        hp.max_xr, hp.max_xb, p->d_tw256, scale, C, st));

@@ -294,6 +294,214 @@ __global__ void __launch_bounds__(256) k_fft_rows(const cf* __restrict__ in, cf*
 }
 
 // ---------------------------------------------------------------------------
+// Fast paths of the big FFT: register radix-16 instead of radix-2 LDS stages.
+// ---------------------------------------------------------------------------
+template <int SIGN>
+__device__ __forceinline__ void dft2(cf& a, cf& b) {
+  const cf s = cadd(a, b), d = csub(a, b);
+  a = s;
+  b = d;
+}
+
+template <int SIGN>
+__device__ __forceinline__ void dft8(cf v[8]) {
+  const float h = 0.70710678118654752f, sg = (float)SIGN;
+  dft4<SIGN>(v[0], v[2], v[4], v[6]);      // E[0..3] in v[0], v[2], v[4], v[6]
+  dft4<SIGN>(v[1], v[3], v[5], v[7]);      // O[0..3] in v[1], v[3], v[5], v[7]
+  const cf o1 = cmul(v[3], make_float2(h, sg * h));
+  const cf o2 = mul_si<SIGN>(v[5]);
+  const cf o3 = cmul(v[7], make_float2(-h, sg * h));
+  const cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+  v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+template <int SIGN, int Q>
+__device__ __forceinline__ void dft_small(cf v[Q]) {
+  if (Q == 2) dft2<SIGN>(v[0], v[1]);
+  else if (Q == 4) dft4<SIGN>(v[0], v[1], v[2], v[3]);
+  else if (Q == 8) dft8<SIGN>(v);
+  else if (Q == 16) dft16<SIGN>(v);
+}
+
+// exp(SIGN 2 pi i idx/4096) from the half table exp(-2 pi i j/4096), j < 2048
+template <int SIGN>
+__device__ __forceinline__ cf tw4096_at(const cf* __restrict__ tw4096, int idx) {
+  cf w = tw4096[idx & 2047];
+  if (idx & 2048) w = make_float2(-w.x, -w.y);
+  if (SIGN > 0) w.y = -w.y;
+  return w;
+}
+
+__device__ __forceinline__ cf unit_phase(int64_t num, int64_t den, int sign) {
+  float sn, cs;
+  sincospif(2.0f * (float)(num % den) / (float)den, &sn, &cs);
+  return make_float2(cs, sign > 0 ? sn : -sn);
+}
+
+__device__ __forceinline__ int pad32(int i) { return i + (i >> 5); }
+
+// Rows of length Q = 256 q, q = 1 << LQ: FFT256 over the stride-q subsequences,
+// twiddle W_Q^(kb a), DFT_q over a; output index kb + 256 ka is contiguous in kb.
+template <int SIGN, int LQ>
+__device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __restrict__ o,
+                                               cf* buf, float* ex_re, float* ex_im, int64_t in_ld,
+                                               int64_t out_ld, int64_t tw_n,
+                                               const cf* __restrict__ tw4096,
+                                               const cf* __restrict__ tw256, float scale, int row0,
+                                               int n_rows) {
+  constexpr int q = 1 << LQ, Q = 256 * q, rows = 16 >> LQ;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 4096; e += 256) {
+    const int rr = e >> (8 + LQ), i = e & (Q - 1);
+    buf[pad32(e)] = row0 + rr < n_rows ? x[(int64_t)(row0 + rr) * in_ld + i] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  const int s = tid >> 4, t = tid & 15;
+  const int rr = s >> LQ, a = s & (q - 1);
+  cf tw[16], v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    cf w = tw256[(t * j) & 255];              // table holds exp(+2 pi i q/256)
+    if (SIGN < 0) w.y = -w.y;
+    tw[j] = w;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = buf[pad32(rr * Q + q * (t + 16 * j) + a)];
+  fft256_16t<SIGN>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
+  if (q == 1) {
+    const int row = row0 + rr;
+    if (row < n_rows) {
+      cf w = make_float2(1.f, 0.f), st = w;
+      if (tw_n > 0) {
+        w = unit_phase((int64_t)row * t, tw_n, SIGN);
+        st = unit_phase((int64_t)row * 16, tw_n, SIGN);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        cf val = v[j];
+        if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
+        o[(int64_t)row * out_ld + t + 16 * j] = make_float2(val.x * scale, val.y * scale);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int kb = t + 16 * j;
+    const cf w = tw4096_at<SIGN>(tw4096, kb * a * (16 >> LQ));
+    buf[pad32(rr * Q + q * kb + a)] = cmul(v[j], w);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < rows; ++i) {
+    const int item = tid + 256 * i;
+    const int r2 = item >> 8, kb = item & 255;
+    const int row = row0 + r2;
+    cf u[q];
+#pragma unroll
+    for (int aa = 0; aa < q; ++aa) u[aa] = buf[pad32(r2 * Q + q * kb + aa)];
+    dft_small<SIGN, q>(u);
+    if (row < n_rows) {
+      cf w = make_float2(1.f, 0.f), st = w;
+      if (tw_n > 0) {
+        w = unit_phase((int64_t)row * kb, tw_n, SIGN);
+        st = unit_phase((int64_t)row * 256, tw_n, SIGN);
+      }
+#pragma unroll
+      for (int ka = 0; ka < q; ++ka) {
+        cf val = u[ka];
+        if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
+        o[(int64_t)row * out_ld + kb + 256 * ka] = make_float2(val.x * scale, val.y * scale);
+      }
+    }
+  }
+}
+
+template <int SIGN>
+__global__ void __launch_bounds__(256) k_fft_rows_fast(const cf* __restrict__ in, cf* __restrict__ out,
+                                                       int lq, int64_t in_ld, int64_t out_ld,
+                                                       int64_t in_cstride, int64_t out_cstride,
+                                                       int64_t tw_n, const cf* __restrict__ tw4096,
+                                                       const cf* __restrict__ tw256, float scale,
+                                                       int n_rows) {
+  __shared__ __attribute__((aligned(16))) cf buf[4096 + 128];
+  __shared__ float ex_re[16 * kExCol];
+  __shared__ float ex_im[16 * kExCol];
+  const cf* x = in + (int64_t)blockIdx.y * in_cstride;
+  cf* o = out + (int64_t)blockIdx.y * out_cstride;
+  const int row0 = blockIdx.x * (16 >> lq);
+  switch (lq) {
+    case 0: rows_fast_body<SIGN, 0>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
+    case 1: rows_fast_body<SIGN, 1>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
+    case 2: rows_fast_body<SIGN, 2>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
+    case 3: rows_fast_body<SIGN, 3>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
+    default: rows_fast_body<SIGN, 4>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
+  }
+}
+
+// Column pass for len = 256: tile of 16 columns, one FFT256 per column by 16 threads.
+template <int SIGN, bool REAL_IN>
+__global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in_, cf* __restrict__ out,
+                                                     int ld, int64_t in_cstride, int64_t out_cstride,
+                                                     int64_t tw_n, const cf* __restrict__ tw256,
+                                                     const double* __restrict__ sums, double inv_n,
+                                                     int64_t n_valid) {
+  __shared__ __attribute__((aligned(16))) cf tile[256 * 17];
+  __shared__ float ex_re[16 * kExCol];
+  __shared__ float ex_im[16 * kExCol];
+  const int c = blockIdx.y, col0 = blockIdx.x * 16, tid = threadIdx.x;
+  if (REAL_IN) {
+    const float* x = reinterpret_cast<const float*>(in_) + (int64_t)c * in_cstride;
+    const float mean = (float)(sums[c] * inv_n);
+    for (int e = tid; e < 4096; e += 256) {
+      const int i = e >> 4, cc = e & 15;
+      const int64_t n = (int64_t)i * ld + col0 + cc;
+      tile[i * 17 + cc] = make_float2(n < n_valid ? x[n] - mean : 0.f, 0.f);
+    }
+  } else {
+    const cf* x = reinterpret_cast<const cf*>(in_) + (int64_t)c * in_cstride;
+    for (int e = tid; e < 4096; e += 256) {
+      const int i = e >> 4, cc = e & 15;
+      tile[i * 17 + cc] = x[(int64_t)i * ld + col0 + cc];
+    }
+  }
+  __syncthreads();
+  const int s = tid >> 4, t = tid & 15;
+  cf tw[16], v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    cf w = tw256[(t * j) & 255];
+    if (SIGN < 0) w.y = -w.y;
+    tw[j] = w;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = tile[(t + 16 * j) * 17 + s];
+  fft256_16t<SIGN>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
+  {
+    cf w = make_float2(1.f, 0.f), st = w;
+    if (tw_n > 0) {
+      w = unit_phase((int64_t)(col0 + s) * t, tw_n, SIGN);
+      st = unit_phase((int64_t)(col0 + s) * 16, tw_n, SIGN);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      cf val = v[j];
+      if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
+      tile[(t + 16 * j) * 17 + s] = val;
+    }
+  }
+  __syncthreads();
+  cf* o = out + (int64_t)c * out_cstride;
+  for (int e = tid; e < 4096; e += 256) {
+    const int k = e >> 4, cc = e & 15;
+    o[(int64_t)k * ld + col0 + cc] = tile[k * 17 + cc];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Block spectra: XB[blk][k] = scale * FFT_256(x_R[(blk*hop - halo + n) mod M])
 // 16 blocks per workgroup, 16 threads per block.  grid (ceil(nblk/16), C)
 // ---------------------------------------------------------------------------
@@ -515,8 +723,22 @@ hipError_t launch_build_direct(cf* psi, const DirectScale* sc, int n_direct, int
 
 hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int len, int ld,
                            int64_t in_cstride, int64_t out_cstride, int64_t tw_n, const cf* tw4096,
+                           const cf* tw256,
                            const double* sums, double inv_n, int64_t n_valid, int n_channels,
                            hipStream_t st) {
+  if (len == 256 && tw256) {
+    dim3 grid(ld / 16, n_channels), block(256);
+    if (sign < 0 && real_in)
+      hipLaunchKernelGGL((k_fft_cols256<-1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid);
+    else if (sign < 0)
+      hipLaunchKernelGGL((k_fft_cols256<-1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid);
+    else if (real_in)
+      hipLaunchKernelGGL((k_fft_cols256<1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid);
+    else
+      hipLaunchKernelGGL((k_fft_cols256<1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid);
+    GCWT_LAUNCH_CHECK();
+    return hipSuccess;
+  }
   const size_t lds = (size_t)len * 16 * sizeof(cf);
   dim3 grid(ld / 16, n_channels), block(256);
   const int l2 = ilog2(len);
@@ -541,10 +763,21 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int 
 
 hipError_t launch_fft_rows(int sign, const cf* in, cf* out, int len, int64_t n_rows, int64_t in_ld,
                            int64_t out_ld, int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
-                           const cf* tw4096, float scale, int n_channels, hipStream_t st) {
+                           const cf* tw4096, const cf* tw256, float scale, int n_channels,
+                           hipStream_t st) {
   const int l2 = ilog2(len);
   const int rows = kRowLenDev / len;
   dim3 grid((unsigned)((n_rows + rows - 1) / rows), n_channels), block(256);
+  if (len >= 256 && tw256) {
+    if (sign < 0)
+      hipLaunchKernelGGL((k_fft_rows_fast<-1>), grid, block, 0, st, in, out, l2 - 8, in_ld, out_ld,
+                         in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows);
+    else
+      hipLaunchKernelGGL((k_fft_rows_fast<1>), grid, block, 0, st, in, out, l2 - 8, in_ld, out_ld,
+                         in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows);
+    GCWT_LAUNCH_CHECK();
+    return hipSuccess;
+  }
   if (sign < 0)
     hipLaunchKernelGGL((k_fft_rows<-1>), grid, block, 0, st, in, out, len, l2, in_ld, out_ld,
                        in_cstride, out_cstride, tw_n, tw4096, scale, (int)n_rows);
