@@ -31,22 +31,23 @@ def cpu_baseline(fs, n_samples, freqs, budget_s=25.0):
     on this box's cores: config 2 shape, ThreadPool over scales like parallel=True."""
     from oracle import ghost_oracle as orc
     from ghost_amd.synthetic import lfp_channel
-    cores = len(os.sched_getaffinity(0))
+    cores = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share is 16 cores
     x = lfp_channel(n_samples, fs, 0).astype(np.float64)
-    best = None
+    best, reps = None, 0
     t_start = time.time()
-    for _ in range(3):
+    while reps < 3 or (time.time() - t_start < 10.0 and reps < 60):   # ~10 s of CPU work
         t0 = time.time()
         orc.cwt_amplitude(x, fs, freqs, n_threads=cores)
         dt = time.time() - t0
         best = dt if best is None else min(best, dt)
+        reps += 1
         if time.time() - t_start > budget_s:
             break
     return {"value": round(n_samples / best / 1e6, 4), "unit": "Msamples/s", "cores": cores,
             "kind": "port",
             "sample": "1 ch x %d samples x %d scales (config 2), float64, scipy.fft overlap-add, "
-                      "ThreadPool(%d) over scales, best of <=3 (%.2f s)" %
-                      (n_samples, len(freqs), cores, best)}
+                      "ThreadPool(%d) over scales, best of %d runs (%.2f s each)" %
+                      (n_samples, len(freqs), cores, reps, best)}
 
 
 def main():
@@ -133,7 +134,7 @@ def main():
                                    "%s f32 out, device-resident" % (C, N, S, args.output),
                        "channels_total": total_channels, "parallelism": "channel-sharded x%d" % world,
                        "bank": bank_via, "comm": comm.backend, "device": device_name(dev)},
-            "roofline": {"bound": "hbm", "kernel": "k_synth", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_synth7", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes": alg_bytes},

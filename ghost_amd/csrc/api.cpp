@@ -20,9 +20,7 @@ using namespace gcwt;
 namespace {
 
 thread_local std::string g_err;
-#ifdef GCWT_DIAG
-unsigned long long* g_diag = nullptr;
-#endif
+
 
 int set_err(int code, const std::string& msg) {
   g_err = msg;
@@ -41,17 +39,11 @@ int hip_err(hipError_t e, const char* what) {
   } while (0)
 
 struct EpochDev {
-  SynthItemDev* items = nullptr;
+  SynthItemDev* items = nullptr;     // 16-column kernel (complex output, odd layouts)
   SynthLevelDev* levels = nullptr;
-  Synth2Item* items2 = nullptr;
-  Synth2Item* items16 = nullptr;
-  Synth7Item* items7 = nullptr;
+  Synth7Item* items7 = nullptr;      // production kernel
   Synth7Level* levels7 = nullptr;
   int n_items7 = 0;
-  Synth2Item* items_staged = nullptr;   // R >= 8
-  Synth2Item* items_direct = nullptr;   // R <= 4
-  int n_staged = 0, n_direct_items = 0;
-  Synth2Level* levels2 = nullptr;
 };
 
 enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_COUNT };
@@ -62,8 +54,7 @@ struct gcwt_plan {
   HostPlan hp;
   bool uploaded = false;
   bool profiling = false;
-  int synth_variant = 7;      // GHOSTCWT_SYNTH=2|3 selects the 32-column kernel variant (A/B tests)
-  bool use_synth16 = false;   // GHOSTCWT_SYNTH16=1: 16-column kernel for real outputs too (A/B tests)
+  bool use_synth16 = false;   // GHOSTCWT_SYNTH16=1: 16-column kernel for every output mode (A/B tests)
   int device = -1;
   hipStream_t stream = nullptr;
   // workspace
@@ -118,7 +109,7 @@ void free_dev(gcwt_plan* p) {
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
-  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items2); fr(e.items16); fr(e.items7); fr(e.levels7); fr(e.items_staged); fr(e.items_direct); fr(e.levels2); }
+  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.levels7); }
   p->ep_dev.clear();
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
   p->ev_pool.clear();
@@ -217,7 +208,6 @@ int gcwt_plan_create(gcwt_plan** out, const gcwt_params* params) {
   p->hp.prm.n_epochs = (int32_t)p->hp.epochs.size();
   p->device = params->device;
   if (const char* e = getenv("GHOSTCWT_SYNTH16")) p->use_synth16 = e[0] == '1';
-  if (const char* e = getenv("GHOSTCWT_SYNTH")) p->synth_variant = atoi(e);
   for (const auto& s : p->hp.scales)
     if (s.method == GCWT_SCALE_DIRECT) p->max_direct_len = std::max(p->max_direct_len, s.length);
   *out = p;
@@ -347,18 +337,6 @@ int gcwt_plan_upload(gcwt_plan* p) {
                ep.lv[l].xb_offset, hp.levels[l].twiddle_offset};
     if ((rc = upload_vec(&p->ep_dev[e].items, items, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels, lv, p->stream))) return bail(rc);
-    std::vector<Synth2Item> items2(ep.items2.size());
-    for (size_t i = 0; i < items2.size(); ++i)
-      items2[i] = {ep.items2[i].level, ep.items2[i].scale, ep.items2[i].blk0, ep.items2[i].nbatch,
-                   ep.items2[i].rtile, 0, 0, 0};
-    std::vector<Synth2Level> lv2(hp.levels.size());
-    for (size_t l = 0; l < lv2.size(); ++l) {
-      int lg = 0;
-      while ((1 << lg) < hp.levels[l].decimation) ++lg;
-      lv2[l] = {hp.levels[l].decimation, lg, hp.levels[l].hop, hp.levels[l].halo, ep.lv[l].nblk, 0,
-                ep.lv[l].xb_offset, hp.levels[l].twiddle_offset};
-    }
-    if ((rc = upload_vec(&p->ep_dev[e].items2, items2, p->stream))) return bail(rc);
     std::vector<Synth7Item> items7;
     std::vector<Synth7Level> lv7(hp.levels.size());
     for (size_t l = 0; l < lv7.size(); ++l) {
@@ -375,19 +353,6 @@ int gcwt_plan_upload(gcwt_plan* p) {
     p->ep_dev[e].n_items7 = (int)items7.size();
     if ((rc = upload_vec(&p->ep_dev[e].items7, items7, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels7, lv7, p->stream))) return bail(rc);
-    std::vector<Synth2Item> st_items, di_items;
-    for (const Synth2Item& q : items2)
-      (hp.levels[q.level].decimation >= 8 ? st_items : di_items).push_back(q);
-    p->ep_dev[e].n_staged = (int)st_items.size();
-    p->ep_dev[e].n_direct_items = (int)di_items.size();
-    if ((rc = upload_vec(&p->ep_dev[e].items_staged, st_items, p->stream))) return bail(rc);
-    if ((rc = upload_vec(&p->ep_dev[e].items_direct, di_items, p->stream))) return bail(rc);
-    std::vector<Synth2Item> items16(ep.items16.size());
-    for (size_t i = 0; i < items16.size(); ++i)
-      items16[i] = {ep.items16[i].level, ep.items16[i].scale, ep.items16[i].blk0,
-                    ep.items16[i].nbatch, ep.items16[i].rtile, 0, 0, 0};
-    if ((rc = upload_vec(&p->ep_dev[e].items16, items16, p->stream))) return bail(rc);
-    if ((rc = upload_vec(&p->ep_dev[e].levels2, lv2, p->stream))) return bail(rc);
   }
 
   hipError_t he = launch_build_bank(p->d_bank, p->d_bank_sc, S, B, hp.prm.gamma, hp.prm.beta, hp.w0,
@@ -481,64 +446,25 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
       a.epoch_start = ep.start;
       a.epoch_len = ep.ne;
       a.n_scales = S;
-      if (mode == GCWT_OUT_COMPLEX_C64 || p->use_synth16) {
+      if (mode == GCWT_OUT_COMPLEX_C64 || p->use_synth16 || !hp.halo_static) {
         RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), C, st));
       } else {
-        Synth2Args a2{};
-        a2.xb = p->d_xb;
-        a2.bank = p->d_bank;
-        a2.tw256 = p->d_tw256;
-        a2.level_tw = p->d_level_tw;
-        a2.items = p->ep_dev[e].items2;
-        a2.levels = p->ep_dev[e].levels2;
-        a2.out = dout;
-        a2.xb_cstride = hp.max_xb;
-        a2.n_samples = N;
-        a2.epoch_start = ep.start;
-        a2.epoch_len = ep.ne;
-        a2.n_scales = S;
-        if (const char* e = getenv("GHOSTCWT_DEBUG_FLAGS")) a2.pad = atoi(e);
-#ifdef GCWT_DIAG
-        if (!g_diag) { hipMalloc((void**)&g_diag, 16 * 8); }
-        hipMemsetAsync(g_diag, 0, 16 * 8, st);
-        a2.diag = g_diag;
-#endif
-        if (p->synth_variant == 2) {
-          RUN(ST_SYNTH, launch_synth2(mode, a2, (int)ep.items2.size(), C, st));
-        } else if (p->synth_variant == 3) {
-          RUN(ST_SYNTH, launch_synth3(mode, a2, (int)ep.items2.size(), C, st));
-        } else if (p->synth_variant == 7 && p->hp.halo_static) {
-          Synth7Args a7{};
-          a7.xb = p->d_xb; a7.bank = p->d_bank; a7.tw256 = p->d_tw256; a7.level_tw = p->d_level_tw;
-          a7.items = p->ep_dev[e].items7; a7.levels = p->ep_dev[e].levels7;
-          a7.scale_list = p->d_scale_list; a7.out = dout; a7.xb_cstride = hp.max_xb;
-          a7.n_samples = N; a7.epoch_start = ep.start; a7.epoch_len = ep.ne; a7.n_scales = S;
-          RUN(ST_SYNTH, launch_synth7(mode, a7, p->ep_dev[e].n_items7, C, st));
-        } else if (p->synth_variant == 6 && p->hp.halo_static) {
-          a2.items = p->ep_dev[e].items_staged;
-          RUN(ST_SYNTH, launch_synth6(mode, a2, p->ep_dev[e].n_staged, C, true, st));
-          a2.items = p->ep_dev[e].items_direct;
-          RUN(ST_SYNTH, launch_synth6(mode, a2, p->ep_dev[e].n_direct_items, C, false, st));
-        } else if (p->synth_variant == 5 && p->hp.halo_static) {
-          RUN(ST_SYNTH, launch_synth5(mode, a2, (int)ep.items2.size(), C, st));
-        } else if (p->synth_variant == 432 || p->synth_variant == 5 || p->synth_variant == 6 || p->synth_variant == 7) {
-          RUN(ST_SYNTH, launch_synth4(mode, 32, a2, (int)ep.items2.size(), C, st));
-        } else {
-          a2.items = p->ep_dev[e].items16;
-          RUN(ST_SYNTH, launch_synth4(mode, 16, a2, (int)ep.items16.size(), C, st));
-        }
+        Synth7Args a7{};
+        a7.xb = p->d_xb;
+        a7.bank = p->d_bank;
+        a7.tw256 = p->d_tw256;
+        a7.level_tw = p->d_level_tw;
+        a7.items = p->ep_dev[e].items7;
+        a7.levels = p->ep_dev[e].levels7;
+        a7.scale_list = p->d_scale_list;
+        a7.out = dout;
+        a7.xb_cstride = hp.max_xb;
+        a7.n_samples = N;
+        a7.epoch_start = ep.start;
+        a7.epoch_len = ep.ne;
+        a7.n_scales = S;
+        RUN(ST_SYNTH, launch_synth7(mode, a7, p->ep_dev[e].n_items7, C, st));
       }
-#ifdef GCWT_DIAG
-      if (g_diag) {
-        unsigned long long h[16];
-        hipStreamSynchronize(st);
-        hipMemcpy(h, g_diag, sizeof(h), hipMemcpyDeviceToHost);
-        double w = (double)h[8];
-        fprintf(stderr, "[diag] waves %.0f; cycles/wave by phase:", w);
-        for (int i = 0; i < 8; ++i) fprintf(stderr, " %d:%.0f", i, h[i] / w);
-        fprintf(stderr, "\n");
-      }
-#endif
       if (p->profiling) p->last.synth_launches++;
     }
     if (hp.n_direct > 0)

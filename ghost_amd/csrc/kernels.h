@@ -53,36 +53,6 @@ struct SynthArgs {
   int32_t pad;
 };
 
-struct Synth2Item {
-  int32_t level, scale, blk0, nbatch, rtile, pad0, pad1, pad2;
-};
-
-struct Synth2Level {
-  int32_t decimation, log2r, hop, halo, nblk, pad;
-  int64_t xb_offset;   // per-channel offset of this level's block spectra (complex elems)
-  int64_t tw_offset;   // into level_tw
-};
-
-struct Synth2Args {
-  const float2* xb;
-  const float2* bank;
-  const float2* tw256;
-  const float2* level_tw;
-  const Synth2Item* items;
-  const Synth2Level* levels;
-  float* out;
-  int64_t xb_cstride;
-  int64_t n_samples;
-  int64_t epoch_start;
-  int64_t epoch_len;
-  int32_t n_scales;
-  int32_t pad;
-  unsigned long long* diag;   // diagnostic builds only (GCWT_DIAG): per-phase cycle sums
-};
-
-hipError_t launch_synth2(int mode, const Synth2Args& a, int n_items, int n_channels, hipStream_t st);
-hipError_t launch_synth4(int mode, int ncol, const Synth2Args& a, int n_items, int n_channels,
-                         hipStream_t st);
 struct Synth7Item {
   int32_t level, blk0, rtile, pad;
 };
@@ -111,10 +81,6 @@ struct Synth7Args {
 };
 
 hipError_t launch_synth7(int mode, const Synth7Args& a, int n_items, int n_channels, hipStream_t st);
-hipError_t launch_synth6(int mode, const Synth2Args& a, int n_items, int n_channels, bool staged,
-                         hipStream_t st);
-hipError_t launch_synth5(int mode, const Synth2Args& a, int n_items, int n_channels, hipStream_t st);
-hipError_t launch_synth3(int mode, const Synth2Args& a, int n_items, int n_channels, hipStream_t st);
 
 hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,
                               hipStream_t st);

@@ -178,22 +178,6 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
         }
       }
     }
-    for (int ncol : {32, 16}) {
-      std::vector<Synth2ItemHost>& dst = ncol == 32 ? ep.items2 : ep.items16;
-      const int per_item = ncol == 32 ? kSynth2Batches : 2 * kSynth2Batches;
-      for (size_t l = 0; l < hp->levels.size(); ++l) {
-        const LevelPlan& lp = hp->levels[l];
-        const EpochLevel& el = ep.lv[l];
-        const int bpb = std::max(1, ncol / lp.decimation);   // blocks per batch
-        const int n_rtiles = std::max(1, lp.decimation / ncol);
-        const int n_batches = (el.nblk + bpb - 1) / bpb;
-        for (int b0 = 0; b0 < n_batches; b0 += per_item)
-          for (int s : lp.scales)
-            for (int rt = 0; rt < n_rtiles; ++rt)
-              dst.push_back({(int32_t)l, (int32_t)s, (int32_t)(b0 * bpb),
-                             (int32_t)std::min(per_item, n_batches - b0), (int32_t)rt});
-      }
-    }
     ep.xr_total = xr;
     ep.xb_total = xb;
     hp->max_xr = std::max(hp->max_xr, xr);

@@ -19,8 +19,7 @@ constexpr int kRowLen = 4096;      // row length of the two-pass big FFT (P = P1
 constexpr int kMaxP1 = 1024;       // P <= 2^22
 constexpr int kMaxDecimation = 256;
 constexpr int kSynthCols = 16;     // columns (block, r) per batch of the 16-column kernel
-constexpr int kSynth2Cols = 32;    // columns per batch of the 32-column kernel
-constexpr int kSynth2Batches = 12; // batches per workgroup (amortises the per-thread tables)
+constexpr int kSynthWide = 32;      // columns per batch of the production kernel
 
 struct ScalePlan {
   double freq_hz = 0, omega = 0;   // omega = f / (fs/2) * pi   (transforms.py:408-410)
@@ -52,18 +51,12 @@ struct SynthItem {                 // one workgroup of the synthesis kernel
   int32_t level, scale, blk0, nblk;
 };
 
-struct Synth2ItemHost {           // one workgroup of the 32-column synthesis kernel
-  int32_t level, scale, blk0, nbatch, rtile;
-};
-
 struct EpochPlan {
   int64_t start = 0, stop = 0, ne = 0;
   int64_t p = 0;                   // FFT length of this epoch
   int p1 = 0;                      // p = p1 * kRowLen
   std::vector<EpochLevel> lv;      // one per HostPlan::levels
   std::vector<SynthItem> items;
-  std::vector<Synth2ItemHost> items2;    // 32 columns per batch
-  std::vector<Synth2ItemHost> items16;   // 16 columns per batch
   int64_t xr_total = 0, xb_total = 0;  // per-channel complex elements
 };
 

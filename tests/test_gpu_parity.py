@@ -114,6 +114,13 @@ def test_config2_reduced(golden):
     err = rel_err(c[0][:, g["cols"]], g["complex_cols"].astype(np.complex128))
     assert err.max() < TOL, err
     np.testing.assert_allclose(np.abs(c[0]).max(axis=1), g["amplitude_rowmax"], rtol=2e-5)
+    # amplitude / power go through the production kernel (k_synth7), all eight decimation levels
+    p, a = _plan(g["x"], float(g["fs"]), g["frequencies"], output="amplitude")
+    assert sorted(set(p.scale_info()["decimation"])) == [2, 4, 8, 16, 32, 64, 128, 256]
+    ref = np.abs(g["complex_cols"].astype(np.complex128))
+    assert rel_err(a[0][:, g["cols"]], ref).max() < TOL
+    p, pw = _plan(g["x"], float(g["fs"]), g["frequencies"], output="power")
+    assert rel_err(pw[0][:, g["cols"]], ref ** 2).max() < 2 * TOL
 
 
 def test_edge_shapes_against_oracle():
@@ -126,6 +133,8 @@ def test_edge_shapes_against_oracle():
         ref = orc.cwt_complex(x.astype(np.float64), fs, f)
         p, c = _plan(x, fs, f, output="complex")
         assert rel_err(c[0], ref).max() < TOL, (n, f)
+        p, a = _plan(x, fs, f, output="amplitude")
+        assert rel_err(a[0], np.abs(ref)).max() < TOL, (n, f)
     p, a = _plan(np.full(3000, 3.25, np.float32), fs, [50.0, 10.0])
     assert np.abs(a).max() < 1e-5          # constant input: mean removal leaves nothing
     p, a = _plan(np.zeros(3000, np.float32), fs, [50.0, 10.0])
