@@ -54,6 +54,7 @@ struct gcwt_plan {
   HostPlan hp;
   bool uploaded = false;
   bool profiling = false;
+  int synth_cols = 32;        // columns per workgroup of k_synth7 (GHOSTCWT_SYNTH_COLS=16|32)
   bool use_synth16 = false;   // GHOSTCWT_SYNTH16=1: 16-column kernel for every output mode (A/B tests)
   int device = -1;
   hipStream_t stream = nullptr;
@@ -208,6 +209,7 @@ int gcwt_plan_create(gcwt_plan** out, const gcwt_params* params) {
   p->hp.prm.n_epochs = (int32_t)p->hp.epochs.size();
   p->device = params->device;
   if (const char* e = getenv("GHOSTCWT_SYNTH16")) p->use_synth16 = e[0] == '1';
+  if (const char* e = getenv("GHOSTCWT_SYNTH_COLS")) p->synth_cols = atoi(e) == 16 ? 16 : 32;
   for (const auto& s : p->hp.scales)
     if (s.method == GCWT_SCALE_DIRECT) p->max_direct_len = std::max(p->max_direct_len, s.length);
   *out = p;
@@ -345,8 +347,8 @@ int gcwt_plan_upload(gcwt_plan* p) {
       while ((1 << lg) < lp.decimation) ++lg;
       lv7[l] = {lp.decimation, lg, lp.hop, lp.halo, ep.lv[l].nblk, (int32_t)lp.scales.size(),
                 scale_off[l], 0, ep.lv[l].xb_offset, lp.twiddle_offset};
-      const int bpb = std::max(1, 32 / lp.decimation);
-      const int n_rtiles = std::max(1, lp.decimation / 32);
+      const int bpb = std::max(1, p->synth_cols / lp.decimation);
+      const int n_rtiles = std::max(1, lp.decimation / p->synth_cols);
       for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
         for (int rt = 0; rt < n_rtiles; ++rt) items7.push_back({(int32_t)l, b0, rt, 0});
     }
@@ -446,7 +448,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
       a.epoch_start = ep.start;
       a.epoch_len = ep.ne;
       a.n_scales = S;
-      if (mode == GCWT_OUT_COMPLEX_C64 || p->use_synth16 || !hp.halo_static) {
+      if (p->use_synth16 || !hp.halo_static) {
         RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), C, st));
       } else {
         Synth7Args a7{};
@@ -463,7 +465,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
         a7.epoch_start = ep.start;
         a7.epoch_len = ep.ne;
         a7.n_scales = S;
-        RUN(ST_SYNTH, launch_synth7(mode, a7, p->ep_dev[e].n_items7, C, st));
+        RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, p->ep_dev[e].n_items7, C, st));
       }
       if (p->profiling) p->last.synth_launches++;
     }

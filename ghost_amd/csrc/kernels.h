@@ -80,7 +80,8 @@ struct Synth7Args {
   int32_t pad;
 };
 
-hipError_t launch_synth7(int mode, const Synth7Args& a, int n_items, int n_channels, hipStream_t st);
+hipError_t launch_synth7(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
+                         hipStream_t st);
 
 hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,
                               hipStream_t st);

@@ -2,8 +2,8 @@
 // phase) multiply the block spectrum by the scale's Morse filter and the polyphase
 // twiddle, inverse-FFT 256 points, take |.| and store the samples in output order.
 // (transforms.py:203-204: convolve each epoch with each scale's kernel, keep abs.)
-// Amplitude / power output; complex output and odd block layouts use the
-// 16-column kernel in kernels.hip.
+// All three output modes; block layouts with halo > 32 use the 16-column kernel in
+// kernels.hip.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -90,9 +90,11 @@ __device__ __forceinline__ void idft16v(v2f v[16]) {
 // rows 2..13 are always kept and rows 1 / 14 are kept lane-wise.
 // LDS: 16 x 513 complex + 2 x 256 complex = 69.8 KB -> two workgroups per CU.
 // ---------------------------------------------------------------------------
-template <int MODE>
-__global__ void __launch_bounds__(512, 4) k_synth7(const Synth7Args a) {
-  constexpr int kPlane = 513;
+template <int MODE, int NCOL>
+__global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
+  constexpr int kThreads = 16 * NCOL;
+  constexpr int kPlane = kThreads + 1;
+  constexpr int kLgN = NCOL == 32 ? 5 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2f* const ex = reinterpret_cast<v2f*>(smem);
   v2f* const twl = ex + 16 * kPlane;
@@ -104,14 +106,15 @@ __global__ void __launch_bounds__(512, 4) k_synth7(const Synth7Args a) {
   const int R = lv.decimation, lg = lv.log2r, hop = lv.hop, halo = lv.halo;
   const int tid = threadIdx.x;
   const int colw = tid >> 4, t = tid & 15;
-  const bool wide = R > 32;
-  const int bpb = wide ? 1 : (32 >> lg);
+  const bool wide = R > NCOL;
+  const int bpb = wide ? 1 : (NCOL >> lg);
   const int blk_l = wide ? 0 : (colw >> lg);
-  const int r = wide ? it.rtile * 32 + colw : (colw & (R - 1));
+  const int r = wide ? it.rtile * NCOL + colw : (colw & (R - 1));
   const int* const scales = a.scale_list + lv.scale_offset;
 
   if (tid < 256) {
-    const float2 w = a.tw256[tid];
+    // W256^(t j) stored [j][t]: the 16 lanes of a column read consecutive entries
+    const float2 w = a.tw256[((tid & 15) * (tid >> 4)) & 255];
     twl[tid] = (v2f){w.x, w.y};
     const float2 h = a.bank[(int64_t)scales[0] * 256 + tid];
     stage[tid] = (v2f){h.x, h.y};
@@ -131,12 +134,12 @@ __global__ void __launch_bounds__(512, 4) k_synth7(const Synth7Args a) {
       wcur = cmulv(wcur, wstep);
     }
   }
-  const int sstride = wide ? 32 : R;
+  const int sstride = wide ? NCOL : R;
   v2f* const exw = ex + t * kPlane + (wide ? colw : (blk_l << (4 + lg)) + r);
   const int blk_l2 = wide ? 0 : (tid >> (4 + lg));
   const int rem = wide ? tid : (tid & ((16 << lg) - 1));
-  const int m2 = wide ? (tid >> 5) : (rem >> lg);
-  const int r2 = wide ? it.rtile * 32 + (tid & 31) : (rem & (R - 1));
+  const int m2 = wide ? (tid >> kLgN) : (rem >> lg);
+  const int r2 = wide ? it.rtile * NCOL + (tid & (NCOL - 1)) : (rem & (R - 1));
   const v2f* const exr = ex + tid;
   const int off0 = (blk_l2 * hop + m2 - halo) * R + r2;   // sample offset of row m1 = 0
   const int m1step = 16 * R;
@@ -148,7 +151,8 @@ __global__ void __launch_bounds__(512, 4) k_synth7(const Synth7Args a) {
   const int lim = inside ? 0x7fffffff
                          : (it.blk0 + blk_l2 < lv.nblk
                                 ? (int)min<int64_t>(a.epoch_len - n_b, (int64_t)0x7fffffff) : 0);
-  float* const out0 = a.out + (int64_t)c * a.n_scales * a.n_samples + a.epoch_start + n_b;
+  constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;   // floats per output sample
+  float* const out0 = a.out + ((int64_t)c * a.n_scales * a.n_samples + a.epoch_start + n_b) * kElem;
   const v2f* const st_rd = stage + t;
   __syncthreads();
 
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(512, 4) k_synth7(const Synth7Args a) {
     if (more && tid < 256) g = a.bank[(int64_t)scales[b + 1] * 256 + tid];
     idft16v(v);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) exw[j * sstride] = cmulv(v[dft16_pos(j)], twl[(t * j) & 255]);
+    for (int j = 0; j < 16; ++j) exw[j * sstride] = cmulv(v[dft16_pos(j)], twl[16 * j + t]);
     __syncthreads();
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) v[k1] = exr[k1 * kPlane];
@@ -170,38 +174,55 @@ __global__ void __launch_bounds__(512, 4) k_synth7(const Synth7Args a) {
     __syncthreads();
     idft16v(v);
 
-    float* const dst = out0 + (int64_t)scales[b] * a.n_samples;
+    float* const dst = out0 + (int64_t)scales[b] * a.n_samples * kElem;
 #pragma unroll
     for (int m1 = 1; m1 < 15; ++m1) {
       const v2f z = v[dft16_pos(m1)];
-      const float p2 = z.x * z.x + z.y * z.y;
-      const float val = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2) : p2;
       const bool keep = m1 == 1 ? keep1 : (m1 == 14 ? keep14 : true);
       const int off = off0 + m1 * m1step;
-      if (keep && off < lim) dst[off] = val;
+      if (MODE == GCWT_OUT_COMPLEX_C64) {
+        if (keep && off < lim) reinterpret_cast<v2f*>(dst)[off] = z;
+      } else {
+        const float p2 = z.x * z.x + z.y * z.y;
+        const float val = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2) : p2;
+        if (keep && off < lim) dst[off] = val;
+      }
     }
   }
 }
 
-hipError_t launch_synth7(int mode, const Synth7Args& a, int n_items, int n_channels, hipStream_t st) {
-  if (n_items == 0) return hipSuccess;
-  constexpr int lds = 16 * 513 * 8 + 2 * 256 * 8;
+template <int NCOL>
+static hipError_t launch_synth7_n(int mode, const Synth7Args& a, int n_items, int n_channels,
+                                  hipStream_t st) {
+  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 2 * 256 * 8;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_AMPLITUDE_F32>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_AMPLITUDE_F32, NCOL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_POWER_F32>,
+    e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_POWER_F32, NCOL>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_COMPLEX_C64, NCOL>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid(n_items, n_channels), block(512);
+  dim3 grid(n_items, n_channels), block(16 * NCOL);
   if (mode == GCWT_OUT_AMPLITUDE_F32)
-    hipLaunchKernelGGL((k_synth7<GCWT_OUT_AMPLITUDE_F32>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((k_synth7<GCWT_OUT_AMPLITUDE_F32, NCOL>), grid, block, lds, st, a);
+  else if (mode == GCWT_OUT_POWER_F32)
+    hipLaunchKernelGGL((k_synth7<GCWT_OUT_POWER_F32, NCOL>), grid, block, lds, st, a);
   else
-    hipLaunchKernelGGL((k_synth7<GCWT_OUT_POWER_F32>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((k_synth7<GCWT_OUT_COMPLEX_C64, NCOL>), grid, block, lds, st, a);
   return hipGetLastError();
+}
+
+hipError_t launch_synth7(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
+                         hipStream_t st) {
+  if (n_items == 0) return hipSuccess;
+  return ncol == 16 ? launch_synth7_n<16>(mode, a, n_items, n_channels, st)
+                    : launch_synth7_n<32>(mode, a, n_items, n_channels, st);
 }
 
 }  // namespace gcwt

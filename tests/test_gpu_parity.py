@@ -179,3 +179,23 @@ def test_full_size_properties():
     sel = [0, 57, 99]
     ref = orc.cwt_complex(x[0].astype(np.float64), fs, f[sel])
     assert rel_err(c[0][sel], ref).max() < TOL
+
+
+def test_rccl_single_rank_communicator():
+    """RCCL entry points on one GPU (world size 1): id, init, max-reduce, bank broadcast."""
+    import ctypes as C
+    from ghost_amd._lib import lib, check, COMM_ID_BYTES
+    from ghost_amd.engine import CwtPlan
+    ident = C.create_string_buffer(COMM_ID_BYTES)
+    check(lib.gcwt_comm_unique_id(ident))
+    comm = C.c_void_p()
+    check(lib.gcwt_comm_create(C.byref(comm), 0, 1, ident))
+    v = C.c_double(3.5)
+    check(lib.gcwt_comm_allreduce_max(comm, C.byref(v)))
+    assert v.value == 3.5
+    check(lib.gcwt_comm_barrier(comm))
+    plan = CwtPlan(8192, 1, 1000.0, [100.0, 20.0])
+    before = plan.filter_bank()
+    check(lib.gcwt_comm_broadcast_bank(comm, plan._handle, 0))
+    np.testing.assert_array_equal(plan.filter_bank(), before)
+    lib.gcwt_comm_destroy(comm)
