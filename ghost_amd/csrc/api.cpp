@@ -418,7 +418,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
                                   p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n, ep.ne, C, st));
       // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]
       RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, P1, kRowLen, kRowLen, P, P, 0,
-                                  p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st));
+                                  p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st,
+                                  kRowLen / 2));   // only X[k < P/2] is ever read
       for (size_t l = 0; l < hp.levels.size(); ++l) {
         const LevelPlan& lp = hp.levels[l];
         const EpochLevel& el = ep.lv[l];

@@ -96,7 +96,7 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, float2* out, 
 hipError_t launch_fft_rows(int sign, const float2* in, float2* out, int len, int64_t n_rows,
                            int64_t in_ld, int64_t out_ld, int64_t in_cstride, int64_t out_cstride,
                            int64_t tw_n, const float2* tw4096, const float2* tw256, float scale,
-                           int n_channels, hipStream_t st);
+                           int n_channels, hipStream_t st, int out_len = 0);
 hipError_t launch_block_fft(const float2* xr, float2* xb, int64_t m, int hop, int halo, int nblk,
                             int64_t xr_cstride, int64_t xb_cstride, const float2* tw256, float scale,
                             int n_channels, hipStream_t st);

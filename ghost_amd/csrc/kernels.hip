@@ -100,6 +100,16 @@ __device__ __forceinline__ void fft256_16t(cf v[16], const cf tw[16], float* ex_
   dft16<SIGN>(v);
 }
 
+// Same, for callers whose exchange planes alias the LDS buffer the inputs were just
+// read from: a barrier before the first exchange write and after the last read.
+template <int SIGN>
+__device__ __forceinline__ void fft256_16t_aliased(cf v[16], const cf tw[16], float* ex_re,
+                                                   float* ex_im, int t) {
+  __syncthreads();
+  fft256_16t<SIGN>(v, tw, ex_re, ex_im, t);
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------
 // per-channel sum (fp64 accumulate), partial sums combined with one atomic per
 // workgroup.  grid (parts, C)
@@ -351,7 +361,7 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
                                                int64_t out_ld, int64_t tw_n,
                                                const cf* __restrict__ tw4096,
                                                const cf* __restrict__ tw256, float scale, int row0,
-                                               int n_rows) {
+                                               int n_rows, int out_len) {
   constexpr int q = 1 << LQ, Q = 256 * q, rows = 16 >> LQ;
   const int tid = threadIdx.x;
   for (int e = tid; e < 4096; e += 256) {
@@ -370,7 +380,7 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
   }
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = buf[pad32(rr * Q + q * (t + 16 * j) + a)];
-  fft256_16t<SIGN>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
+  fft256_16t_aliased<SIGN>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
   if (q == 1) {
     const int row = row0 + rr;
     if (row < n_rows) {
@@ -383,7 +393,8 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
       for (int j = 0; j < 16; ++j) {
         cf val = v[j];
         if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
-        o[(int64_t)row * out_ld + t + 16 * j] = make_float2(val.x * scale, val.y * scale);
+        if (t + 16 * j < out_len)
+          o[(int64_t)row * out_ld + t + 16 * j] = make_float2(val.x * scale, val.y * scale);
       }
     }
     return;
@@ -414,7 +425,8 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
       for (int ka = 0; ka < q; ++ka) {
         cf val = u[ka];
         if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
-        o[(int64_t)row * out_ld + kb + 256 * ka] = make_float2(val.x * scale, val.y * scale);
+        if (256 * ka < out_len)   // out_len is a multiple of 256 (or the whole row)
+          o[(int64_t)row * out_ld + kb + 256 * ka] = make_float2(val.x * scale, val.y * scale);
       }
     }
   }
@@ -426,19 +438,20 @@ __global__ void __launch_bounds__(256) k_fft_rows_fast(const cf* __restrict__ in
                                                        int64_t in_cstride, int64_t out_cstride,
                                                        int64_t tw_n, const cf* __restrict__ tw4096,
                                                        const cf* __restrict__ tw256, float scale,
-                                                       int n_rows) {
-  __shared__ __attribute__((aligned(16))) cf buf[4096 + 128];
-  __shared__ float ex_re[16 * kExCol];
-  __shared__ float ex_im[16 * kExCol];
+                                                       int n_rows, int out_len) {
+  // 16 exchange planes (16 x 272 complex) alias the 4096(+128 pad)-element data buffer
+  __shared__ __attribute__((aligned(16))) cf buf[16 * kExCol];
+  float* const ex_re = reinterpret_cast<float*>(buf);
+  float* const ex_im = ex_re + 16 * kExCol;
   const cf* x = in + (int64_t)blockIdx.y * in_cstride;
   cf* o = out + (int64_t)blockIdx.y * out_cstride;
   const int row0 = blockIdx.x * (16 >> lq);
   switch (lq) {
-    case 0: rows_fast_body<SIGN, 0>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
-    case 1: rows_fast_body<SIGN, 1>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
-    case 2: rows_fast_body<SIGN, 2>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
-    case 3: rows_fast_body<SIGN, 3>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
-    default: rows_fast_body<SIGN, 4>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows); break;
+    case 0: rows_fast_body<SIGN, 0>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
+    case 1: rows_fast_body<SIGN, 1>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
+    case 2: rows_fast_body<SIGN, 2>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
+    case 3: rows_fast_body<SIGN, 3>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
+    default: rows_fast_body<SIGN, 4>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
   }
 }
 
@@ -449,9 +462,9 @@ __global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in
                                                      int64_t tw_n, const cf* __restrict__ tw256,
                                                      const double* __restrict__ sums, double inv_n,
                                                      int64_t n_valid) {
-  __shared__ __attribute__((aligned(16))) cf tile[256 * 17];
-  __shared__ float ex_re[16 * kExCol];
-  __shared__ float ex_im[16 * kExCol];
+  __shared__ __attribute__((aligned(16))) cf tile[256 * 17];   // = 16 exchange planes, aliased
+  float* const ex_re = reinterpret_cast<float*>(tile);
+  float* const ex_im = ex_re + 16 * kExCol;
   const int c = blockIdx.y, col0 = blockIdx.x * 16, tid = threadIdx.x;
   if (REAL_IN) {
     const float* x = reinterpret_cast<const float*>(in_) + (int64_t)c * in_cstride;
@@ -479,7 +492,7 @@ __global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in
   }
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = tile[(t + 16 * j) * 17 + s];
-  fft256_16t<SIGN>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
+  fft256_16t_aliased<SIGN>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
   {
     cf w = make_float2(1.f, 0.f), st = w;
     if (tw_n > 0) {
@@ -764,17 +777,19 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int 
 hipError_t launch_fft_rows(int sign, const cf* in, cf* out, int len, int64_t n_rows, int64_t in_ld,
                            int64_t out_ld, int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
                            const cf* tw4096, const cf* tw256, float scale, int n_channels,
-                           hipStream_t st) {
+                           hipStream_t st, int out_len) {
   const int l2 = ilog2(len);
   const int rows = kRowLenDev / len;
   dim3 grid((unsigned)((n_rows + rows - 1) / rows), n_channels), block(256);
   if (len >= 256 && tw256) {
     if (sign < 0)
       hipLaunchKernelGGL((k_fft_rows_fast<-1>), grid, block, 0, st, in, out, l2 - 8, in_ld, out_ld,
-                         in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows);
+                         in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows,
+                         out_len > 0 ? out_len : len);
     else
       hipLaunchKernelGGL((k_fft_rows_fast<1>), grid, block, 0, st, in, out, l2 - 8, in_ld, out_ld,
-                         in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows);
+                         in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows,
+                         out_len > 0 ? out_len : len);
     GCWT_LAUNCH_CHECK();
     return hipSuccess;
   }

@@ -10,7 +10,8 @@ extern "C" {
 #endif
 
 enum {
-  GCWT_DEBUG_SPECTRUM = 0,      /* X~[k1][k2] = X[k1 + P1 k2], P complex values          */
+  GCWT_DEBUG_SPECTRUM = 0,      /* X~[k1][k2] = X[k1 + P1 k2], P complex values; only
+                                   k2 < 2048 (positive frequencies) is filled            */
   GCWT_DEBUG_DECIMATED = 1,     /* x_R of one level, M = P/R complex values (times P)    */
   GCWT_DEBUG_BLOCK_SPECTRA = 2  /* XB[blk][k] of one level, nblk*B complex values        */
 };
