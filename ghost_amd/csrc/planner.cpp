@@ -150,7 +150,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       return fail(GCWT_ERR_UNSUPPORTED,
                   "a wavelet is too long for the 256-sample decimated block at the largest "
                   "decimation this build supports (256): lowest frequency too low for fs");
-    if (lp.halo > 32) hp->halo_static = false;
+    if (lp.halo > 32 || lp.scales.size() > 256) hp->halo_static = false;   // fast kernel's limits
     lp.twiddle_offset = hp->level_twiddle_total;
     hp->level_twiddle_total += (int64_t)kSynthCols * lp.decimation;
   }

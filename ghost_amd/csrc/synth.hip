@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   v2f* const ex = reinterpret_cast<v2f*>(smem);
   v2f* const twl = ex + 16 * kPlane;
   v2f* const stage = twl + 256;
+  int* const sc_lds = reinterpret_cast<int*>(stage + 4 * 256);   // this level's scale indices
 
   const Synth7Item it = a.items[blockIdx.x];
   const Synth7Level lv = a.levels[it.level];
@@ -107,18 +108,30 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   const int tid = threadIdx.x;
   const int colw = tid >> 4, t = tid & 15;
   const bool wide = R > NCOL;
-  const int bpb = wide ? 1 : (NCOL >> lg);
   const int blk_l = wide ? 0 : (colw >> lg);
   const int r = wide ? it.rtile * NCOL + colw : (colw & (R - 1));
   const int* const scales = a.scale_list + lv.scale_offset;
+  // scale indices are read from LDS inside the loop: a global load there would have to
+  // wait for vmcnt(0), i.e. for every store still in flight
+  for (int i = tid; i < lv.n_scales; i += kThreads) sc_lds[i] = scales[i];
 
   if (tid < 256) {
     // W256^(t j) stored [j][t]: the 16 lanes of a column read consecutive entries
     const float2 w = a.tw256[((tid & 15) * (tid >> 4)) & 255];
     twl[tid] = (v2f){w.x, w.y};
-    const float2 h = a.bank[(int64_t)scales[0] * 256 + tid];
-    stage[tid] = (v2f){h.x, h.y};
   }
+  // Filters of kChunk scales at a time are parked in LDS (8 KB).  A refill is one
+  // global load per thread per kChunk batches, so its vmcnt(0) drain of the
+  // outstanding stores is paid once per kChunk batches, not per batch.
+  constexpr int kChunk = 4;
+  auto fill_stage = [&](int b0) {
+    for (int i = tid; i < kChunk * 256; i += kThreads) {
+      const int sb = min(b0 + (i >> 8), lv.n_scales - 1);
+      const float2 h = a.bank[(int64_t)scales[sb] * 256 + (i & 255)];
+      stage[i] = (v2f){h.x, h.y};
+    }
+  };
+  fill_stage(0);
   v2f pw[16];
   {
     const int blk = min(it.blk0 + blk_l, lv.nblk - 1);   // past-the-end columns: never stored
@@ -145,47 +158,58 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   const int m1step = 16 * R;
   const bool keep1 = m2 >= halo - 16, keep14 = m2 < 32 - halo;
 
-  const int64_t n_b = (int64_t)it.blk0 * hop * R;          // first sample of the block group
-  const int span = bpb * hop * R;
-  const bool inside = it.blk0 + bpb <= lv.nblk && n_b + span <= a.epoch_len;   // wave-uniform
-  const int lim = inside ? 0x7fffffff
-                         : (it.blk0 + blk_l2 < lv.nblk
-                                ? (int)min<int64_t>(a.epoch_len - n_b, (int64_t)0x7fffffff) : 0);
+  // Stores go through a buffer descriptor whose extent ends at the end of the epoch:
+  // samples past it (and whole blocks past the last one, which start beyond it) are
+  // dropped by the hardware range check, so the store loop carries no bound tests.
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;   // floats per output sample
+  const int64_t n_b = (int64_t)it.blk0 * hop * R;          // first sample of the block group
+  const int64_t left = a.epoch_len - n_b;
+  const unsigned ext_bytes = left > 0 ? (unsigned)min<int64_t>(left * (4 * kElem), (int64_t)0x7fffffff) : 0u;
   float* const out0 = a.out + ((int64_t)c * a.n_scales * a.n_samples + a.epoch_start + n_b) * kElem;
+  const unsigned voff0 = (unsigned)(off0 * (4 * kElem));   // negative (halo rows) wraps out of range
+  const unsigned vstep = (unsigned)(m1step * (4 * kElem));
   const v2f* const st_rd = stage + t;
   __syncthreads();
 
   for (int b = 0; b < lv.n_scales; ++b) {
-    const bool more = b + 1 < lv.n_scales;
-    v2f* const st_cur = stage;                 // single buffer: refilled between the barriers
+    if (b > 0 && (b & (kChunk - 1)) == 0) {    // wave-uniform
+      __syncthreads();                         // everyone is done with the previous chunk
+      fill_stage(b);
+      __syncthreads();
+    }
+    const v2f* const hs = st_rd + (b & (kChunk - 1)) * 256;
     v2f v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = cmulv(st_rd[16 * j], pw[j]);
-    float2 g = make_float2(0.f, 0.f);
-    if (more && tid < 256) g = a.bank[(int64_t)scales[b + 1] * 256 + tid];
+    for (int j = 0; j < 16; ++j) v[j] = cmulv(hs[16 * j], pw[j]);
     idft16v(v);
 #pragma unroll
     for (int j = 0; j < 16; ++j) exw[j * sstride] = cmulv(v[dft16_pos(j)], twl[16 * j + t]);
     __syncthreads();
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) v[k1] = exr[k1 * kPlane];
-    if (more && tid < 256) st_cur[tid] = (v2f){g.x, g.y};   // every thread is past this batch's reads
     __syncthreads();
     idft16v(v);
 
-    float* const dst = out0 + (int64_t)scales[b] * a.n_samples * kElem;
+    // descriptor built from provably wave-uniform words (else hipcc waterfalls every store)
+    const int srow = __builtin_amdgcn_readfirstlane(sc_lds[b]);
+    const uint64_t dst_bits = reinterpret_cast<uint64_t>(out0 + (int64_t)srow * a.n_samples * kElem);
+    const uint32_t dst_lo = __builtin_amdgcn_readfirstlane((uint32_t)dst_bits);
+    const uint32_t dst_hi = __builtin_amdgcn_readfirstlane((uint32_t)(dst_bits >> 32));
+    float* const dst = reinterpret_cast<float*>(((uint64_t)dst_hi << 32) | dst_lo);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        dst, 0, __builtin_amdgcn_readfirstlane(ext_bytes), 0x00020000);
 #pragma unroll
     for (int m1 = 1; m1 < 15; ++m1) {
       const v2f z = v[dft16_pos(m1)];
       const bool keep = m1 == 1 ? keep1 : (m1 == 14 ? keep14 : true);
-      const int off = off0 + m1 * m1step;
+      const unsigned vo = voff0 + (unsigned)m1 * vstep;
       if (MODE == GCWT_OUT_COMPLEX_C64) {
-        if (keep && off < lim) reinterpret_cast<v2f*>(dst)[off] = z;
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        if (keep) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, z), rsrc, vo, 0, 0);
       } else {
         const float p2 = z.x * z.x + z.y * z.y;
         const float val = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2) : p2;
-        if (keep && off < lim) dst[off] = val;
+        if (keep) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc, vo, 0, 0);
       }
     }
   }
@@ -194,7 +218,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
 template <int NCOL>
 static hipError_t launch_synth7_n(int mode, const Synth7Args& a, int n_items, int n_channels,
                                   hipStream_t st) {
-  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 2 * 256 * 8;
+  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 4 * 256 * 8 + 256 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_AMPLITUDE_F32, NCOL>,
