@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GHOSTCWT_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "libghostcwt.so")
 
 OUT_AMPLITUDE, OUT_POWER, OUT_COMPLEX = 0, 1, 2
-X_ON_DEVICE, OUT_ON_DEVICE = 1, 2
+X_ON_DEVICE, OUT_ON_DEVICE, REUSE_MEANS = 1, 2, 4
 SCALE_SPECTRAL, SCALE_DIRECT = 0, 1
 ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_COMM = -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
@@ -32,7 +32,8 @@ class Params(C.Structure):
                 ("fs", C.c_double), ("gamma", C.c_double), ("beta", C.c_double),
                 ("freqs_hz", C.POINTER(C.c_double)), ("n_epochs", C.c_int32),
                 ("out_mode", C.c_int32), ("epoch_bounds", C.POINTER(C.c_int64)),
-                ("device", C.c_int32), ("block", C.c_int32), ("band_eps", C.c_double)]
+                ("device", C.c_int32), ("block", C.c_int32), ("band_eps", C.c_double),
+                ("max_fft_log2", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PlanInfo(C.Structure):
@@ -74,6 +75,9 @@ def _load():
         "gcwt_plan_set_profiling": (C.c_int, [vp, C.c_int]),
         "gcwt_plan_upload": (C.c_int, [vp]),
         "gcwt_execute": (C.c_int, [vp, vp, vp, C.c_int]),
+        "gcwt_execute_block": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int]),
+        "gcwt_plan_segment_count": (C.c_int, [vp]),
+        "gcwt_plan_segment_info": (C.c_int, [vp, C.c_int, i64p, i64p, i64p]),
         "gcwt_filter_bank": (C.c_int, [vp, f32p]),
         "gcwt_direct_kernel": (C.c_int, [vp, C.c_int, f32p]),
         "gcwt_get_timings": (C.c_int, [vp, C.POINTER(Timings)]),

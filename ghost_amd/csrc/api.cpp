@@ -85,6 +85,7 @@ struct gcwt_plan {
   std::vector<Span> spans;
   gcwt_timings last{};
   bool have_timings = false;
+  bool have_means = false;
 };
 
 namespace {
@@ -206,7 +207,7 @@ int gcwt_plan_create(gcwt_plan** out, const gcwt_params* params) {
   // the plan keeps its own copies of the arrays
   p->hp.prm.freqs_hz = p->hp.freqs.data();
   p->hp.prm.epoch_bounds = p->hp.bounds.data();
-  p->hp.prm.n_epochs = (int32_t)p->hp.epochs.size();
+  p->hp.prm.n_epochs = (int32_t)(p->hp.bounds.size() / 2);
   p->device = params->device;
   if (const char* e = getenv("GHOSTCWT_SYNTH16")) p->use_synth16 = e[0] == '1';
   if (const char* e = getenv("GHOSTCWT_SYNTH_COLS")) p->synth_cols = atoi(e) == 16 ? 16 : 32;
@@ -335,7 +336,7 @@ int gcwt_plan_upload(gcwt_plan* p) {
       items[i] = {ep.items[i].level, ep.items[i].scale, ep.items[i].blk0, ep.items[i].nblk};
     std::vector<SynthLevelDev> lv(hp.levels.size());
     for (size_t l = 0; l < lv.size(); ++l)
-      lv[l] = {hp.levels[l].decimation, hp.levels[l].hop, hp.levels[l].halo, 0,
+      lv[l] = {hp.levels[l].decimation, hp.levels[l].hop, hp.levels[l].halo, ep.lv[l].blk_lo,
                ep.lv[l].xb_offset, hp.levels[l].twiddle_offset};
     if ((rc = upload_vec(&p->ep_dev[e].items, items, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels, lv, p->stream))) return bail(rc);
@@ -346,7 +347,7 @@ int gcwt_plan_upload(gcwt_plan* p) {
       int lg = 0;
       while ((1 << lg) < lp.decimation) ++lg;
       lv7[l] = {lp.decimation, lg, lp.hop, lp.halo, ep.lv[l].nblk, (int32_t)lp.scales.size(),
-                scale_off[l], 0, ep.lv[l].xb_offset, lp.twiddle_offset};
+                scale_off[l], ep.lv[l].blk_lo, ep.lv[l].xb_offset, lp.twiddle_offset};
       const int bpb = std::max(1, p->synth_cols / lp.decimation);
       const int n_rtiles = std::max(1, lp.decimation / p->synth_cols);
       for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
@@ -369,7 +370,10 @@ int gcwt_plan_upload(gcwt_plan* p) {
   return GCWT_OK;
 }
 
-static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
+// Computes samples [r0, r1) of every (channel, scale) row into rows of row_len samples
+// (column = sample - r0).  The full transform is r0 = 0, r1 = N, row_len = N.
+static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, int64_t r1,
+                        int64_t row_len, bool reuse_means) {
   const HostPlan& hp = p->hp;
   const int C = hp.prm.n_channels, S = hp.prm.n_freqs;
   const int64_t N = hp.prm.n_samples;
@@ -388,54 +392,67 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
     if (rc_) return rc_;                            \
   } while (0)
 
-  RUN(ST_MEAN, launch_channel_sum(dx, N, C, p->d_sums, st));
+  if (!reuse_means) RUN(ST_MEAN, launch_channel_sum(dx, N, C, p->d_sums, st));
 
   // samples outside every epoch are zero (transforms.py:185)
   {
-    int64_t cursor = 0;
+    int64_t cursor = r0;
     std::vector<std::pair<int64_t, int64_t>> eps;
-    for (const auto& e : hp.epochs) eps.push_back({e.start, e.stop});
+    for (size_t i = 0; i + 1 < hp.bounds.size(); i += 2) eps.push_back({hp.bounds[i], hp.bounds[i + 1]});
     std::sort(eps.begin(), eps.end());
     for (size_t i = 0; i <= eps.size(); ++i) {
-      int64_t gap_end = i < eps.size() ? eps[i].first : N;
+      const int64_t gap_end = std::min(r1, i < eps.size() ? eps[i].first : N);
       if (gap_end > cursor) {
-        he = launch_zero_range(dout, N * elem, (int64_t)C * S, cursor * elem, (gap_end - cursor) * elem, st);
+        he = launch_zero_range(dout, row_len * elem, (int64_t)C * S, (cursor - r0) * elem,
+                               (gap_end - cursor) * elem, st);
         if (he != hipSuccess) return hip_err(he, "zero_range");
       }
-      if (i < eps.size()) cursor = std::max(cursor, eps[i].second);
+      if (i < eps.size()) cursor = std::max(cursor, std::min(r1, eps[i].second));
     }
   }
 
   const bool any_spectral = hp.n_direct < S;
   const bool fast_fft = !getenv("GHOSTCWT_SLOW_FFT");
-  for (size_t e = 0; e < hp.epochs.size(); ++e) {
+  for (size_t e = 0; any_spectral && e < hp.epochs.size(); ++e) {
     const EpochPlan& ep = hp.epochs[e];
-    if (any_spectral) {
-      const int64_t P = ep.p;
-      const int P1 = ep.p1;
-      // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
-      RUN(ST_FWD, launch_fft_cols(-1, true, dx + ep.start, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0,
-                                  p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n, ep.ne, C, st));
-      // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]
-      RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, P1, kRowLen, kRowLen, P, P, 0,
-                                  p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st,
-                                  kRowLen / 2));   // only X[k < P/2] is ever read
-      for (size_t l = 0; l < hp.levels.size(); ++l) {
-        const LevelPlan& lp = hp.levels[l];
-        const EpochLevel& el = ep.lv[l];
+    // output window of this segment, segment-local: core of the segment, cut to the range
+    const int64_t w_lo = std::max(ep.core0, r0) - ep.start, w_hi = std::min(ep.core1, r1) - ep.start;
+    if (w_hi <= w_lo) continue;
+    const int64_t P = ep.p;
+    const int P1 = ep.p1;
+    // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
+    RUN(ST_FWD, launch_fft_cols(-1, true, dx + ep.start, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0,
+                                p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n,
+                                ep.ne, C, st));
+    // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]
+    RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, P1, kRowLen, kRowLen, P, P, 0,
+                                p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st,
+                                kRowLen / 2));   // only X[k < P/2] is ever read
+    for (size_t l = 0; l < hp.levels.size(); ++l) {
+      const LevelPlan& lp = hp.levels[l];
+      const EpochLevel& el = ep.lv[l];
+      float2* xr = p->d_xr + el.xr_offset;
+      if (lp.decimation <= kMaxTwoPassDecimation) {
         const int Q = kRowLen / lp.decimation;
-        float2* xr = p->d_xr + el.xr_offset;
         // x_R[Q m1 + m2] = sum_{j1} e^{2 pi i j1 m1/P1} e^{2 pi i j1 m2/M} sum_{j2} X~[j1][j2] e^{2 pi i j2 m2/Q}
         RUN(ST_DECIM, launch_fft_rows(+1, p->d_x, xr, Q, P1, kRowLen, Q, P, hp.max_xr,
-                                      P1 > 1 ? el.m : 0, p->d_tw4096, fast_fft ? p->d_tw256 : nullptr,
-                                      1.0f, C, st));
+                                      P1 > 1 ? el.m : 0, p->d_tw4096,
+                                      fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st));
         if (P1 > 1)
           RUN(ST_DECIM, launch_fft_cols(+1, false, xr, xr, P1, Q, hp.max_xr, hp.max_xr, 0,
-                                        p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n, 0, C, st));
-        const float scale = (float)(1.0 / ((double)hp.block * (double)P));
-        RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.nblk,
-                                       hp.max_xr, hp.max_xb, p->d_tw256, scale, C, st));
+                                        p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums,
+                                        inv_n, 0, C, st));
+      } else {
+        // M = P/R <= 8192: rows j1 < n1 of X~, q leading entries each
+        const int n1 = (int)std::min<int64_t>(P1, el.m);
+        const int q = (int)(el.m / n1);
+        RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, C, st));
       }
+      const float scale = (float)(1.0 / ((double)hp.block * (double)P));
+      RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.blk_lo,
+                                     el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, C, st));
+    }
+    if (p->use_synth16 || !hp.halo_static) {
       SynthArgs a{};
       a.xb = p->d_xb;
       a.bank = p->d_bank;
@@ -445,48 +462,55 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout) {
       a.levels = p->ep_dev[e].levels;
       a.out = dout;
       a.xb_cstride = hp.max_xb;
-      a.n_samples = N;
-      a.epoch_start = ep.start;
-      a.epoch_len = ep.ne;
+      a.row_len = row_len;
+      a.seg_col = ep.start - r0;
+      a.w_lo = w_lo;
+      a.w_hi = w_hi;
       a.n_scales = S;
-      if (p->use_synth16 || !hp.halo_static) {
-        RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), C, st));
-      } else {
-        Synth7Args a7{};
-        a7.xb = p->d_xb;
-        a7.bank = p->d_bank;
-        a7.tw256 = p->d_tw256;
-        a7.level_tw = p->d_level_tw;
-        a7.items = p->ep_dev[e].items7;
-        a7.levels = p->ep_dev[e].levels7;
-        a7.scale_list = p->d_scale_list;
-        a7.out = dout;
-        a7.xb_cstride = hp.max_xb;
-        a7.n_samples = N;
-        a7.epoch_start = ep.start;
-        a7.epoch_len = ep.ne;
-        a7.n_scales = S;
-        RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, p->ep_dev[e].n_items7, C, st));
-      }
-      if (p->profiling) p->last.synth_launches++;
+      RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), C, st));
+    } else {
+      Synth7Args a7{};
+      a7.xb = p->d_xb;
+      a7.bank = p->d_bank;
+      a7.tw256 = p->d_tw256;
+      a7.level_tw = p->d_level_tw;
+      a7.items = p->ep_dev[e].items7;
+      a7.levels = p->ep_dev[e].levels7;
+      a7.scale_list = p->d_scale_list;
+      a7.out = dout;
+      a7.xb_cstride = hp.max_xb;
+      a7.row_len = row_len;
+      a7.seg_col = ep.start - r0;
+      a7.w_lo = w_lo;
+      a7.w_hi = w_hi;
+      a7.n_scales = S;
+      RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, p->ep_dev[e].n_items7, C, st));
     }
-    if (hp.n_direct > 0)
-      RUN(ST_DIRECT, launch_direct(mode, dx, dout, p->d_psi, p->d_direct_sc, hp.n_direct, p->d_sums,
-                                   inv_n, N, S, ep.start, ep.ne, C, st));
+    if (p->profiling) p->last.synth_launches++;
+  }
+  if (hp.n_direct > 0) {
+    for (size_t i = 0; i + 1 < hp.bounds.size(); i += 2) {
+      const int64_t e0 = hp.bounds[i], e1 = hp.bounds[i + 1];
+      const int64_t g_lo = std::max(e0, r0), g_hi = std::min(e1, r1);
+      if (g_hi > g_lo)
+        RUN(ST_DIRECT, launch_direct(mode, dx, dout, p->d_psi, p->d_direct_sc, hp.n_direct,
+                                     p->d_sums, inv_n, N, S, e0, e1 - e0, g_lo, g_hi, r0, row_len,
+                                     C, st));
+    }
   }
 #undef RUN
   return GCWT_OK;
 }
 
-int gcwt_execute(gcwt_plan* p, const void* x, void* out, int flags) {
-  if (!p || !x || !out) return set_err(GCWT_ERR_INVALID, "NULL argument");
+static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int64_t r1, int flags) {
   int rc = gcwt_plan_upload(p);
   if (rc) return rc;
   if (p->device >= 0) HIP_TRY(hipSetDevice(p->device));
   const HostPlan& hp = p->hp;
+  const int64_t row_len = r1 - r0;
   const size_t in_bytes = sizeof(float) * (size_t)hp.prm.n_channels * (size_t)hp.prm.n_samples;
   const size_t out_bytes = hp.out_elem_bytes * (size_t)hp.prm.n_channels * (size_t)hp.prm.n_freqs *
-                           (size_t)hp.prm.n_samples;
+                           (size_t)row_len;
   const float* dx;
   float* dout;
   if (flags & GCWT_X_ON_DEVICE) {
@@ -513,8 +537,10 @@ int gcwt_execute(gcwt_plan* p, const void* x, void* out, int flags) {
   p->ev_used = 0;
   p->spans.clear();
   if (p->profiling) { p->last = gcwt_timings{}; }
-  rc = run_pipeline(p, dx, dout);
+  const bool reuse = (flags & GCWT_REUSE_MEANS) && p->have_means;
+  rc = run_pipeline(p, dx, dout, r0, r1, row_len, reuse);
   if (rc) { (void)hipStreamSynchronize(p->stream); return rc; }
+  p->have_means = true;
   if (!(flags & GCWT_OUT_ON_DEVICE))
     HIP_TRY(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -538,6 +564,33 @@ int gcwt_execute(gcwt_plan* p, const void* x, void* out, int flags) {
     p->last.direct_ms = acc[ST_DIRECT];
     p->have_timings = true;
   }
+  return GCWT_OK;
+}
+
+int gcwt_execute(gcwt_plan* p, const void* x, void* out, int flags) {
+  if (!p || !x || !out) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  return execute_range(p, x, out, 0, p->hp.prm.n_samples, flags & ~GCWT_REUSE_MEANS);
+}
+
+int gcwt_execute_block(gcwt_plan* p, const void* x, void* out, int64_t start, int64_t length,
+                       int flags) {
+  if (!p || !x || !out) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  if (start < 0 || length <= 0 || start + length > p->hp.prm.n_samples)
+    return set_err(GCWT_ERR_INVALID, "block range outside the recording");
+  return execute_range(p, x, out, start, start + length, flags);
+}
+
+int gcwt_plan_segment_count(const gcwt_plan* p) { return p ? (int)p->hp.epochs.size() : -1; }
+
+int gcwt_plan_segment_info(const gcwt_plan* p, int segment, int64_t* core_start, int64_t* core_stop,
+                           int64_t* fft_length) {
+  if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  if (segment < 0 || segment >= (int)p->hp.epochs.size())
+    return set_err(GCWT_ERR_INVALID, "segment out of range");
+  const EpochPlan& ep = p->hp.epochs[segment];
+  if (core_start) *core_start = ep.core0;
+  if (core_stop) *core_stop = ep.core1;
+  if (fft_length) *fft_length = ep.p;
   return GCWT_OK;
 }
 

@@ -32,7 +32,7 @@ struct SynthItemDev {
 };
 
 struct SynthLevelDev {
-  int32_t decimation, hop, halo, pad;
+  int32_t decimation, hop, halo, blk_base;   // block b of the level sits at XB index b - blk_base
   int64_t xb_offset;   // per-channel offset of this level's block spectra (complex elems)
   int64_t tw_offset;   // into level_tw
 };
@@ -46,9 +46,9 @@ struct SynthArgs {
   const SynthLevelDev* levels;
   float* out;
   int64_t xb_cstride;
-  int64_t n_samples;     // N, row length of out in samples
-  int64_t epoch_start;
-  int64_t epoch_len;
+  int64_t row_len;       // samples per (channel, scale) row of out
+  int64_t seg_col;       // column of the segment's sample 0 in an out row (may be negative)
+  int64_t w_lo, w_hi;    // segment-local samples [w_lo, w_hi) are written
   int32_t n_scales;
   int32_t pad;
 };
@@ -58,7 +58,7 @@ struct Synth7Item {
 };
 
 struct Synth7Level {
-  int32_t decimation, log2r, hop, halo, nblk, n_scales, scale_offset, pad;
+  int32_t decimation, log2r, hop, halo, nblk, n_scales, scale_offset, blk_base;
   int64_t xb_offset;   // per-channel offset of this level's block spectra (complex elems)
   int64_t tw_offset;   // into level_tw
 };
@@ -73,9 +73,9 @@ struct Synth7Args {
   const int32_t* scale_list;   // scale indices grouped by level
   float* out;
   int64_t xb_cstride;
-  int64_t n_samples;
-  int64_t epoch_start;
-  int64_t epoch_len;
+  int64_t row_len;       // samples per (channel, scale) row of out
+  int64_t seg_col;       // column of the segment's sample 0 in an out row (may be negative)
+  int64_t w_lo, w_hi;    // segment-local samples [w_lo, w_hi) are written
   int32_t n_scales;
   int32_t pad;
 };
@@ -97,14 +97,21 @@ hipError_t launch_fft_rows(int sign, const float2* in, float2* out, int len, int
                            int64_t in_ld, int64_t out_ld, int64_t in_cstride, int64_t out_cstride,
                            int64_t tw_n, const float2* tw4096, const float2* tw256, float scale,
                            int n_channels, hipStream_t st, int out_len = 0);
-hipError_t launch_block_fft(const float2* xr, float2* xb, int64_t m, int hop, int halo, int nblk,
+hipError_t launch_block_fft(const float2* xr, float2* xb, int64_t m, int hop, int halo, int blk_lo,
+                            int nblk,
                             int64_t xr_cstride, int64_t xb_cstride, const float2* tw256, float scale,
                             int n_channels, hipStream_t st);
 hipError_t launch_synth(int mode, const SynthArgs& a, int n_items, int n_channels, hipStream_t st);
+// epoch [epoch_start, epoch_start + epoch_len); samples [g_lo, g_hi) of it are computed and
+// written at column (n - col0) of rows of row_len samples
 hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi,
                          const DirectScale* sc, int n_direct, const double* sums, double inv_n,
                          int64_t n_samples, int n_scales, int64_t epoch_start, int64_t epoch_len,
-                         int n_channels, hipStream_t st);
+                         int64_t g_lo, int64_t g_hi, int64_t col0, int64_t row_len, int n_channels,
+                         hipStream_t st);
+hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_t p1_stride,
+                              int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,
+                              int n_channels, hipStream_t st);
 hipError_t launch_zero_range(float* out, int64_t row_len_floats, int64_t n_rows, int64_t start,
                              int64_t len, hipStream_t st);
 

@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in
 // 16 blocks per workgroup, 16 threads per block.  grid (ceil(nblk/16), C)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_block_fft(const cf* __restrict__ xr, cf* __restrict__ xb,
-                                                   int64_t m_mask, int hop, int halo, int nblk,
+                                                   int64_t m_mask, int hop, int halo, int blk_lo, int nblk,
                                                    int64_t xr_cstride, int64_t xb_cstride,
                                                    const cf* __restrict__ tw256, float scale) {
   __shared__ float ex_re[16 * kExCol];
@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(256) k_block_fft(const cf* __restrict__ xr, cf
   }
   cf v[16];
   const cf* x = xr + (int64_t)c * xr_cstride;
-  const int64_t base = (int64_t)blk * hop - halo + t;
+  const int64_t base = (int64_t)(blk_lo + blk) * hop - halo + t;   // block blk_lo + blk -> XB[blk]
 #pragma unroll
   for (int j = 0; j < 16; ++j)
     v[j] = valid ? x[(base + 16 * j) & m_mask] : make_float2(0.f, 0.f);
@@ -580,8 +580,7 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
 
   const cf* xb = a.xb + (int64_t)c * a.xb_cstride + lv.xb_offset;
   const cf* ltw = a.level_tw + lv.tw_offset;
-  float* out = a.out + ((int64_t)c * a.n_scales + it.scale) * a.n_samples * kElem +
-               a.epoch_start * kElem;
+  float* out = a.out + (((int64_t)c * a.n_scales + it.scale) * a.row_len + a.seg_col) * kElem;
 
   const int ncols = it.nblk * R;
   // per batch geometry of the staged tile
@@ -591,7 +590,7 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
     const bool valid = col < ncols;
     const int blk_l = col / R;           // block within the item
     const int r = col - blk_l * R;
-    const int blk = it.blk0 + blk_l;
+    const int blk = it.blk0 + blk_l;     // index into the level's computed blocks
 
     cf v[16];
     if (valid) {
@@ -634,17 +633,17 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
       int count;  // staged samples
       if (R <= 16) {
         const int nb = min(16 / R, it.nblk - blk_b);
-        n0 = (int64_t)(it.blk0 + blk_b) * hop * R;
+        n0 = (int64_t)(lv.blk_base + it.blk0 + blk_b) * hop * R;
         count = nb * hop * R;
       } else {
-        const int blk_cur = it.blk0 + col0 / R;
+        const int blk_cur = lv.blk_base + it.blk0 + col0 / R;
         const int r0 = col0 % R;
         n0 = (int64_t)blk_cur * hop * R + r0;
         count = hop * 16;
       }
       for (int q = threadIdx.x; q < count; q += 256) {
         const int64_t n = n0 + (int64_t)(q >> 4) * row_stride + (q & 15);
-        if (n < a.epoch_len) {
+        if (n >= a.w_lo && n < a.w_hi) {
           if (kElem == 1) out[n] = tile[q];
           else { out[2 * n] = tile[2 * q]; out[2 * n + 1] = tile[2 * q + 1]; }
         }
@@ -664,12 +663,14 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
                                                 const DirectScale* __restrict__ sc,
                                                 const double* __restrict__ sums, double inv_n,
                                                 int64_t n_samples, int n_scales,
-                                                int64_t epoch_start, int64_t epoch_len) {
+                                                int64_t epoch_start, int64_t epoch_len, int64_t g_lo,
+                                                int64_t g_hi, int64_t col0, int64_t row_len) {
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
   const DirectScale p = sc[blockIdx.y];
   const int c = blockIdx.z;
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= epoch_len) return;
+  const int64_t gn = g_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;   // sample index in the recording
+  if (gn >= g_hi) return;
+  const int64_t n = gn - epoch_start;                                  // index in the epoch
   const float mean = (float)(sums[c] * inv_n);
   const float* xe = x + (int64_t)c * n_samples + epoch_start;
   const cf* k = psi + p.offset;
@@ -683,10 +684,43 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
       im += xv * k[j].y;
     }
   }
-  float* o = out + ((int64_t)c * n_scales + p.scale) * n_samples * kElem + (epoch_start + n) * kElem;
+  float* o = out + (((int64_t)c * n_scales + p.scale) * row_len + (gn - col0)) * kElem;
   if (MODE == GCWT_OUT_AMPLITUDE_F32) o[0] = sqrtf(re * re + im * im);
   else if (MODE == GCWT_OUT_POWER_F32) o[0] = re * re + im * im;
   else { o[0] = re; o[1] = im; }
+}
+
+// ---------------------------------------------------------------------------
+// Level IFFT for decimations above 256 (M = P/R <= 8192 points): one workgroup per
+// channel gathers X~[j1][0:q], j1 < n1, applies the length-q row DFT and the
+// W_M^(j1 m2) twiddle directly, and runs the length-n1 column FFTs in LDS.
+//   x_R[q m1 + m2] = sum_j1 e^{2 pi i j1 m1/n1} e^{2 pi i j1 m2/M} sum_j2 X~[j1][j2] e^{2 pi i j2 m2/q}
+// grid (C), dynamic LDS n1*q*8 bytes
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_level_small(const cf* __restrict__ x, cf* __restrict__ xr,
+                                                     int n1, int log2n1, int q, int64_t row_stride,
+                                                     int64_t x_cstride, int64_t xr_cstride,
+                                                     const cf* __restrict__ tw4096) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* buf = reinterpret_cast<cf*>(smem);
+  const cf* xc = x + (int64_t)blockIdx.x * x_cstride;
+  const int m = n1 * q;
+  for (int idx = threadIdx.x; idx < m; idx += 256) {
+    const int j1 = idx / q, m2 = idx - j1 * q;
+    cf acc = make_float2(0.f, 0.f);
+    for (int j2 = 0; j2 < q; ++j2) {
+      const cf v = xc[(int64_t)j1 * row_stride + j2];
+      acc = cadd(acc, cmul(v, unit_phase((int64_t)j2 * m2, q, 1)));
+    }
+    buf[idx] = cmul(acc, unit_phase((int64_t)j1 * m2, m, 1));
+  }
+  __syncthreads();
+  if (n1 > 1) lds_fft_radix2<1>(buf, n1, log2n1, q, 1, q, tw4096);
+  cf* o = xr + (int64_t)blockIdx.x * xr_cstride;
+  for (int idx = threadIdx.x; idx < m; idx += 256) {
+    const int m1 = idx / q, m2 = idx - m1 * q;
+    o[idx] = buf[bitrev(m1, log2n1) * q + m2];
+  }
 }
 
 // zero [start, stop) of every (channel, scale) row.  grid (ceil(len/256), C*S)
@@ -803,11 +837,11 @@ hipError_t launch_fft_rows(int sign, const cf* in, cf* out, int len, int64_t n_r
   return hipSuccess;
 }
 
-hipError_t launch_block_fft(const cf* xr, cf* xb, int64_t m, int hop, int halo, int nblk,
+hipError_t launch_block_fft(const cf* xr, cf* xb, int64_t m, int hop, int halo, int blk_lo, int nblk,
                             int64_t xr_cstride, int64_t xb_cstride, const cf* tw256, float scale,
                             int n_channels, hipStream_t st) {
   dim3 grid((nblk + 15) / 16, n_channels), block(256);
-  hipLaunchKernelGGL(k_block_fft, grid, block, 0, st, xr, xb, m - 1, hop, halo, nblk, xr_cstride,
+  hipLaunchKernelGGL(k_block_fft, grid, block, 0, st, xr, xb, m - 1, hop, halo, blk_lo, nblk, xr_cstride,
                      xb_cstride, tw256, scale);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
@@ -828,17 +862,35 @@ hipError_t launch_synth(int mode, const SynthArgs& a, int n_items, int n_channel
 
 hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, const DirectScale* sc,
                          int n_direct, const double* sums, double inv_n, int64_t n_samples,
-                         int n_scales, int64_t epoch_start, int64_t epoch_len, int n_channels,
+                         int n_scales, int64_t epoch_start, int64_t epoch_len, int64_t g_lo,
+                         int64_t g_hi, int64_t col0, int64_t row_len, int n_channels,
                          hipStream_t st) {
-  if (n_direct == 0) return hipSuccess;
-  dim3 grid((unsigned)((epoch_len + 255) / 256), n_direct, n_channels), block(256);
+  if (n_direct == 0 || g_hi <= g_lo) return hipSuccess;
+  dim3 grid((unsigned)((g_hi - g_lo + 255) / 256), n_direct, n_channels), block(256);
 #define GCWT_DIRECT(M)                                                                       \
   hipLaunchKernelGGL((k_direct<M>), grid, block, 0, st, x, out, psi, sc, sums, inv_n,        \
-                     n_samples, n_scales, epoch_start, epoch_len)
+                     n_samples, n_scales, epoch_start, epoch_len, g_lo, g_hi, col0, row_len)
   if (mode == GCWT_OUT_AMPLITUDE_F32) GCWT_DIRECT(GCWT_OUT_AMPLITUDE_F32);
   else if (mode == GCWT_OUT_POWER_F32) GCWT_DIRECT(GCWT_OUT_POWER_F32);
   else GCWT_DIRECT(GCWT_OUT_COMPLEX_C64);
 #undef GCWT_DIRECT
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_level_small(const cf* x, cf* xr, int n1, int q, int64_t row_stride,
+                              int64_t x_cstride, int64_t xr_cstride, const cf* tw4096,
+                              int n_channels, hipStream_t st) {
+  const size_t lds = (size_t)n1 * q * sizeof(cf);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_level_small,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_level_small, dim3(n_channels), dim3(256), lds, st, x, xr, n1, ilog2(n1), q,
+                     row_stride, x_cstride, xr_cstride, tw4096);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

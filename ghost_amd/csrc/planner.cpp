@@ -97,23 +97,41 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     }
   }
 
-  // per-epoch FFT length
-  hp->epochs.resize(n_ep);
+  // segments: one per epoch, or overlapping time blocks when an epoch needs a longer FFT
+  hp->max_fft_log2 = prm.max_fft_log2 == 0 ? 22 : prm.max_fft_log2;
+  if (hp->max_fft_log2 < 12 || hp->max_fft_log2 > 22)
+    return fail(GCWT_ERR_INVALID, "max_fft_log2 must be 0 or 12..22");
+  const int64_t pmax = (int64_t)1 << hp->max_fft_log2;
   int64_t pmin = INT64_MAX;
   for (int e = 0; e < n_ep; ++e) {
-    EpochPlan& ep = hp->epochs[e];
-    ep.start = hp->bounds[2 * e];
-    ep.stop = hp->bounds[2 * e + 1];
-    ep.ne = ep.stop - ep.start;
-    ep.p = std::max<int64_t>(kRowLen, next_pow2(ep.ne + lmax_spec));
-    if (ep.p > (int64_t)kRowLen * kMaxP1)
+    const int64_t e0 = hp->bounds[2 * e], e1 = hp->bounds[2 * e + 1];
+    auto add = [&](int64_t in0, int64_t in1, int64_t c0, int64_t c1, int64_t p) {
+      EpochPlan ep;
+      ep.start = in0; ep.stop = in1; ep.ne = in1 - in0;
+      ep.core0 = c0; ep.core1 = c1; ep.epoch = e;
+      ep.p = p; ep.p1 = (int)(p / kRowLen);
+      pmin = std::min(pmin, p);
+      hp->max_p = std::max(hp->max_p, p);
+      hp->epochs.push_back(ep);
+    };
+    const int64_t whole = std::max<int64_t>(kRowLen, next_pow2(e1 - e0 + lmax_spec));
+    if (whole <= pmax) {
+      add(e0, e1, e0, e1, whole);
+      continue;
+    }
+    // time blocks: every output sample needs the input within (L-1)/2 of it
+    const int64_t halo_s = lmax_spec / 2 + 2;
+    const int64_t core_len = pmax - 2 * halo_s;
+    if (core_len < pmax / 4)
       return fail(GCWT_ERR_UNSUPPORTED,
-                  "epoch + kernel longer than 2^22 samples: split the recording into "
-                  "time blocks (streaming front end is not built yet)");
-    ep.p1 = (int)(ep.p / kRowLen);
-    pmin = std::min(pmin, ep.p);
-    hp->max_p = std::max(hp->max_p, ep.p);
+                  "longest wavelet is too long for time blocks of 2^max_fft_log2 samples");
+    for (int64_t c0 = e0; c0 < e1; c0 += core_len) {
+      const int64_t c1 = std::min(e1, c0 + core_len);
+      add(std::max(e0, c0 - halo_s), std::min(e1, c1 + halo_s), c0, c1, pmax);
+    }
   }
+  const int n_seg = (int)hp->epochs.size();
+  (void)n_seg;
 
   // decimation factor per spectral scale, levels
   const int r_cap = (int)std::min<int64_t>(kMaxDecimation, pmin / B);
@@ -163,13 +181,16 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       const LevelPlan& lp = hp->levels[l];
       EpochLevel& el = ep.lv[l];
       el.m = ep.p / lp.decimation;
-      int64_t n_dec = (ep.ne + lp.decimation - 1) / lp.decimation;
-      el.nblk = (int)((n_dec + lp.hop - 1) / lp.hop);
+      // blocks whose kept samples [b*hop*R, (b+1)*hop*R) meet the output range (segment-local)
+      const int64_t w_lo = ep.core0 - ep.start, w_hi = ep.core1 - ep.start;
+      const int64_t span = (int64_t)lp.hop * lp.decimation;
+      el.blk_lo = (int)(w_lo / span);
+      el.nblk = (int)((w_hi + span - 1) / span) - el.blk_lo;
       el.xr_offset = xr;
       el.xb_offset = xb;
       xr += el.m;
       xb += (int64_t)el.nblk * B;
-      const int group = std::max(1, 64 / lp.decimation);
+      const int group = std::max(1, 64 / std::min(lp.decimation, 64));
       for (int b0 = 0; b0 < el.nblk; b0 += group) {
         for (int s : lp.scales) {
           SynthItem it{(int32_t)l, (int32_t)s, (int32_t)b0,

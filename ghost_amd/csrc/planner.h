@@ -17,7 +17,8 @@ namespace gcwt {
 
 constexpr int kRowLen = 4096;      // row length of the two-pass big FFT (P = P1 * 4096)
 constexpr int kMaxP1 = 1024;       // P <= 2^22
-constexpr int kMaxDecimation = 256;
+constexpr int kMaxDecimation = 16384;
+constexpr int kMaxTwoPassDecimation = 256;   // above it the level IFFT uses the small-size kernel
 constexpr int kSynthCols = 16;     // columns (block, r) per batch of the 16-column kernel
 constexpr int kSynthWide = 32;      // columns per batch of the production kernel
 
@@ -42,7 +43,8 @@ struct LevelPlan {
 
 struct EpochLevel {
   int64_t m = 0;                   // decimated length M = P / R
-  int nblk = 0;
+  int blk_lo = 0;                  // first block that touches the segment's output range
+  int nblk = 0;                    // blocks blk_lo .. blk_lo + nblk - 1 are computed
   int64_t xr_offset = 0;           // per-channel offsets, complex elements
   int64_t xb_offset = 0;
 };
@@ -51,8 +53,13 @@ struct SynthItem {                 // one workgroup of the synthesis kernel
   int32_t level, scale, blk0, nblk;
 };
 
+// One FFT-sized piece of work: a whole epoch, or a time block of a long epoch with a
+// halo of input on each side.  Input samples [start, stop) (clipped to the epoch, zero
+// outside it); output samples [core0, core1).
 struct EpochPlan {
   int64_t start = 0, stop = 0, ne = 0;
+  int64_t core0 = 0, core1 = 0;
+  int epoch = 0;
   int64_t p = 0;                   // FFT length of this epoch
   int p1 = 0;                      // p = p1 * kRowLen
   std::vector<EpochLevel> lv;      // one per HostPlan::levels
@@ -71,13 +78,14 @@ struct HostPlan {
   double u_lo = 0, u_hi = 0;       // filter support [u_lo, u_hi] * omega at band_eps
   std::vector<ScalePlan> scales;
   std::vector<LevelPlan> levels;
-  std::vector<EpochPlan> epochs;
+  std::vector<EpochPlan> epochs;   // segments, in time order
   bool halo_static = true;         // every level has 16 <= halo <= 32 (fast synthesis kernel)
   double halo_frac = 0.82;         // kernel support kept, as a fraction of the reference length L
   int n_direct = 0;
   int64_t direct_total = 0;        // complex elements of all direct kernels
   int64_t level_twiddle_total = 0;
   int64_t max_p = 0, max_xr = 0, max_xb = 0;
+  int max_fft_log2 = 22;
   size_t out_elem_bytes = 4;
   int64_t workspace_bytes = 0;
 };

@@ -134,7 +134,9 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   fill_stage(0);
   v2f pw[16];
   {
-    const int blk = min(it.blk0 + blk_l, lv.nblk - 1);   // past-the-end columns: never stored
+    // it.blk0 counts from the level's first computed block (lv.blk_base); columns past
+    // the last block reuse it and are never stored
+    const int blk = min(it.blk0 + blk_l, lv.nblk - 1);
     const float2* xb = a.xb + (int64_t)c * a.xb_cstride + lv.xb_offset + (int64_t)blk * 256 + t;
     const float2* ltw = a.level_tw + lv.tw_offset;
     const float2 b0 = ltw[t * r], st = ltw[16 * r];
@@ -158,15 +160,16 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   const int m1step = 16 * R;
   const bool keep1 = m2 >= halo - 16, keep14 = m2 < 32 - halo;
 
-  // Stores go through a buffer descriptor whose extent ends at the end of the epoch:
-  // samples past it (and whole blocks past the last one, which start beyond it) are
+  // Stores go through a buffer descriptor that covers exactly the samples this launch
+  // may write, [w_lo, w_hi) of the segment: anything else -- halo rows (negative offsets
+  // wrap), the end of the epoch, blocks past the last one, neighbouring time blocks -- is
   // dropped by the hardware range check, so the store loop carries no bound tests.
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;   // floats per output sample
-  const int64_t n_b = (int64_t)it.blk0 * hop * R;          // first sample of the block group
-  const int64_t left = a.epoch_len - n_b;
-  const unsigned ext_bytes = left > 0 ? (unsigned)min<int64_t>(left * (4 * kElem), (int64_t)0x7fffffff) : 0u;
-  float* const out0 = a.out + ((int64_t)c * a.n_scales * a.n_samples + a.epoch_start + n_b) * kElem;
-  const unsigned voff0 = (unsigned)(off0 * (4 * kElem));   // negative (halo rows) wraps out of range
+  const int64_t n_b = (int64_t)(lv.blk_base + it.blk0) * hop * R;   // first sample of the block group
+  const int64_t w_len = a.w_hi - a.w_lo;
+  const unsigned ext_bytes = w_len > 0 ? (unsigned)(w_len * (4 * kElem)) : 0u;
+  float* const out0 = a.out + ((int64_t)c * a.n_scales * a.row_len + a.seg_col + a.w_lo) * kElem;
+  const unsigned voff0 = (unsigned)(((int)(n_b - a.w_lo) + off0) * (4 * kElem));
   const unsigned vstep = (unsigned)(m1step * (4 * kElem));
   const v2f* const st_rd = stage + t;
   __syncthreads();
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
 
     // descriptor built from provably wave-uniform words (else hipcc waterfalls every store)
     const int srow = __builtin_amdgcn_readfirstlane(sc_lds[b]);
-    const uint64_t dst_bits = reinterpret_cast<uint64_t>(out0 + (int64_t)srow * a.n_samples * kElem);
+    const uint64_t dst_bits = reinterpret_cast<uint64_t>(out0 + (int64_t)srow * a.row_len * kElem);
     const uint32_t dst_lo = __builtin_amdgcn_readfirstlane((uint32_t)dst_bits);
     const uint32_t dst_hi = __builtin_amdgcn_readfirstlane((uint32_t)(dst_bits >> 32));
     float* const dst = reinterpret_cast<float*>(((uint64_t)dst_hi << 32) | dst_lo);

@@ -75,7 +75,8 @@ class CwtPlan:
     frequencies in the order the output rows are wanted."""
 
     def __init__(self, n_samples, n_channels, fs, freqs_hz, *, gamma=3.0, beta=20.0,
-                 epoch_bounds=None, output="amplitude", device=-1, band_eps=0.0, block=0):
+                 epoch_bounds=None, output="amplitude", device=-1, band_eps=0.0, block=0,
+                 max_fft_log2=0):
         self._handle = C.c_void_p()
         self.freqs = np.ascontiguousarray(freqs_hz, dtype=np.float64)
         if epoch_bounds is None:
@@ -96,6 +97,7 @@ class CwtPlan:
         p.device = int(device)
         p.block = int(block)
         p.band_eps = float(band_eps)
+        p.max_fft_log2 = int(max_fft_log2)
         check(lib.gcwt_plan_create(C.byref(self._handle), C.byref(p)))
         self.n_samples, self.n_channels = int(n_samples), int(n_channels)
         self.n_freqs = int(self.freqs.size)
@@ -147,6 +149,31 @@ class CwtPlan:
         xp = x_buf.ptr if isinstance(x_buf, DeviceBuffer) else x_buf
         op = out_buf.ptr if isinstance(out_buf, DeviceBuffer) else out_buf
         check(lib.gcwt_execute(self._handle, xp, op, _lib.X_ON_DEVICE | _lib.OUT_ON_DEVICE))
+
+    def segments(self):
+        """[(core_start, core_stop, fft_length)] of the time blocks the plan works in."""
+        res = []
+        for i in range(lib.gcwt_plan_segment_count(self._handle)):
+            a, b, p = C.c_int64(), C.c_int64(), C.c_int64()
+            check(lib.gcwt_plan_segment_info(self._handle, i, C.byref(a), C.byref(b), C.byref(p)))
+            res.append((a.value, b.value, p.value))
+        return res
+
+    def execute_block(self, x, start, length, reuse_means=False):
+        """Samples [start, start+length) of every channel and scale from the whole
+        recording x (C, N): ndarray (C, S, length).  Host in, host out."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.n_channels, self.n_samples)
+        out = np.empty((self.n_channels, self.n_freqs, int(length)), dtype=self.out_dtype)
+        check(lib.gcwt_execute_block(self._handle, x.ctypes.data_as(C.c_void_p),
+                                     out.ctypes.data_as(C.c_void_p), int(start), int(length),
+                                     _lib.REUSE_MEANS if reuse_means else 0))
+        return out
+
+    def execute_block_device(self, x_buf, out_buf, start, length, reuse_means=False):
+        xp = x_buf.ptr if isinstance(x_buf, DeviceBuffer) else x_buf
+        op = out_buf.ptr if isinstance(out_buf, DeviceBuffer) else out_buf
+        flags = _lib.X_ON_DEVICE | _lib.OUT_ON_DEVICE | (_lib.REUSE_MEANS if reuse_means else 0)
+        check(lib.gcwt_execute_block(self._handle, xp, op, int(start), int(length), flags))
 
     def filter_bank(self):
         b = self.info["block"]

@@ -56,7 +56,9 @@ typedef enum {
 
 enum {
   GCWT_X_ON_DEVICE = 1,   /* gcwt_execute: x is a device pointer                 */
-  GCWT_OUT_ON_DEVICE = 2  /* gcwt_execute: out is a device pointer               */
+  GCWT_OUT_ON_DEVICE = 2, /* gcwt_execute: out is a device pointer               */
+  GCWT_REUSE_MEANS = 4    /* gcwt_execute_block: keep the channel means of the
+                             previous call on this plan (same x)                 */
 };
 
 typedef struct gcwt_plan gcwt_plan;
@@ -74,6 +76,9 @@ typedef struct {
   int32_t device;              /* HIP ordinal; -1 = leave the current device      */
   int32_t block;               /* decimated block length B; 0 = default (256)     */
   double band_eps;             /* filter treated as 0 below eps*peak; 0 = 1e-9    */
+  int32_t max_fft_log2;        /* longest FFT the plan may use, 12..22; 0 = 22.  Epochs
+                                  that need more are cut into overlapping time blocks  */
+  int32_t reserved;
 } gcwt_params;
 
 typedef struct {
@@ -137,6 +142,20 @@ int gcwt_plan_upload(gcwt_plan* plan);
  * out: per out_mode, [C][S][N] row-major, scales in the order of freqs_hz.
  * Samples outside every epoch are written as 0 (transforms.py:185). */
 int gcwt_execute(gcwt_plan* plan, const void* x, void* out, int flags);
+
+/* Streaming form of the same transform for recordings whose output does not fit
+ * in memory: computes samples [start, start+length) of every channel and scale.
+ * x is the WHOLE recording, float32 [C][N] (the global mean and the kernels'
+ * support around the range are taken from it); out is [C][S][length].  Cheapest
+ * when ranges coincide with the plan's time blocks (gcwt_plan_segment_info).
+ * This is the overlap-save front end the reference sketches in
+ * ghost/wave/transforms.py:529-597 (_cwtft: chunks with both edges discarded). */
+int gcwt_execute_block(gcwt_plan* plan, const void* x, void* out, int64_t start, int64_t length,
+                       int flags);
+/* Time blocks the plan cuts the epochs into: output range [core_start, core_stop). */
+int gcwt_plan_segment_count(const gcwt_plan* plan);
+int gcwt_plan_segment_info(const gcwt_plan* plan, int segment, int64_t* core_start,
+                           int64_t* core_stop, int64_t* fft_length);
 
 /* Filter bank as held on the device, for parity tests of the bank builder:
  * bank: float32 (re,im) [S][B], H_s(2 pi k / (B R_s)), zero rows for direct

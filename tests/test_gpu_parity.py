@@ -199,3 +199,63 @@ def test_rccl_single_rank_communicator():
     check(lib.gcwt_comm_broadcast_bank(comm, plan._handle, 0))
     np.testing.assert_array_equal(plan.filter_bank(), before)
     lib.gcwt_comm_destroy(comm)
+
+
+def test_time_blocks_are_seamless(golden):
+    """Long epochs are processed in overlapping time blocks (transforms.py:529-597 sketches
+    the same both-edges-discarded scheme); the seams must not show."""
+    from ghost_amd.synthetic import lfp_channel
+    fs, n = 1000.0, 40000
+    x = lfp_channel(n, fs, 4)
+    f = [200.0, 77.0, 20.0]
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f)
+    p, c = _plan(x, fs, f, output="complex", max_fft_log2=13)
+    assert len(p.segments()) > 4
+    assert rel_err(c[0], ref).max() < TOL
+    p, a = _plan(x, fs, f, output="amplitude", max_fft_log2=13)
+    assert rel_err(a[0], np.abs(ref)).max() < TOL
+    # two epochs, the second one cut into blocks; plus a near-Nyquist (direct) scale
+    eb = [[0, 5000], [5000, 40000]]
+    f2 = [350.0, 120.0, 25.0]
+    ref2 = orc.cwt_complex(x.astype(np.float64), fs, f2, np.array(eb))
+    p, c2 = _plan(x, fs, f2, output="complex", epoch_bounds=eb, max_fft_log2=13)
+    assert p.scale_info()["method"].tolist() == [1, 0, 0]
+    assert rel_err(c2[0], ref2).max() < TOL
+
+
+def test_execute_block_streams_the_same_numbers():
+    """gcwt_execute_block: any sample range, from the whole recording, equals the slice of
+    the full transform (global mean included)."""
+    from ghost_amd.synthetic import lfp
+    fs, n = 1000.0, 30000
+    x = lfp(2, n, fs) + 0.75                     # non-zero mean: must be the recording's
+    f = [300.0, 150.0, 40.0, 12.0]
+    p, full = _plan(x, fs, f, output="amplitude", max_fft_log2=13)
+    segs = p.segments()
+    for (a, b, _) in (segs[0], segs[2], segs[-1]):
+        blk = p.execute_block(x, a, b - a)
+        np.testing.assert_array_equal(blk, full[:, :, a:b])
+    blk = p.execute_block(x, 7777, 9001, reuse_means=True)     # unaligned, spans several blocks
+    np.testing.assert_array_equal(blk, full[:, :, 7777:7777 + 9001])
+    p2, cfull = _plan(x, fs, f, output="complex")
+    np.testing.assert_array_equal(p2.execute_block(x, 100, 5000), cfull[:, :, 100:5100])
+
+
+def test_low_frequencies_at_high_sampling_rate():
+    """BASELINE config 5 regime (30 kHz, 1-500 Hz): decimation far beyond 256."""
+    from ghost_amd.synthetic import lfp_channel
+    fs = 30000.0
+    n = 300000
+    x = lfp_channel(n, fs, 8)
+    f = [500.0, 80.0, 12.0, 6.0]
+    p, c = _plan(x, fs, f, output="complex")
+    assert p.scale_info()["decimation"].tolist() == [32, 128, 1024, 2048]
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f)
+    assert rel_err(c[0], ref).max() < TOL
+    # 1 Hz at 30 kHz: 418 430-tap kernel, decimation 8192, in time blocks of 2^21
+    n = 1500000
+    x = lfp_channel(n, fs, 9)
+    p, a = _plan(x, fs, [1.0, 30.0], output="amplitude")
+    assert p.scale_info()["length"][0] == 418430 and p.scale_info()["decimation"][0] == 8192
+    ref = np.abs(orc.cwt_complex(x.astype(np.float64), fs, [1.0, 30.0]))
+    assert rel_err(a[0], ref).max() < TOL

@@ -234,10 +234,7 @@ def test_planner_rejects_bad_requests():
                     epoch_bounds=args["bounds"])
         assert e.value.code == _lib.ERR_INVALID
     with pytest.raises(GhostCwtError) as e:
-        CwtPlan(1 << 23, 1, 1000.0, [10.0])             # longer than 2^22: not built yet
-    assert e.value.code == _lib.ERR_UNSUPPORTED
-    with pytest.raises(GhostCwtError) as e:
-        CwtPlan(1 << 20, 1, 30000.0, [1.0])             # kernel too long for R <= 256
+        CwtPlan(1 << 20, 1, 30000.0, [0.13])            # 3.2 M-tap kernel: no room for time blocks
     assert e.value.code == _lib.ERR_UNSUPPORTED
 
 
@@ -251,3 +248,28 @@ def test_decimated_model_matches_oracle(golden):
     g = golden("g5_two_epochs.npz")
     c = cwt_decimated(g["x"], float(g["fs"]), g["frequencies"][::6], g["epoch_bounds"])
     assert rel_err(c[:, g["cols"]], g["complex_cols"][::6]).max() < 5e-7
+
+
+def test_time_blocks_tile_the_epochs():
+    """Epochs that need a longer FFT than allowed are cut into overlapping time blocks."""
+    f = [200.0, 77.0, 20.0]
+    p = CwtPlan(40000, 1, 1000.0, f, max_fft_log2=13)
+    seg = p.segments()
+    assert len(seg) > 4 and all(s[2] == 8192 for s in seg)
+    assert seg[0][0] == 0 and seg[-1][1] == 40000
+    assert all(a[1] == b[0] for a, b in zip(seg, seg[1:]))
+    # whole epochs when they fit; two epochs -> independent segment lists
+    p = CwtPlan(40000, 1, 1000.0, f, epoch_bounds=[[0, 5000], [5000, 40000]], max_fft_log2=14)
+    seg = p.segments()
+    assert seg[0][:2] == (0, 5000) and seg[1][0] == 5000 and seg[-1][1] == 40000
+    assert len(CwtPlan(40000, 1, 1000.0, f).segments()) == 1
+    with pytest.raises(GhostCwtError):
+        CwtPlan(40000, 1, 1000.0, f, max_fft_log2=9)
+    with pytest.raises(GhostCwtError):          # kernel of 6974 taps cannot live in 8192-sample blocks
+        CwtPlan(100000, 1, 1000.0, [2.0], max_fft_log2=13)
+    # the 2^22 limit now only bounds the block, not the recording
+    p = CwtPlan(1 << 23, 1, 1000.0, [10.0])
+    assert len(p.segments()) == 3
+    # low frequencies relative to fs: decimation beyond 256
+    p = CwtPlan(1 << 21, 1, 30000.0, [500.0, 6.0, 1.0])
+    assert p.scale_info()["decimation"].tolist() == [32, 2048, 16384]
