@@ -73,6 +73,7 @@ def _load():
         "gcwt_plan_get_info": (C.c_int, [vp, C.POINTER(PlanInfo)]),
         "gcwt_plan_scale_info": (C.c_int, [vp, i32p, i32p, i32p, i32p, i64p]),
         "gcwt_plan_set_profiling": (C.c_int, [vp, C.c_int]),
+        "gcwt_plan_set_row_pitch": (C.c_int, [vp, C.c_int64]),
         "gcwt_plan_upload": (C.c_int, [vp]),
         "gcwt_execute": (C.c_int, [vp, vp, vp, C.c_int]),
         "gcwt_execute_block": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int]),

@@ -86,6 +86,7 @@ struct gcwt_plan {
   gcwt_timings last{};
   bool have_timings = false;
   bool have_means = false;
+  int64_t row_pitch = 0;     // device output rows, samples; 0 = dense
 };
 
 namespace {
@@ -264,6 +265,12 @@ int gcwt_plan_set_profiling(gcwt_plan* plan, int enabled) {
   return GCWT_OK;
 }
 
+int gcwt_plan_set_row_pitch(gcwt_plan* plan, int64_t pitch_samples) {
+  if (!plan || pitch_samples < 0) return set_err(GCWT_ERR_INVALID, "bad row pitch");
+  plan->row_pitch = pitch_samples;
+  return GCWT_OK;
+}
+
 int gcwt_plan_upload(gcwt_plan* p) {
   if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
   if (p->uploaded) return GCWT_OK;
@@ -423,7 +430,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
     RUN(ST_FWD, launch_fft_cols(-1, true, dx + ep.start, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0,
                                 p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n,
-                                ep.ne, C, st));
+                                ep.ne, C, st, ep.lead));
     // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]
     RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, P1, kRowLen, kRowLen, P, P, 0,
                                 p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st,
@@ -507,10 +514,19 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   if (rc) return rc;
   if (p->device >= 0) HIP_TRY(hipSetDevice(p->device));
   const HostPlan& hp = p->hp;
-  const int64_t row_len = r1 - r0;
+  const int64_t n_out = r1 - r0;
+  const size_t rows = (size_t)hp.prm.n_channels * (size_t)hp.prm.n_freqs;
+  // host output: dense for the caller, padded to 32 samples on the device so that every
+  // row starts on a 128-byte boundary; device output: the caller's pitch (0 = dense)
+  int64_t row_len;
+  if (flags & GCWT_OUT_ON_DEVICE) {
+    row_len = p->row_pitch ? p->row_pitch : n_out;
+    if (row_len < n_out) return set_err(GCWT_ERR_INVALID, "row pitch shorter than the output rows");
+  } else {
+    row_len = (n_out + 31) & ~(int64_t)31;
+  }
   const size_t in_bytes = sizeof(float) * (size_t)hp.prm.n_channels * (size_t)hp.prm.n_samples;
-  const size_t out_bytes = hp.out_elem_bytes * (size_t)hp.prm.n_channels * (size_t)hp.prm.n_freqs *
-                           (size_t)row_len;
+  const size_t out_bytes = hp.out_elem_bytes * rows * (size_t)row_len;
   const float* dx;
   float* dout;
   if (flags & GCWT_X_ON_DEVICE) {
@@ -542,7 +558,9 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   if (rc) { (void)hipStreamSynchronize(p->stream); return rc; }
   p->have_means = true;
   if (!(flags & GCWT_OUT_ON_DEVICE))
-    HIP_TRY(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpy2DAsync(out, hp.out_elem_bytes * (size_t)n_out, dout,
+                             hp.out_elem_bytes * (size_t)row_len, hp.out_elem_bytes * (size_t)n_out,
+                             rows, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (p->profiling) {
     float acc[ST_COUNT] = {0};

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) k_fft_cols(const void* __restrict__ in_, 
                                                   int64_t out_cstride, int64_t tw_n,
                                                   const cf* __restrict__ tw4096,
                                                   const double* __restrict__ sums, double inv_n,
-                                                  int64_t n_valid) {
+                                                  int64_t n_valid, int64_t n_lead) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* buf = reinterpret_cast<cf*>(smem);
   const int c = blockIdx.y;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) k_fft_cols(const void* __restrict__ in_, 
     for (int e = threadIdx.x; e < total; e += 256) {
       const int i = e >> 4, cc = e & 15;
       const int64_t n = (int64_t)i * ld + col0 + cc;
-      buf[e] = make_float2(n < n_valid ? x[n] - mean : 0.f, 0.f);
+      buf[e] = make_float2(n >= n_lead && n < n_valid ? x[n] - mean : 0.f, 0.f);
     }
   } else {
     const cf* x = reinterpret_cast<const cf*>(in_) + (int64_t)c * in_cstride;
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in
                                                      int ld, int64_t in_cstride, int64_t out_cstride,
                                                      int64_t tw_n, const cf* __restrict__ tw256,
                                                      const double* __restrict__ sums, double inv_n,
-                                                     int64_t n_valid) {
+                                                     int64_t n_valid, int64_t n_lead) {
   __shared__ __attribute__((aligned(16))) cf tile[256 * 17];   // = 16 exchange planes, aliased
   float* const ex_re = reinterpret_cast<float*>(tile);
   float* const ex_im = ex_re + 16 * kExCol;
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in
     for (int e = tid; e < 4096; e += 256) {
       const int i = e >> 4, cc = e & 15;
       const int64_t n = (int64_t)i * ld + col0 + cc;
-      tile[i * 17 + cc] = make_float2(n < n_valid ? x[n] - mean : 0.f, 0.f);
+      tile[i * 17 + cc] = make_float2(n >= n_lead && n < n_valid ? x[n] - mean : 0.f, 0.f);
     }
   } else {
     const cf* x = reinterpret_cast<const cf*>(in_) + (int64_t)c * in_cstride;
@@ -772,17 +772,17 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int 
                            int64_t in_cstride, int64_t out_cstride, int64_t tw_n, const cf* tw4096,
                            const cf* tw256,
                            const double* sums, double inv_n, int64_t n_valid, int n_channels,
-                           hipStream_t st) {
+                           hipStream_t st, int64_t n_lead) {
   if (len == 256 && tw256) {
     dim3 grid(ld / 16, n_channels), block(256);
     if (sign < 0 && real_in)
-      hipLaunchKernelGGL((k_fft_cols256<-1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid);
+      hipLaunchKernelGGL((k_fft_cols256<-1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead);
     else if (sign < 0)
-      hipLaunchKernelGGL((k_fft_cols256<-1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid);
+      hipLaunchKernelGGL((k_fft_cols256<-1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead);
     else if (real_in)
-      hipLaunchKernelGGL((k_fft_cols256<1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid);
+      hipLaunchKernelGGL((k_fft_cols256<1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead);
     else
-      hipLaunchKernelGGL((k_fft_cols256<1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid);
+      hipLaunchKernelGGL((k_fft_cols256<1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead);
     GCWT_LAUNCH_CHECK();
     return hipSuccess;
   }
@@ -797,7 +797,7 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int 
       if (e != hipSuccess) return e;                                                              \
     }                                                                                             \
     hipLaunchKernelGGL((k_fft_cols<S, RI>), grid, block, lds, st, in, out, len, l2, ld,           \
-                       in_cstride, out_cstride, tw_n, tw4096, sums, inv_n, n_valid);              \
+                       in_cstride, out_cstride, tw_n, tw4096, sums, inv_n, n_valid, n_lead);              \
   }
   if (sign < 0 && real_in) GCWT_COLS(-1, true)
   else if (sign < 0) GCWT_COLS(-1, false)

@@ -107,27 +107,31 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     const int64_t e0 = hp->bounds[2 * e], e1 = hp->bounds[2 * e + 1];
     auto add = [&](int64_t in0, int64_t in1, int64_t c0, int64_t c1, int64_t p) {
       EpochPlan ep;
-      ep.start = in0; ep.stop = in1; ep.ne = in1 - in0;
+      ep.start = in0 & ~(int64_t)63;            // aligned; samples before the epoch read as zero
+      ep.lead = std::max<int64_t>(0, e0 - ep.start);
+      ep.stop = in1; ep.ne = in1 - ep.start;
       ep.core0 = c0; ep.core1 = c1; ep.epoch = e;
       ep.p = p; ep.p1 = (int)(p / kRowLen);
       pmin = std::min(pmin, p);
       hp->max_p = std::max(hp->max_p, p);
       hp->epochs.push_back(ep);
     };
-    const int64_t whole = std::max<int64_t>(kRowLen, next_pow2(e1 - e0 + lmax_spec));
+    const int64_t whole = std::max<int64_t>(kRowLen, next_pow2(e1 - (e0 & ~(int64_t)63) + lmax_spec));
     if (whole <= pmax) {
       add(e0, e1, e0, e1, whole);
       continue;
     }
-    // time blocks: every output sample needs the input within (L-1)/2 of it
+    // time blocks: every output sample needs the input within (L-1)/2 of it; block
+    // boundaries sit on multiples of 64 samples of the recording
     const int64_t halo_s = lmax_spec / 2 + 2;
-    const int64_t core_len = pmax - 2 * halo_s;
+    const int64_t core_len = (pmax - 2 * halo_s - 64) & ~(int64_t)63;
     if (core_len < pmax / 4)
       return fail(GCWT_ERR_UNSUPPORTED,
                   "longest wavelet is too long for time blocks of 2^max_fft_log2 samples");
-    for (int64_t c0 = e0; c0 < e1; c0 += core_len) {
-      const int64_t c1 = std::min(e1, c0 + core_len);
+    for (int64_t c0 = e0; c0 < e1;) {
+      const int64_t c1 = std::min(e1, (c0 + core_len) & ~(int64_t)63);
       add(std::max(e0, c0 - halo_s), std::min(e1, c1 + halo_s), c0, c1, pmax);
+      c0 = c1;
     }
   }
   const int n_seg = (int)hp->epochs.size();

@@ -54,11 +54,13 @@ struct SynthItem {                 // one workgroup of the synthesis kernel
 };
 
 // One FFT-sized piece of work: a whole epoch, or a time block of a long epoch with a
-// halo of input on each side.  Input samples [start, stop) (clipped to the epoch, zero
-// outside it); output samples [core0, core1).
+// halo of input on each side.  Input samples [start, stop) (zero outside the epoch);
+// `start` is a multiple of 64 so that every block's output lands on whole 128-byte lines
+// of rows that are themselves aligned; output samples [core0, core1).
 struct EpochPlan {
   int64_t start = 0, stop = 0, ne = 0;
   int64_t core0 = 0, core1 = 0;
+  int64_t lead = 0;                // leading samples of the segment that lie before the epoch (zero)
   int epoch = 0;
   int64_t p = 0;                   // FFT length of this epoch
   int p1 = 0;                      // p = p1 * kRowLen

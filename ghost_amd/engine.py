@@ -131,6 +131,11 @@ class CwtPlan:
     def set_profiling(self, on=True):
         check(lib.gcwt_plan_set_profiling(self._handle, 1 if on else 0))
 
+    def set_row_pitch(self, pitch_samples):
+        """Row pitch (samples) of device output buffers; 0 = dense.  Use a multiple of 32
+        when the row length is not one (see gcwt_plan_set_row_pitch)."""
+        check(lib.gcwt_plan_set_row_pitch(self._handle, int(pitch_samples)))
+
     def timings(self):
         t = _lib.Timings()
         check(lib.gcwt_get_timings(self._handle, C.byref(t)))

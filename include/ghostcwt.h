@@ -130,6 +130,11 @@ int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info);
 int gcwt_plan_scale_info(const gcwt_plan* plan, int32_t* method, int32_t* decimation,
                          int32_t* halo, int32_t* hop, int64_t* length);
 int gcwt_plan_set_profiling(gcwt_plan* plan, int enabled);
+/* Row pitch, in samples, of DEVICE output buffers (0 = dense rows of N, or of the block
+ * length).  Rows whose byte offset is not a multiple of 128 make every store straddle
+ * cache lines; pad rows to a multiple of 32 samples for full speed when N is not one.
+ * Host output buffers are always dense (the library pads internally). */
+int gcwt_plan_set_row_pitch(gcwt_plan* plan, int64_t pitch_samples);
 
 /* Device side ------------------------------------------------------------ */
 /* Allocate workspace, build the Morse filter bank and FFT tables on the
