@@ -882,7 +882,10 @@ hipError_t launch_level_small(const cf* x, cf* xr, int n1, int q, int64_t row_st
                               int64_t x_cstride, int64_t xr_cstride, const cf* tw4096,
                               int n_channels, hipStream_t st) {
   const size_t lds = (size_t)n1 * q * sizeof(cf);
-  static bool attr_set = false;
+  static bool attr_done[64] = {};            // per device: one process may drive several
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  bool& attr_set = attr_done[dev_ & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_level_small,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

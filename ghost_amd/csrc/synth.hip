@@ -222,7 +222,10 @@ template <int NCOL>
 static hipError_t launch_synth7_n(int mode, const Synth7Args& a, int n_items, int n_channels,
                                   hipStream_t st) {
   constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 4 * 256 * 8 + 256 * 4;
-  static bool attr_set = false;
+  static bool attr_done[64] = {};            // per device: one process may drive several
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  bool& attr_set = attr_done[dev_ & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_AMPLITUDE_F32, NCOL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -70,6 +70,8 @@ class Comm:
         self._handle = None
         self.backend = "single" if world == 1 else "file"
         self.rccl_error = None
+        if os.environ.get("GHOSTCWT_COMM", "") == "file":   # rehearsals on a single GPU
+            use_rccl = False
         if world > 1 and use_rccl:
             self._try_rccl()
         if world > 1:
