@@ -1,2 +1,3 @@
-"""Input adapters (reference: ghost/formats)."""
-from .preprocessing import *   # noqa: F401,F403
+"""Input / output adapters (reference: ghost/formats)."""
+from .preprocessing import *    # noqa: F401,F403
+from .postprocessing import *   # noqa: F401,F403

@@ -273,3 +273,15 @@ def test_time_blocks_tile_the_epochs():
     # low frequencies relative to fs: decimation beyond 256
     p = CwtPlan(1 << 21, 1, 30000.0, [500.0, 6.0, 1.0])
     assert p.scale_info()["decimation"].tolist() == [32, 2048, 16384]
+
+
+def test_output_adapter():
+    from ghost_amd.formats import output_numpy_or_asa
+    d = np.zeros((10, 3))
+    assert output_numpy_or_asa(None, d) is d
+    with pytest.raises(TypeError):
+        output_numpy_or_asa(None, [1, 2, 3])
+    with pytest.raises(TypeError):
+        output_numpy_or_asa(None, d, output_type="pandas")
+    with pytest.raises(ModuleNotFoundError):       # nelpy is not installed here
+        output_numpy_or_asa(FakeASA(np.zeros((1, 10)), 10.0, [10]), d, output_type="asa")
