@@ -112,6 +112,9 @@ hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi
 hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_t p1_stride,
                               int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,
                               int n_channels, hipStream_t st);
+hipError_t launch_cmul_inplace(float2* a, const float2* b, int64_t n, hipStream_t st);
+hipError_t launch_crop_scale(const float2* in, float2* out, int64_t first, int64_t count, float scale,
+                             hipStream_t st);
 hipError_t launch_zero_range(float* out, int64_t row_len_floats, int64_t n_rows, int64_t start,
                              int64_t len, hipStream_t st);
 

@@ -172,6 +172,16 @@ int gcwt_direct_kernel(gcwt_plan* plan, int scale, float* psi);
 
 int gcwt_get_timings(const gcwt_plan* plan, gcwt_timings* t);
 
+/* FFT convolution of one real signal with one kernel, the operator layer under the
+ * transform: ghost/sigtools/convolution.py:16-87 (fastconv_scipy) / :89-216
+ * (fastconv_fftw).  signal: float32 [n] (host).  kernel: float32 [m] real, or (re,im)
+ * pairs [m] when kernel_is_complex.  mode: 0 'full' (n+m-1 samples), 1 'same' (n, centred
+ * as convolution.py:85), 2 'valid' (n-m+1).  out: float32 (re,im) pairs (host).  One FFT
+ * of length 2^k >= n+m-1 <= 2^22 instead of the reference's chunked overlap-add: same
+ * numbers. */
+int gcwt_fastconv(const float* signal, int64_t n, const float* kernel, int64_t m,
+                  int kernel_is_complex, int mode, float* out, int device);
+
 /* Multi-GPU control plane (one process per GPU; RCCL over xGMI).  The data path
  * has no collective: channels are sharded.  The filter bank is broadcast once
  * from rank 0 as BASELINE.json asks; barrier/all-reduce exist for bench timing. */
