@@ -68,12 +68,22 @@ class Comm:
         self.dir = session or _session_dir()
         self._seq = 0
         self._handle = None
+        self._rccl_abandoned = False
         self.backend = "single" if world == 1 else "file"
         self.rccl_error = None
         if os.environ.get("GHOSTCWT_COMM", "") == "file":   # rehearsals on a single GPU
             use_rccl = False
         if world > 1 and use_rccl:
-            self._try_rccl()
+            # communicator set-up in a helper thread: if RCCL's bootstrap hangs (it has no
+            # timeout of its own) the run carries on with the file backend instead
+            import threading
+            th = threading.Thread(target=self._try_rccl, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("GHOSTCWT_RCCL_TIMEOUT", "90")))
+            if th.is_alive():
+                self.rccl_error = "RCCL communicator set-up timed out"
+                self._handle = None
+                self._rccl_abandoned = True
         if world > 1:
             # all ranks must agree on the backend
             ok = self._file_allreduce_max(1.0 if self._handle else 0.0, "agree_min", negate=True)
@@ -96,7 +106,8 @@ class Comm:
             h = C.c_void_p()
             check(lib.gcwt_comm_create(C.byref(h), self.rank, self.world,
                                        C.create_string_buffer(ident, COMM_ID_BYTES)))
-            self._handle = h
+            if not self._rccl_abandoned:
+                self._handle = h
         except Exception as e:            # RCCL missing / init failed: fall back to files
             self.rccl_error = "%s: %s" % (type(e).__name__, e)
             self._handle = None
