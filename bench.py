@@ -83,7 +83,7 @@ def main():
     c0, c1 = shard_channels(total_channels, rank, world)
     assert c1 - c0 == C
 
-    comm = Comm(rank, world)
+    comm = Comm(rank, world, device=dev)
     plan = CwtPlan(N, C, fs, freqs, output=args.output, device=dev)
     bank_via = comm.broadcast_bank(plan, root=0)
     plan.set_profiling(True)

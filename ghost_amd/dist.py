@@ -61,10 +61,12 @@ def _wait_for(path, timeout):
 class Comm:
     """barrier(), allreduce_max(x), broadcast_bank(plan) over ``world`` ranks."""
 
-    def __init__(self, rank=None, world=None, *, use_rccl=True, timeout=120.0, session=None):
+    def __init__(self, rank=None, world=None, *, use_rccl=True, timeout=120.0, session=None,
+                 device=None):
         if rank is None:
             rank, world, _ = env_rank()
         self.rank, self.world, self.timeout = rank, world, timeout
+        self.device = device          # HIP ordinal of this rank (the current device is per thread)
         self.dir = session or _session_dir()
         self._seq = 0
         self._handle = None
@@ -95,6 +97,8 @@ class Comm:
     def _try_rccl(self):
         try:
             from ._lib import lib, check, COMM_ID_BYTES
+            if self.device is not None:
+                check(lib.gcwt_set_device(int(self.device)))
             path = os.path.join(self.dir, "rccl_id")
             if self.rank == 0:
                 buf = C.create_string_buffer(COMM_ID_BYTES)
