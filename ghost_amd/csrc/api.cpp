@@ -63,6 +63,8 @@ struct gcwt_plan {
   float2* d_xr = nullptr;     // [C][max_xr]  decimated analytic signals, all levels
   float2* d_xb = nullptr;     // [C][max_xb]  block spectra, all levels
   float2* d_bank = nullptr;   // [S][B]
+  float* d_gain = nullptr;    // [S][B] |H|
+  float2* d_half_tw = nullptr; // [levels][256] exp(-i pi k/(256 R))
   float2* d_psi = nullptr;    // direct kernels
   float2* d_tw4096 = nullptr; // exp(-2 pi i j/4096), j < 2048
   float2* d_tw256 = nullptr;  // exp(+2 pi i q/256)
@@ -108,7 +110,7 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
-  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_bank); fr(p->d_psi); fr(p->d_tw4096);
+  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_bank); fr(p->d_gain); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
@@ -293,6 +295,7 @@ int gcwt_plan_upload(gcwt_plan* p) {
     if ((rc = dev_alloc(&p->d_xb, (size_t)(C * hp.max_xb)))) return bail(rc);
   }
   if ((rc = dev_alloc(&p->d_bank, (size_t)S * B))) return bail(rc);
+  if ((rc = dev_alloc(&p->d_gain, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_psi, (size_t)hp.direct_total))) return bail(rc);
   if ((rc = dev_alloc(&p->d_sums, (size_t)C))) return bail(rc);
 
@@ -330,10 +333,22 @@ int gcwt_plan_upload(gcwt_plan* p) {
 
   std::vector<int32_t> scale_list;
   std::vector<int> scale_off(hp.levels.size());
+  std::vector<int> n_plain(hp.levels.size());
+  std::vector<float2> half_tw(hp.levels.size() * 256);
   for (size_t l = 0; l < hp.levels.size(); ++l) {
     scale_off[l] = (int)scale_list.size();
-    for (int sidx : hp.levels[l].scales) scale_list.push_back(sidx);
+    // odd kernel lengths (no half-sample delay, real filter) first, even ones after
+    for (int sidx : hp.levels[l].scales)
+      if (hp.scales[sidx].half_delay == 0.0) scale_list.push_back(sidx);
+    n_plain[l] = (int)scale_list.size() - scale_off[l];
+    for (int sidx : hp.levels[l].scales)
+      if (hp.scales[sidx].half_delay != 0.0) scale_list.push_back(sidx);
+    for (int k = 0; k < 256; ++k) {
+      const double a = -M_PI * k / (256.0 * hp.levels[l].decimation);
+      half_tw[l * 256 + k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
   }
+  if ((rc = upload_vec(&p->d_half_tw, half_tw, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_scale_list, scale_list, p->stream))) return bail(rc);
   p->ep_dev.resize(hp.epochs.size());
   for (size_t e = 0; e < hp.epochs.size(); ++e) {
@@ -354,7 +369,8 @@ int gcwt_plan_upload(gcwt_plan* p) {
       int lg = 0;
       while ((1 << lg) < lp.decimation) ++lg;
       lv7[l] = {lp.decimation, lg, lp.hop, lp.halo, ep.lv[l].nblk, (int32_t)lp.scales.size(),
-                scale_off[l], ep.lv[l].blk_lo, ep.lv[l].xb_offset, lp.twiddle_offset};
+                scale_off[l], ep.lv[l].blk_lo, n_plain[l], (int32_t)(l * 256), ep.lv[l].xb_offset,
+                lp.twiddle_offset};
       const int bpb = std::max(1, p->synth_cols / lp.decimation);
       const int n_rtiles = std::max(1, lp.decimation / p->synth_cols);
       for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
@@ -368,6 +384,8 @@ int gcwt_plan_upload(gcwt_plan* p) {
   hipError_t he = launch_build_bank(p->d_bank, p->d_bank_sc, S, B, hp.prm.gamma, hp.prm.beta, hp.w0,
                                     p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_bank"));
+  he = launch_bank_gain(p->d_bank, p->d_gain, S, p->stream);
+  if (he != hipSuccess) return bail(hip_err(he, "bank_gain"));
   he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, hp.prm.gamma,
                            hp.prm.beta, hp.w0, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_direct"));
@@ -484,6 +502,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       a7.items = p->ep_dev[e].items7;
       a7.levels = p->ep_dev[e].levels7;
       a7.scale_list = p->d_scale_list;
+      a7.gain = p->d_gain;
+      a7.level_half_tw = p->d_half_tw;
       a7.out = dout;
       a7.xb_cstride = hp.max_xb;
       a7.row_len = row_len;
@@ -775,6 +795,11 @@ int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, 
 }  // extern "C"
 
 // accessors for comm.cpp
+int gcwt_internal_refresh_bank(gcwt_plan* p) {   // derived tables follow a (broadcast) bank
+  hipError_t he = launch_bank_gain(p->d_bank, p->d_gain, p->hp.prm.n_freqs, p->stream);
+  if (he != hipSuccess) return hip_err(he, "bank_gain");
+  return GCWT_OK;
+}
 int gcwt_internal_set_error(int code, const char* msg) { return set_err(code, msg); }
 float2* gcwt_internal_bank_ptr(gcwt_plan* p, size_t* bytes) {
   *bytes = sizeof(float2) * (size_t)p->hp.prm.n_freqs * p->hp.block;

@@ -20,6 +20,7 @@ enum { kNcclMax = 2 };
 
 float2* gcwt_internal_bank_ptr(gcwt_plan* p, size_t* bytes);
 hipStream_t gcwt_internal_stream(gcwt_plan* p);
+int gcwt_internal_refresh_bank(gcwt_plan* p);
 
 namespace {
 
@@ -154,6 +155,7 @@ int gcwt_comm_broadcast_bank(gcwt_comm* c, gcwt_plan* plan, int root) {
   hipStream_t st = gcwt_internal_stream(plan);
   ncclResult_t nr = rccl().Broadcast(bank, bank, bytes, kNcclUint8, root, c->comm, st);
   if (nr != 0) return nccl_fail("ncclBroadcast", nr);
+  if ((rc = gcwt_internal_refresh_bank(plan))) return rc;   // |H| table follows the bank
   if (hipStreamSynchronize(st) != hipSuccess) return cerr_(GCWT_ERR_HIP, "broadcast did not complete");
   return GCWT_OK;
 }

@@ -59,6 +59,8 @@ struct Synth7Item {
 
 struct Synth7Level {
   int32_t decimation, log2r, hop, halo, nblk, n_scales, scale_offset, blk_base;
+  int32_t n_plain;     // the first n_plain scales of the level's list have odd L (real filter);
+  int32_t half_offset; // the rest carry the half-sample phase level_half_tw[half_offset + k]
   int64_t xb_offset;   // per-channel offset of this level's block spectra (complex elems)
   int64_t tw_offset;   // into level_tw
 };
@@ -70,7 +72,9 @@ struct Synth7Args {
   const float2* level_tw;
   const Synth7Item* items;
   const Synth7Level* levels;
-  const int32_t* scale_list;   // scale indices grouped by level
+  const int32_t* scale_list;   // scale indices grouped by level, odd kernel lengths first
+  const float* gain;           // |H_s[k]|, [S][256]
+  const float2* level_half_tw; // exp(-i pi k/(256 R)), 256 per level
   float* out;
   int64_t xb_cstride;
   int64_t row_len;       // samples per (channel, scale) row of out
@@ -87,6 +91,7 @@ hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double*
                               hipStream_t st);
 hipError_t launch_build_bank(float2* bank, const BankScale* sc, int n_scales, int B, double gamma,
                              double beta, double w0, hipStream_t st);
+hipError_t launch_bank_gain(const float2* bank, float* gain, int n_scales, hipStream_t st);
 hipError_t launch_build_direct(float2* psi, const DirectScale* sc, int n_direct, int64_t max_len,
                                double gamma, double beta, double w0, hipStream_t st);
 hipError_t launch_fft_cols(int sign, bool real_in, const void* in, float2* out, int len, int ld,

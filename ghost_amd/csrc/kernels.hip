@@ -152,6 +152,15 @@ __global__ void k_build_bank(cf* __restrict__ bank, const BankScale* __restrict_
   bank[(int64_t)s * B + k] = h;
 }
 
+// gain[s][k] = |H_s[k]|: the production synthesis kernel multiplies by the real gain and
+// folds the half-sample phase of even-length kernels into its persistent operand.
+// grid (S), block (256)
+__global__ void k_bank_gain(const cf* __restrict__ bank, float* __restrict__ gain) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const cf h = bank[i];
+  gain[i] = sqrtf(h.x * h.x + h.y * h.y);
+}
+
 // ---------------------------------------------------------------------------
 // literal kernels for direct scales: psi[n] = (1/L) sum_{k<K} A(k) e^{i pi k (L+1)/L}
 //   e^{2 pi i k n / L},  K = round-half-even(L/2)            (morseutils.py:117-149)
@@ -771,6 +780,12 @@ hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double*
 hipError_t launch_build_bank(cf* bank, const BankScale* sc, int n_scales, int B, double gamma,
                              double beta, double w0, hipStream_t st) {
   hipLaunchKernelGGL(k_build_bank, dim3(n_scales), dim3(B), 0, st, bank, sc, B, gamma, beta, w0);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_bank_gain(const cf* bank, float* gain, int n_scales, hipStream_t st) {
+  hipLaunchKernelGGL(k_bank_gain, dim3(n_scales), dim3(256), 0, st, bank, gain);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

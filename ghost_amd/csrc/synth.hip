@@ -98,8 +98,8 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2f* const ex = reinterpret_cast<v2f*>(smem);
   v2f* const twl = ex + 16 * kPlane;
-  v2f* const stage = twl + 256;
-  int* const sc_lds = reinterpret_cast<int*>(stage + 4 * 256);   // this level's scale indices
+  float* const stage = reinterpret_cast<float*>(twl + 256);       // gains of kChunk scales
+  int* const sc_lds = reinterpret_cast<int*>(stage + 8 * 256);   // this level's scale indices
 
   const Synth7Item it = a.items[blockIdx.x];
   const Synth7Level lv = a.levels[it.level];
@@ -120,15 +120,16 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     const float2 w = a.tw256[((tid & 15) * (tid >> 4)) & 255];
     twl[tid] = (v2f){w.x, w.y};
   }
-  // Filters of kChunk scales at a time are parked in LDS (8 KB).  A refill is one
-  // global load per thread per kChunk batches, so its vmcnt(0) drain of the
-  // outstanding stores is paid once per kChunk batches, not per batch.
-  constexpr int kChunk = 4;
+  // The filter enters as its real gain |H_s[k]|; the half-sample phase that even kernel
+  // lengths carry is folded into P when the walk reaches those scales (they come last in
+  // the level's list).  Gains of kChunk scales at a time are parked in LDS (8 KB): a
+  // refill is one global load per thread per kChunk batches, so its vmcnt(0) drain of
+  // the outstanding stores is paid once per kChunk batches, not per batch.
+  constexpr int kChunk = 8;
   auto fill_stage = [&](int b0) {
     for (int i = tid; i < kChunk * 256; i += kThreads) {
       const int sb = min(b0 + (i >> 8), lv.n_scales - 1);
-      const float2 h = a.bank[(int64_t)scales[sb] * 256 + (i & 255)];
-      stage[i] = (v2f){h.x, h.y};
+      stage[i] = a.gain[(int64_t)scales[sb] * 256 + (i & 255)];
     }
   };
   fill_stage(0);
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   float* const out0 = a.out + ((int64_t)c * a.n_scales * a.row_len + a.seg_col + a.w_lo) * kElem;
   const unsigned voff0 = (unsigned)(((int)(n_b - a.w_lo) + off0) * (4 * kElem));
   const unsigned vstep = (unsigned)(m1step * (4 * kElem));
-  const v2f* const st_rd = stage + t;
+  const float* const st_rd = stage + t;
   __syncthreads();
 
   for (int b = 0; b < lv.n_scales; ++b) {
@@ -180,10 +181,18 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
       fill_stage(b);
       __syncthreads();
     }
-    const v2f* const hs = st_rd + (b & (kChunk - 1)) * 256;
+    if (b == lv.n_plain) {                     // wave-uniform; at most once per workgroup
+      const float2* hp = a.level_half_tw + lv.half_offset + t;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float2 q = hp[16 * j];
+        pw[j] = cmulv(pw[j], (v2f){q.x, q.y});
+      }
+    }
+    const float* const hs = st_rd + (b & (kChunk - 1)) * 256;
     v2f v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = cmulv(hs[16 * j], pw[j]);
+    for (int j = 0; j < 16; ++j) v[j] = pw[j] * hs[16 * j];
     idft16v(v);
 #pragma unroll
     for (int j = 0; j < 16; ++j) exw[j * sstride] = cmulv(v[dft16_pos(j)], twl[16 * j + t]);
@@ -221,7 +230,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
 template <int NCOL>
 static hipError_t launch_synth7_n(int mode, const Synth7Args& a, int n_items, int n_channels,
                                   hipStream_t st) {
-  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 4 * 256 * 8 + 256 * 4;
+  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 8 * 256 * 4 + 256 * 4;
   static bool attr_done[64] = {};            // per device: one process may drive several
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
