@@ -120,6 +120,13 @@ hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_
 hipError_t launch_cmul_inplace(float2* a, const float2* b, int64_t n, hipStream_t st);
 hipError_t launch_crop_scale(const float2* in, float2* out, int64_t first, int64_t count, float scale,
                              hipStream_t st);
+// Bluestein pieces (arbitrary-length DFT, analytic signal)
+hipError_t launch_chirp_kernel(float2* b, int64_t N, int64_t P, hipStream_t st);
+hipError_t launch_chirp_load(const float* v, int is_complex, int conj_in, int64_t n_valid, int64_t N,
+                             int64_t P, const double* sums, double inv_n, float2* a, hipStream_t st);
+hipError_t launch_chirp_analytic_mask(float2* y, int64_t N, int64_t P, float scale, hipStream_t st);
+hipError_t launch_chirp_store(const float2* y, float2* out, int64_t count, int64_t N, float scale,
+                              int conj_out, const double* sums, double inv_n, hipStream_t st);
 hipError_t launch_zero_range(float* out, int64_t row_len_floats, int64_t n_rows, int64_t start,
                              int64_t len, hipStream_t st);
 

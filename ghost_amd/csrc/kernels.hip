@@ -732,6 +732,79 @@ __global__ void __launch_bounds__(256) k_level_small(const cf* __restrict__ x, c
   }
 }
 
+// ---------------------------------------------------------------------------
+// Bluestein (chirp-z) DFT of arbitrary length N on top of the power-of-two FFTs:
+//   DFT_N(v)[k] = W[k] * sum_n (v[n] W[n]) conj(W)[k-n],   W[n] = exp(-i pi n^2 / N)
+// (the identity ghost/sigtools/fourier.py:9-52 uses).  n^2 is reduced mod 2N in
+// integers so the chirp phase is exact before the fp64 sincos.
+__device__ __forceinline__ cf chirp_w(int64_t n, int64_t N, double sign) {
+  const int64_t t = (n * n) % (2 * N);
+  double s, c;
+  sincospi(sign * (double)t / (double)N, &s, &c);
+  return make_float2((float)c, (float)s);
+}
+
+// Circular chirp kernel b[j] = conj(W)[d], d = j (j < N) or P - j (P - j < N), else 0.
+__global__ void k_chirp_kernel(cf* __restrict__ b, int64_t N, int64_t P) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= P) return;
+  const int64_t d = j < N ? j : (P - j < N ? P - j : -1);
+  b[j] = d < 0 ? make_float2(0.f, 0.f) : chirp_w(d, N, +1.0);
+}
+
+// a[n] = (v[n] - m) W[n], n < N (v = 0 beyond n_valid), 0 for N <= n < P.  v is real or
+// complex (optionally conjugated: the inverse DFT is conj(DFT(conj v))/N); m = sums[0]*inv_n.
+__global__ void k_chirp_load(const float* __restrict__ v, int is_complex, int conj_in,
+                             int64_t n_valid, int64_t N, int64_t P,
+                             const double* __restrict__ sums, double inv_n, cf* __restrict__ a) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= P) return;
+  cf z = make_float2(0.f, 0.f);
+  if (n < N) {
+    const float m = (float)(sums[0] * inv_n);
+    if (n < n_valid) {
+      if (is_complex) {
+        z = reinterpret_cast<const cf*>(v)[n];
+        if (conj_in) z.y = -z.y;
+      } else {
+        z.x = v[n];
+      }
+    }
+    z.x -= m;
+    z = cmul(z, chirp_w(n, N, -1.0));
+  }
+  a[n] = z;
+}
+
+// Second leg of the analytic signal: with y = conv(a, b) the spectrum is W[k] y[k]/P and the
+// inverse DFT's chirped input conj(mask X) W collapses to mask[k] conj(y[k]) / P (|W| = 1).
+// mask = 1 at DC (and at N/2 for even N), 2 on the other non-negative bins, 0 elsewhere
+// (ghost/sigtools/analytic.py:100-108).  In place.
+__global__ void k_chirp_analytic_mask(cf* __restrict__ y, int64_t N, int64_t P, float scale) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= P) return;
+  float g = 0.f;
+  if (k < N) {
+    if (k == 0 || ((N & 1) == 0 && k == N / 2)) g = scale;
+    else if (k < (N + 1) / 2) g = 2.f * scale;
+  }
+  const cf v = y[k];
+  y[k] = make_float2(g * v.x, -g * v.y);
+}
+
+// out[n] = scale * W[n] y[n] (conjugated when conj_out) + add_re, n < count.
+__global__ void k_chirp_store(const cf* __restrict__ y, cf* __restrict__ out, int64_t count,
+                              int64_t N, float scale, int conj_out,
+                              const double* __restrict__ sums, double inv_n) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= count) return;
+  cf z = cmul(y[n], chirp_w(n, N, -1.0));
+  z.x *= scale;
+  z.y *= conj_out ? -scale : scale;
+  z.x += (float)(sums[0] * inv_n);
+  out[n] = z;
+}
+
 // a[i] *= b[i] (complex), n elements.  grid (ceil(n/256))
 __global__ void k_cmul_inplace(cf* __restrict__ a, const cf* __restrict__ b, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -940,6 +1013,35 @@ hipError_t launch_crop_scale(const cf* in, cf* out, int64_t first, int64_t count
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_crop_scale, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, in, out,
                      first, count, scale);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_chirp_kernel(cf* b, int64_t N, int64_t P, hipStream_t st) {
+  hipLaunchKernelGGL(k_chirp_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, b, N, P);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_chirp_load(const float* v, int is_complex, int conj_in, int64_t n_valid, int64_t N,
+                             int64_t P, const double* sums, double inv_n, cf* a, hipStream_t st) {
+  hipLaunchKernelGGL(k_chirp_load, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, v, is_complex,
+                     conj_in, n_valid, N, P, sums, inv_n, a);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_chirp_analytic_mask(cf* y, int64_t N, int64_t P, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(k_chirp_analytic_mask, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, y, N,
+                     P, scale);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_chirp_store(const cf* y, cf* out, int64_t count, int64_t N, float scale,
+                              int conj_out, const double* sums, double inv_n, hipStream_t st) {
+  hipLaunchKernelGGL(k_chirp_store, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, y, out,
+                     count, N, scale, conj_out, sums, inv_n);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

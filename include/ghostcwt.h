@@ -182,6 +182,20 @@ int gcwt_get_timings(const gcwt_plan* plan, gcwt_timings* t);
 int gcwt_fastconv(const float* signal, int64_t n, const float* kernel, int64_t m,
                   int kernel_is_complex, int mode, float* out, int device);
 
+/* DFT of arbitrary length n (not only powers of two) by the chirp-z identity, the operator
+ * of ghost/sigtools/fourier.py:9-52 (chirpz_dft).  x: float32 [n] real, or (re,im) pairs
+ * when is_complex; inverse != 0 gives the normalised inverse DFT.  out: (re,im) pairs [n]
+ * (host).  n <= 2^21. */
+int gcwt_dft(const float* x, int64_t n, int is_complex, int inverse, float* out, int device);
+
+/* Analytic signal x + i*Hilbert(x) of a real signal through an fft_length-point DFT
+ * (0 = n, the reference's default: no padding), as ghost/sigtools/analytic.py:22-112
+ * (analytic_signal_fftw; the same numbers as scipy.signal.hilbert(x, N=fft_length)[:n]).
+ * signal: float32 [n] (host); out: (re,im) pairs [n] (host).  fft_length <= 2^21, any
+ * length (the DFTs run as chirp-z transforms on power-of-two FFTs). */
+int gcwt_analytic_signal(const float* signal, int64_t n, int64_t fft_length, float* out,
+                         int device);
+
 /* Multi-GPU control plane (one process per GPU; RCCL over xGMI).  The data path
  * has no collective: channels are sharded.  The filter bank is broadcast once
  * from rank 0 as BASELINE.json asks; barrier/all-reduce exist for bench timing. */

@@ -45,3 +45,51 @@ def test_fastconv_freq_domain():
     Y = fft(y, n=3000)
     for mode in ("full", "same", "valid"):
         assert _close(fastconv_freq_hip(x, Y, len(y), mode=mode), convolve(x, y, mode=mode)), mode
+
+
+def test_chirpz_dft():
+    """tests/test_fourier.py:4-18 of the reference: even and odd (prime) lengths vs np.fft."""
+    from ghost_amd.sigtools import chirpz_dft_hip, chirpz_idft_hip
+    rng = np.random.default_rng(3)
+    for n in (1009, 1010, 1, 2, 4096, 100003):
+        x = rng.random(n)
+        ref = np.fft.fft(x)
+        got = chirpz_dft_hip(x)
+        assert got.dtype == np.complex64 and got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 3e-6 * np.abs(ref).max(), n
+    z = rng.standard_normal(5003) + 1j * rng.standard_normal(5003)
+    ref = np.fft.fft(z)
+    assert np.abs(chirpz_dft_hip(z) - ref).max() <= 3e-6 * np.abs(ref).max()
+    back = chirpz_idft_hip(ref)
+    assert np.abs(back - z).max() <= 3e-6 * np.abs(z).max()
+    with pytest.raises(ValueError):
+        chirpz_dft_hip(np.zeros((2, 8)))
+
+
+def test_analytic_signal():
+    """tests/test_hilbert.py:4-11 of the reference (30 kHz x 60 s of uniform noise) against
+    scipy.signal.hilbert, plus padded, odd and tiny lengths and a large DC offset."""
+    from scipy.signal import hilbert
+    from ghost_amd.sigtools import analytic_signal_hip
+    rng = np.random.default_rng(4)
+    x = rng.random(30000 * 60)
+    ref = hilbert(x)
+    got = analytic_signal_hip(x)
+    assert got.dtype == np.complex64 and got.shape == ref.shape
+    # the real part is the input itself; the Hilbert part carries the arithmetic
+    assert np.abs(got.real - x).max() <= 2e-6
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    for n, f in ((1000, None), (1001, None), (1000, 1500), (1001, 2003), (1, None), (2, None),
+                 (3, None), (50000, 65536)):
+        x = rng.standard_normal(n) + 1000.0
+        ref = hilbert(x, N=f)[:n]
+        got = analytic_signal_hip(x, fft_length=f)
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref - 1000.0).max() + 1e-3, (n, f)
+    with pytest.raises(ValueError):
+        analytic_signal_hip(x.astype(complex))
+    with pytest.raises(ValueError):
+        analytic_signal_hip(np.zeros(0))
+    with pytest.raises(ValueError):
+        analytic_signal_hip(np.zeros((4, 4)))
+    with pytest.raises(ValueError):
+        analytic_signal_hip(np.zeros(8), fft_length=4)
