@@ -27,31 +27,18 @@ class Morse(Wavelet):
         self.beta = 20 if beta is None else beta
 
     def __call__(self, length, *, normalization=None):
-        """(psi, psif) of ``length`` samples, 'bandpass' normalisation: peak of
-        the spectrum is 2 (morse.py:53-91 -> morseutils.py:93-198)."""
-        if length is None:
-            length = 16384
-        if length < 1:
-            raise ValueError("length must at least 1 but got {}".format(length))
-        if normalization is None:
-            normalization = "bandpass"
-        if normalization not in ("bandpass", "energy"):
+        """(psi, psif) of ``length`` samples (morse.py:53-91 -> morseutils.py:22-198):
+        'bandpass' (default; the spectrum peaks at 2) or 'energy' normalisation."""
+        n = 16384 if length is None else length
+        if n < 1:
+            raise ValueError("length must at least 1 but got {}".format(n))
+        norm = normalization or "bandpass"
+        if norm not in ("bandpass", "energy"):
             raise ValueError("normalization must be 'bandpass' or 'energy' but got {}"
-                             .format(normalization))
-        if normalization == "energy":
-            raise NotImplementedError("'energy' normalisation is outside the transform() "
-                                      "path and is not built")
-        n = int(length)
-        g, b = self._gamma, self._beta
-        w0 = morseutils.morsefreq(g, b)
-        k = np.arange(n)
-        w = (2 * np.pi * k / n) * (w0 / self._norm_radian_freq)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            psif = 2 * np.exp(-b * np.log(w0) + w0 ** g + b * np.log(w) - w ** g)
-        psif[0] = 0.0
-        psif[round(n / 2):] = 0.0           # one-sided: bins 0..round(L/2)-1 (banker's round)
-        psi = np.fft.ifft(psif * np.exp(1j * np.pi * k * (n + 1) / n))
-        return psi, psif
+                             .format(norm))
+        psi, psif = morseutils.morsewave(n, self._gamma, self._beta, self._norm_radian_freq,
+                                         normalization=norm)
+        return psi[:, 0, 0], psif[:, 0, 0]
 
     def compute_freq_bounds(self, N, *, p=None, **kwargs):
         """[lowest, highest] peak frequency (rad/sample) for N samples (morse.py:93-106)."""
