@@ -32,9 +32,19 @@ def shard_channels(n_channels, rank, world):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def _launcher_start():
+    """Start time (clock ticks since boot) of the parent process: with the pid it names one
+    launcher instance, so a reused pid cannot pick up an older run's files."""
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as fh:
+            return fh.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        return "0"
+
+
 def _session_dir():
-    key = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(),
-                        os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+    key = "%s_%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), _launcher_start(),
+                           os.environ.get("TORCHELASTIC_RUN_ID", "none"))
     d = os.path.join(os.environ.get("GHOSTCWT_RDZV_DIR", tempfile.gettempdir()),
                      "ghostcwt_" + key)
     os.makedirs(d, exist_ok=True)
@@ -67,7 +77,7 @@ class Comm:
             rank, world, _ = env_rank()
         self.rank, self.world, self.timeout = rank, world, timeout
         self.device = device          # HIP ordinal of this rank (the current device is per thread)
-        self.dir = session or _session_dir()
+        self.dir = session or (_session_dir() if world > 1 else None)
         self._seq = 0
         self._handle = None
         self._rccl_abandoned = False
@@ -162,5 +172,16 @@ class Comm:
     def close(self):
         if self._handle:
             self._drop_rccl()
-        if self.world > 1:
+        if self.world > 1 and self.backend != "closed":
             self.backend = "closed"
+            # leave no rendezvous files behind: every rank signs off, rank 0 removes the
+            # directory once all have (nobody reads from it after signing off)
+            try:
+                _publish(os.path.join(self.dir, "done.%d" % self.rank), b"1")
+                if self.rank == 0:
+                    import shutil
+                    for r in range(self.world):
+                        _wait_for(os.path.join(self.dir, "done.%d" % r), 10.0)
+                    shutil.rmtree(self.dir, ignore_errors=True)
+            except (OSError, TimeoutError):
+                pass
