@@ -51,6 +51,7 @@ def _worker(rank, world, session, port, q):
         # each rank's shard of a synthetic job: weak scaling keeps per-rank work fixed
         a, b = shard_channels(16 * world, rank, world)
         comm.barrier()
+        comm.close()                                  # signs off; rank 0 removes the session dir
         q.put((rank, got, float(t[0]), b - a))
     except Exception as e:  # pragma: no cover
         q.put((rank, "error", repr(e), 0))
@@ -72,6 +73,7 @@ def test_world_size_two_control_plane():
     assert [r[1] for r in res] == [13.0, 13.0]          # file backend
     assert [r[2] for r in res] == [13.0, 13.0]          # gloo agrees
     assert [r[3] for r in res] == [16, 16]
+    assert not os.path.exists(session)                  # close() left nothing behind
 
 
 def test_single_rank_comm_is_a_noop():
