@@ -84,7 +84,11 @@ def main():
     assert c1 - c0 == C
 
     comm = Comm(rank, world, device=dev)
+    t_plan = time.perf_counter()
     plan = CwtPlan(N, C, fs, freqs, output=args.output, device=dev)
+    plan.upload()                                    # workspace, filter bank, FFT tables
+    check(lib.gcwt_device_synchronize())
+    plan_ms = (time.perf_counter() - t_plan) * 1e3   # reported apart from the timed steps
     bank_via = comm.broadcast_bank(plan, root=0)
     plan.set_profiling(True)
 
@@ -133,7 +137,8 @@ def main():
             "config": {"workload": "%d ch/GPU x %d samples @ 1 kHz x %d Morse scales 200..2 Hz, "
                                    "%s f32 out, device-resident" % (C, N, S, args.output),
                        "channels_total": total_channels, "parallelism": "channel-sharded x%d" % world,
-                       "bank": bank_via, "comm": comm.backend, "device": device_name(dev)},
+                       "bank": bank_via, "comm": comm.backend, "device": device_name(dev),
+                       "plan_create_ms": round(plan_ms, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_synth7", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel_ms": round(k_ms, 4),

@@ -442,7 +442,7 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
 }
 
 template <int SIGN>
-__global__ void __launch_bounds__(256) k_fft_rows_fast(const cf* __restrict__ in, cf* __restrict__ out,
+__global__ void __launch_bounds__(256, 4) k_fft_rows_fast(const cf* __restrict__ in, cf* __restrict__ out,
                                                        int lq, int64_t in_ld, int64_t out_ld,
                                                        int64_t in_cstride, int64_t out_cstride,
                                                        int64_t tw_n, const cf* __restrict__ tw4096,

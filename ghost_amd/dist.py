@@ -14,7 +14,7 @@ import os
 import tempfile
 import time
 
-__all__ = ["Comm", "shard_channels", "env_rank"]
+__all__ = ["Comm", "shard_channels", "shard_time_blocks", "env_rank"]
 
 
 def env_rank():
@@ -30,6 +30,27 @@ def shard_channels(n_channels, rank, world):
     base, extra = divmod(n_channels, world)
     start = rank * base + min(rank, extra)
     return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_time_blocks(segments, rank, world):
+    """Few channels, long recording: rank's share of the plan's time blocks.
+
+    ``segments`` is ``CwtPlan.segments()`` -- [(core_start, core_stop, fft_length)].  Blocks
+    are dealt in contiguous runs of near-equal total length; every rank reads the whole
+    recording from the host (each block carries its own halo, so no rank needs another's
+    samples) and streams its runs with ``CwtPlan.execute_block``.  Returns the sample
+    range (start, stop) covered by the rank, or (s, s) when it has nothing to do."""
+    if not segments:
+        return 0, 0
+    first, last = segments[0][0], segments[-1][1]
+    total = last - first
+    lo_t = first + total * rank // world
+    hi_t = first + total * (rank + 1) // world
+    # cut at block boundaries: a block belongs to the rank its first sample falls to
+    mine = [(a, b) for a, b, _ in segments if lo_t <= a < hi_t]
+    if not mine:
+        return lo_t, lo_t
+    return mine[0][0], mine[-1][1]
 
 
 def _launcher_start():

@@ -76,6 +76,27 @@ def test_world_size_two_control_plane():
     assert not os.path.exists(session)                  # close() left nothing behind
 
 
+def test_time_block_shards_tile_the_recording():
+    from ghost_amd.dist import shard_time_blocks
+    # 11 blocks of uneven length, as the planner cuts two epochs
+    edges = [0, 3968, 7936, 11904, 15000, 18968, 22936, 26904, 30872, 34840, 38808, 40000]
+    segs = [(a, b, 8192) for a, b in zip(edges[:-1], edges[1:])]
+    for world in (1, 2, 3, 4, 8, 16):
+        covered = []
+        for r in range(world):
+            a, b = shard_time_blocks(segs, r, world)
+            assert a <= b
+            if b > a:
+                assert a in edges and b in edges          # whole blocks only
+                covered.append((a, b))
+        assert covered[0][0] == 0 and covered[-1][1] == 40000
+        assert all(x[1] == y[0] for x, y in zip(covered[:-1], covered[1:]))
+        if world <= 4:
+            sizes = [b - a for a, b in covered]
+            assert max(sizes) - min(sizes) <= 2 * 3968
+    assert shard_time_blocks([], 0, 2) == (0, 0)
+
+
 def test_single_rank_comm_is_a_noop():
     c = Comm(0, 1)
     assert c.backend == "single"

@@ -241,6 +241,24 @@ def test_execute_block_streams_the_same_numbers():
     np.testing.assert_array_equal(p2.execute_block(x, 100, 5000), cfull[:, :, 100:5100])
 
 
+def test_time_block_shards_reassemble_the_transform():
+    """SURVEY.md 8e, few channels x long recording: ranks take runs of time blocks, read
+    the whole recording and stream their part; glued together = the full transform."""
+    from ghost_amd.dist import shard_time_blocks
+    from ghost_amd.synthetic import lfp
+    fs, n = 1000.0, 50000
+    x = lfp(1, n, fs) - 0.3
+    f = [250.0, 60.0, 9.0]
+    p, full = _plan(x, fs, f, output="amplitude", max_fft_log2=13)
+    world = 3
+    parts = []
+    for r in range(world):
+        a, b = shard_time_blocks(p.segments(), r, world)
+        assert b > a
+        parts.append(p.execute_block(x, a, b - a))
+    np.testing.assert_array_equal(np.concatenate(parts, axis=2), full)
+
+
 def test_low_frequencies_at_high_sampling_rate():
     """BASELINE config 5 regime (30 kHz, 1-500 Hz): decimation far beyond 256."""
     from ghost_amd.synthetic import lfp_channel
