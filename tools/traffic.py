@@ -1,0 +1,42 @@
+"""profiles/traffic.json and the round's rocprof summaries from the newest files that
+tools/prof_round.sh left under gpurun_out/<round>/.  Usage: python tools/traffic.py r01"""
+import collections, csv, glob, json, os, re, shutil, sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(root, "gpurun_out", rnd)
+
+
+def newest(pattern):
+    files = glob.glob(os.path.join(src, pattern))
+    return max(files, key=os.path.getmtime)
+
+
+def counter(kind):
+    f = newest("%s/*/*counter_collection.csv" % kind)
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "")
+        acc[name].append(float(row["Counter_Value"]))
+    return {k: {"calls": len(v), "avg_KB": sum(v) / len(v)} for k, v in acc.items()}
+
+
+fetch, write = counter("fetch"), counter("write")
+key = [k for k in fetch if "k_synth7" in k][0]
+f_kb, w_kb = fetch[key]["avg_KB"], write[key]["avg_KB"]
+out = {
+    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py 128ch x "
+            "1e6 x 100 scales amplitude; values are KB per launch. On gfx950 FETCH_SIZE counts 64 B "
+            "per 128 B request for coalesced streams, so fetched bytes = 2 * FETCH_SIZE * 1024 "
+            "(guides/MI355X_MICROARCH.md, HBM section); k_channel_sum confirms it here (250 000 KB "
+            "reported for 512 MB read). WRITE_SIZE is exact for k_synth7's 4 B/lane 256 B/wave "
+            "stores: it reports 5.0e7 KB = 51.2 GB = the amplitude output.",
+    "k_synth_hbm_bytes_per_launch": int(2 * f_kb * 1024 + w_kb * 1024),
+    "k_synth7_fetch_KB": f_kb, "k_synth7_write_KB": w_kb,
+    "counters": {"FETCH_SIZE": fetch, "WRITE_SIZE": write},
+}
+json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+shutil.copy(newest("stats/*/*kernel_stats.csv"), os.path.join(root, "profiles", rnd + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(root, "profiles", rnd + "_bench.json"))
+print("k_synth7: fetch %.1f MB (x2 corrected) + write %.1f MB = %d bytes per launch" %
+      (2 * f_kb / 1024, w_kb / 1024, out["k_synth_hbm_bytes_per_launch"]))
