@@ -8,14 +8,14 @@ import ctypes as C
 import os
 
 __all__ = ["lib", "GhostCwtError", "check", "Params", "PlanInfo", "Timings", "LIB_PATH",
-           "OUT_AMPLITUDE", "OUT_POWER", "OUT_COMPLEX", "X_ON_DEVICE", "OUT_ON_DEVICE",
+           "OUT_AMPLITUDE", "OUT_POWER", "OUT_COMPLEX", "X_ON_DEVICE", "OUT_ON_DEVICE", "OUT_F64",
            "SCALE_SPECTRAL", "SCALE_DIRECT", "ERR_INVALID", "ERR_UNSUPPORTED", "ERR_NO_DEVICE"]
 
 LIB_PATH = os.environ.get("GHOSTCWT_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "libghostcwt.so")
 
 OUT_AMPLITUDE, OUT_POWER, OUT_COMPLEX = 0, 1, 2
-X_ON_DEVICE, OUT_ON_DEVICE, REUSE_MEANS = 1, 2, 4
+X_ON_DEVICE, OUT_ON_DEVICE, REUSE_MEANS, OUT_F64 = 1, 2, 4, 8
 SCALE_SPECTRAL, SCALE_DIRECT = 0, 1
 ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_COMM = -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128

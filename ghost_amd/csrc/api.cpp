@@ -12,6 +12,7 @@
 
 #include "../../include/ghostcwt.h"
 #include "../../include/ghostcwt_debug.h"
+#include "host_out.h"
 #include "kernels.h"
 #include "planner.h"
 
@@ -80,6 +81,7 @@ struct gcwt_plan {
   size_t d_in_bytes = 0;
   void* d_out = nullptr;
   size_t d_out_bytes = 0;
+  HostOut host_out;          // pinned staging ring for host results
   // profiling
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -114,6 +116,7 @@ void free_dev(gcwt_plan* p) {
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
+  p->host_out.release();
   for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.levels7); }
   p->ep_dev.clear();
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
@@ -530,6 +533,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
 }
 
 static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int64_t r1, int flags) {
+  if ((flags & GCWT_OUT_F64) && (flags & GCWT_OUT_ON_DEVICE))
+    return set_err(GCWT_ERR_INVALID, "GCWT_OUT_F64 applies to host output only");
   int rc = gcwt_plan_upload(p);
   if (rc) return rc;
   if (p->device >= 0) HIP_TRY(hipSetDevice(p->device));
@@ -577,10 +582,23 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   rc = run_pipeline(p, dx, dout, r0, r1, row_len, reuse);
   if (rc) { (void)hipStreamSynchronize(p->stream); return rc; }
   p->have_means = true;
-  if (!(flags & GCWT_OUT_ON_DEVICE))
-    HIP_TRY(hipMemcpy2DAsync(out, hp.out_elem_bytes * (size_t)n_out, dout,
-                             hp.out_elem_bytes * (size_t)row_len, hp.out_elem_bytes * (size_t)n_out,
-                             rows, hipMemcpyDeviceToHost, p->stream));
+  if (!(flags & GCWT_OUT_ON_DEVICE)) {
+    // complex rows are float pairs: the same routine moves (and widens) them
+    const size_t k = hp.out_elem_bytes / sizeof(float);
+    hipError_t he = p->host_out.drain(dout, k * (size_t)row_len, rows, k * (size_t)n_out, out,
+                                      (flags & GCWT_OUT_F64) != 0, p->stream);
+    if (he == hipErrorInvalidValue && !(flags & GCWT_OUT_F64)) {   // rows beyond the staging size
+      (void)hipGetLastError();
+      HIP_TRY(hipMemcpy2DAsync(out, hp.out_elem_bytes * (size_t)n_out, dout,
+                               hp.out_elem_bytes * (size_t)row_len, hp.out_elem_bytes * (size_t)n_out,
+                               rows, hipMemcpyDeviceToHost, p->stream));
+    } else if (he == hipErrorInvalidValue) {
+      (void)hipStreamSynchronize(p->stream);
+      return set_err(GCWT_ERR_UNSUPPORTED, "GCWT_OUT_F64 needs rows of at most 8M samples: use gcwt_execute_block");
+    } else if (he != hipSuccess) {
+      return hip_err(he, "host_out.drain");
+    }
+  }
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (p->profiling) {
     float acc[ST_COUNT] = {0};

@@ -141,12 +141,20 @@ class CwtPlan:
         check(lib.gcwt_get_timings(self._handle, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.Timings._fields_}
 
-    def execute(self, x):
+    def _host_result(self, shape, wide):
+        """(array, flags) for a host result: float32/complex64, or the reference's
+        float64/complex128 when ``wide`` (widened by the library while it copies)."""
+        if not wide:
+            return np.empty(shape, dtype=self.out_dtype), 0
+        dt = np.complex128 if self.out_dtype == np.complex64 else np.float64
+        return np.empty(shape, dtype=dt), _lib.OUT_F64
+
+    def execute(self, x, wide=False):
         """x: array-like (C, N) -> ndarray out_shape (host in, host out)."""
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.n_channels, self.n_samples)
-        out = np.empty(self.out_shape, dtype=self.out_dtype)
+        out, flags = self._host_result(self.out_shape, wide)
         check(lib.gcwt_execute(self._handle, x.ctypes.data_as(C.c_void_p),
-                               out.ctypes.data_as(C.c_void_p), 0))
+                               out.ctypes.data_as(C.c_void_p), flags))
         return out
 
     def execute_device(self, x_buf, out_buf):
@@ -164,14 +172,14 @@ class CwtPlan:
             res.append((a.value, b.value, p.value))
         return res
 
-    def execute_block(self, x, start, length, reuse_means=False):
+    def execute_block(self, x, start, length, reuse_means=False, wide=False):
         """Samples [start, start+length) of every channel and scale from the whole
         recording x (C, N): ndarray (C, S, length).  Host in, host out."""
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.n_channels, self.n_samples)
-        out = np.empty((self.n_channels, self.n_freqs, int(length)), dtype=self.out_dtype)
+        out, flags = self._host_result((self.n_channels, self.n_freqs, int(length)), wide)
         check(lib.gcwt_execute_block(self._handle, x.ctypes.data_as(C.c_void_p),
                                      out.ctypes.data_as(C.c_void_p), int(start), int(length),
-                                     _lib.REUSE_MEANS if reuse_means else 0))
+                                     flags | (_lib.REUSE_MEANS if reuse_means else 0)))
         return out
 
     def execute_block_device(self, x_buf, out_buf, start, length, reuse_means=False):

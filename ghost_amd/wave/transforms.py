@@ -157,7 +157,8 @@ class ContinuousWaveletTransform(WaveletTransform):
             self._plan_key = key
         self._plan.set_profiling(bool(verbose))
         start_time = time.time()
-        res = self._plan.execute(x)                            # (C, S, N)
+        # float64 (the reference's dtype) is widened by the library while the result is copied
+        res = self._plan.execute(x, wide=np.dtype(dtype) == np.float64)   # (C, S, N)
         if verbose:
             self.last_timings = self._plan.timings()
             print("Elapsed time (only wavelet convolution): {} seconds"

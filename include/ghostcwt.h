@@ -57,8 +57,11 @@ typedef enum {
 enum {
   GCWT_X_ON_DEVICE = 1,   /* gcwt_execute: x is a device pointer                 */
   GCWT_OUT_ON_DEVICE = 2, /* gcwt_execute: out is a device pointer               */
-  GCWT_REUSE_MEANS = 4    /* gcwt_execute_block: keep the channel means of the
+  GCWT_REUSE_MEANS = 4,   /* gcwt_execute_block: keep the channel means of the
                              previous call on this plan (same x)                 */
+  GCWT_OUT_F64 = 8        /* host output only: out is float64 (amplitude, power) or
+                             float64 pairs (complex), the reference's result dtype
+                             (transforms.py:185); widened while the copy is in flight */
 };
 
 typedef struct gcwt_plan gcwt_plan;

@@ -241,6 +241,35 @@ def test_execute_block_streams_the_same_numbers():
     np.testing.assert_array_equal(p2.execute_block(x, 100, 5000), cfull[:, :, 100:5100])
 
 
+def test_wide_host_output_is_the_float32_result_widened():
+    """GCWT_OUT_F64: the reference's float64/complex128 result, widened while the copy from
+    the device is in flight (rows staged through pinned buffers, scattered by threads)."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp
+    fs, n = 1000.0, 70001                       # odd length: padded device rows, dense host rows
+    x = lfp(3, n, fs)
+    f = np.geomspace(200.0, 5.0, 40)            # 120 rows x 280 KB: several staging chunks
+    for output, narrow_dt, wide_dt in (("amplitude", np.float32, np.float64),
+                                       ("complex", np.complex64, np.complex128)):
+        p = CwtPlan(n, 3, fs, f, output=output)
+        a = p.execute(x)
+        b = p.execute(x, wide=True)
+        assert a.dtype == narrow_dt and b.dtype == wide_dt and a.shape == b.shape
+        np.testing.assert_array_equal(b, a.astype(wide_dt))
+        blk = p.execute_block(x, 1234, 40000, wide=True)
+        np.testing.assert_array_equal(blk, b[:, :, 1234:41234])
+        p.close()
+    # through the public API: float64 amplitude by default, float32 on request
+    from ghost_amd.wave import ContinuousWaveletTransform
+    cwt = ContinuousWaveletTransform()
+    t = np.arange(n) / fs
+    cwt.transform(x[0].astype(np.float64), fs=fs, timestamps=t, freq_limits=[5, 200])
+    a64 = cwt.amplitude
+    cwt.transform(x[0].astype(np.float64), fs=fs, timestamps=t, freq_limits=[5, 200], dtype=np.float32)
+    assert a64.dtype == np.float64 and cwt.amplitude.dtype == np.float32
+    np.testing.assert_array_equal(a64, cwt.amplitude.astype(np.float64))
+
+
 def test_time_block_shards_reassemble_the_transform():
     """SURVEY.md 8e, few channels x long recording: ranks take runs of time blocks, read
     the whole recording and stream their part; glued together = the full transform."""
