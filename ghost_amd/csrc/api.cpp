@@ -449,13 +449,17 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     const int64_t P = ep.p;
     const int P1 = ep.p1;
     // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
+    // The input is real, so rows k1 and P1 - k1 of the k1-major spectrum mirror each other:
+    // the fast path builds rows 0 .. P1/2 only and writes the rest as their reflections.
+    const bool hermitian = fast_fft && P1 >= 4;
+    const int rows_a = hermitian ? P1 / 2 + 1 : P1;
     RUN(ST_FWD, launch_fft_cols(-1, true, dx + ep.start, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0,
                                 p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n,
-                                ep.ne, C, st, ep.lead));
-    // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]
-    RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, P1, kRowLen, kRowLen, P, P, 0,
+                                ep.ne, C, st, ep.lead, rows_a));
+    // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]; only X[k < P/2] is ever read
+    RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, rows_a, kRowLen, kRowLen, P, P, 0,
                                 p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st,
-                                kRowLen / 2));   // only X[k < P/2] is ever read
+                                kRowLen / 2, hermitian ? P1 : 0));
     for (size_t l = 0; l < hp.levels.size(); ++l) {
       const LevelPlan& lp = hp.levels[l];
       const EpochLevel& el = ep.lv[l];

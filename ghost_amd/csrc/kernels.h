@@ -97,11 +97,11 @@ hipError_t launch_build_direct(float2* psi, const DirectScale* sc, int n_direct,
 hipError_t launch_fft_cols(int sign, bool real_in, const void* in, float2* out, int len, int ld,
                            int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
                            const float2* tw4096, const float2* tw256, const double* sums, double inv_n, int64_t n_valid,
-                           int n_channels, hipStream_t st, int64_t n_lead = 0);
+                           int n_channels, hipStream_t st, int64_t n_lead = 0, int rows_out = 0);
 hipError_t launch_fft_rows(int sign, const float2* in, float2* out, int len, int64_t n_rows,
                            int64_t in_ld, int64_t out_ld, int64_t in_cstride, int64_t out_cstride,
                            int64_t tw_n, const float2* tw4096, const float2* tw256, float scale,
-                           int n_channels, hipStream_t st, int out_len = 0);
+                           int n_channels, hipStream_t st, int out_len = 0, int mirror = 0);
 hipError_t launch_block_fft(const float2* xr, float2* xb, int64_t m, int hop, int halo, int blk_lo,
                             int nblk,
                             int64_t xr_cstride, int64_t xb_cstride, const float2* tw256, float scale,

@@ -118,9 +118,28 @@ __global__ void __launch_bounds__(256) k_channel_sum(const float* __restrict__ x
                                                      double* __restrict__ sums) {
   const int c = blockIdx.y;
   const float* xc = x + (int64_t)c * n;
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    acc += (double)xc[i];
+  // 16-byte loads over the aligned middle of the row, four independent fp64 accumulators
+  const int64_t head = std::min<int64_t>(n, (4 - (((uintptr_t)xc >> 2) & 3)) & 3);
+  const int64_t nv = (n - head) >> 2;
+  const float4* xv = reinterpret_cast<const float4*>(xc + head);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < nv; i += 2 * stride) {
+    const float4 u = xv[i], v = xv[i + stride];
+    a0 += (double)u.x + (double)v.x; a1 += (double)u.y + (double)v.y;
+    a2 += (double)u.z + (double)v.z; a3 += (double)u.w + (double)v.w;
+  }
+  if (i < nv) {
+    const float4 u = xv[i];
+    a0 += (double)u.x; a1 += (double)u.y; a2 += (double)u.z; a3 += (double)u.w;
+  }
+  double acc = (a0 + a1) + (a2 + a3);
+  if (blockIdx.x == 0) {   // the unaligned ends of the row
+    const int64_t tail0 = head + 4 * nv;
+    if ((int64_t)threadIdx.x < head) acc += (double)xc[threadIdx.x];
+    if (tail0 + (int64_t)threadIdx.x < n) acc += (double)xc[tail0 + threadIdx.x];
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   __shared__ double part[4];
@@ -370,7 +389,7 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
                                                int64_t out_ld, int64_t tw_n,
                                                const cf* __restrict__ tw4096,
                                                const cf* __restrict__ tw256, float scale, int row0,
-                                               int n_rows, int out_len) {
+                                               int n_rows, int out_len, int mirror) {
   constexpr int q = 1 << LQ, Q = 256 * q, rows = 16 >> LQ;
   const int tid = threadIdx.x;
   for (int e = tid; e < 4096; e += 256) {
@@ -434,8 +453,17 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
       for (int ka = 0; ka < q; ++ka) {
         cf val = u[ka];
         if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
-        if (256 * ka < out_len)   // out_len is a multiple of 256 (or the whole row)
-          o[(int64_t)row * out_ld + kb + 256 * ka] = make_float2(val.x * scale, val.y * scale);
+        const int idx = kb + 256 * ka;
+        if (mirror == 0) {
+          if (256 * ka < out_len)   // out_len is a multiple of 256 (or the whole row)
+            o[(int64_t)row * out_ld + idx] = make_float2(val.x * scale, val.y * scale);
+        } else if (idx < Q / 2) {
+          o[(int64_t)row * out_ld + idx] = make_float2(val.x * scale, val.y * scale);
+        } else if (row > 0 && 2 * row < mirror) {
+          // spectrum of a real signal, k1-major: X[(P1 - k1) + P1 k2] = conj(X[k1 + P1 (Q-1-k2)]),
+          // so the upper half of row k1 is the lower half of row P1 - k1, reversed
+          o[(int64_t)(mirror - row) * out_ld + (Q - 1 - idx)] = make_float2(val.x * scale, -val.y * scale);
+        }
       }
     }
   }
@@ -447,7 +475,7 @@ __global__ void __launch_bounds__(256, 4) k_fft_rows_fast(const cf* __restrict__
                                                        int64_t in_cstride, int64_t out_cstride,
                                                        int64_t tw_n, const cf* __restrict__ tw4096,
                                                        const cf* __restrict__ tw256, float scale,
-                                                       int n_rows, int out_len) {
+                                                       int n_rows, int out_len, int mirror) {
   // 16 exchange planes (16 x 272 complex) alias the 4096(+128 pad)-element data buffer
   __shared__ __attribute__((aligned(16))) cf buf[16 * kExCol];
   float* const ex_re = reinterpret_cast<float*>(buf);
@@ -456,11 +484,11 @@ __global__ void __launch_bounds__(256, 4) k_fft_rows_fast(const cf* __restrict__
   cf* o = out + (int64_t)blockIdx.y * out_cstride;
   const int row0 = blockIdx.x * (16 >> lq);
   switch (lq) {
-    case 0: rows_fast_body<SIGN, 0>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
-    case 1: rows_fast_body<SIGN, 1>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
-    case 2: rows_fast_body<SIGN, 2>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
-    case 3: rows_fast_body<SIGN, 3>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
-    default: rows_fast_body<SIGN, 4>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len); break;
+    case 0: rows_fast_body<SIGN, 0>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
+    case 1: rows_fast_body<SIGN, 1>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
+    case 2: rows_fast_body<SIGN, 2>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
+    case 3: rows_fast_body<SIGN, 3>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
+    default: rows_fast_body<SIGN, 4>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
   }
 }
 
@@ -470,7 +498,7 @@ __global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in
                                                      int ld, int64_t in_cstride, int64_t out_cstride,
                                                      int64_t tw_n, const cf* __restrict__ tw256,
                                                      const double* __restrict__ sums, double inv_n,
-                                                     int64_t n_valid, int64_t n_lead) {
+                                                     int64_t n_valid, int64_t n_lead, int rows_out) {
   __shared__ __attribute__((aligned(16))) cf tile[256 * 17];   // = 16 exchange planes, aliased
   float* const ex_re = reinterpret_cast<float*>(tile);
   float* const ex_im = ex_re + 16 * kExCol;
@@ -517,7 +545,8 @@ __global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in
   }
   __syncthreads();
   cf* o = out + (int64_t)c * out_cstride;
-  for (int e = tid; e < 4096; e += 256) {
+  // real input: rows k and 256 - k are conjugates, the caller asks for 0 .. 128 only
+  for (int e = tid; e < 16 * rows_out; e += 256) {
     const int k = e >> 4, cc = e & 15;
     o[(int64_t)k * ld + col0 + cc] = tile[k * 17 + cc];
   }
@@ -843,7 +872,7 @@ hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double*
                               hipStream_t st) {
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * n_channels, st);
   if (e != hipSuccess) return e;
-  int parts = (int)std::min<int64_t>(64, (n + 256 * 16 - 1) / (256 * 16));
+  int parts = (int)std::min<int64_t>(32, (n + 256 * 32 - 1) / (256 * 32));
   if (parts < 1) parts = 1;
   hipLaunchKernelGGL(k_channel_sum, dim3(parts, n_channels), dim3(256), 0, st, x, n, sums);
   GCWT_LAUNCH_CHECK();
@@ -876,17 +905,18 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int 
                            int64_t in_cstride, int64_t out_cstride, int64_t tw_n, const cf* tw4096,
                            const cf* tw256,
                            const double* sums, double inv_n, int64_t n_valid, int n_channels,
-                           hipStream_t st, int64_t n_lead) {
+                           hipStream_t st, int64_t n_lead, int rows_out) {
+  if (rows_out <= 0 || rows_out > len) rows_out = len;
   if (len == 256 && tw256) {
     dim3 grid(ld / 16, n_channels), block(256);
     if (sign < 0 && real_in)
-      hipLaunchKernelGGL((k_fft_cols256<-1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead);
+      hipLaunchKernelGGL((k_fft_cols256<-1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead, rows_out);
     else if (sign < 0)
-      hipLaunchKernelGGL((k_fft_cols256<-1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead);
+      hipLaunchKernelGGL((k_fft_cols256<-1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead, rows_out);
     else if (real_in)
-      hipLaunchKernelGGL((k_fft_cols256<1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead);
+      hipLaunchKernelGGL((k_fft_cols256<1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead, rows_out);
     else
-      hipLaunchKernelGGL((k_fft_cols256<1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead);
+      hipLaunchKernelGGL((k_fft_cols256<1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead, rows_out);
     GCWT_LAUNCH_CHECK();
     return hipSuccess;
   }
@@ -915,19 +945,20 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int 
 hipError_t launch_fft_rows(int sign, const cf* in, cf* out, int len, int64_t n_rows, int64_t in_ld,
                            int64_t out_ld, int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
                            const cf* tw4096, const cf* tw256, float scale, int n_channels,
-                           hipStream_t st, int out_len) {
+                           hipStream_t st, int out_len, int mirror) {
   const int l2 = ilog2(len);
+  if (mirror && !(len == kRowLenDev && tw256)) return hipErrorInvalidValue;   // fast 4096-point rows only
   const int rows = kRowLenDev / len;
   dim3 grid((unsigned)((n_rows + rows - 1) / rows), n_channels), block(256);
   if (len >= 256 && tw256) {
     if (sign < 0)
       hipLaunchKernelGGL((k_fft_rows_fast<-1>), grid, block, 0, st, in, out, l2 - 8, in_ld, out_ld,
                          in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows,
-                         out_len > 0 ? out_len : len);
+                         out_len > 0 ? out_len : len, mirror);
     else
       hipLaunchKernelGGL((k_fft_rows_fast<1>), grid, block, 0, st, in, out, l2 - 8, in_ld, out_ld,
                          in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows,
-                         out_len > 0 ? out_len : len);
+                         out_len > 0 ? out_len : len, mirror);
     GCWT_LAUNCH_CHECK();
     return hipSuccess;
   }
