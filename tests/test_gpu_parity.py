@@ -241,6 +241,18 @@ def test_execute_block_streams_the_same_numbers():
     np.testing.assert_array_equal(p2.execute_block(x, 100, 5000), cfull[:, :, 100:5100])
 
 
+def test_large_dc_offset_is_removed_in_double():
+    """Raw ADC-like data: offset 20x the signal.  The global mean (transforms.py:142-143) is
+    taken out in fp64 before any fp32 arithmetic, so the gate still holds."""
+    from ghost_amd.synthetic import lfp_channel
+    fs, n = 1000.0, 30000
+    x = (300.0 * lfp_channel(n, fs, 2) + 6000.0).astype(np.float32)
+    f = [220.0, 90.0, 31.0, 7.5]
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f)
+    p, c = _plan(x, fs, f, output="complex")
+    assert rel_err(c[0], ref).max() < TOL
+
+
 def test_wide_host_output_is_the_float32_result_widened():
     """GCWT_OUT_F64: the reference's float64/complex128 result, widened while the copy from
     the device is in flight (rows staged through pinned buffers, scattered by threads)."""

@@ -219,9 +219,41 @@ def test_planner_through_the_abi():
     # near-Nyquist scales go to the direct path (closed form invalid > 0.28 fs)
     p2 = CwtPlan(4096, 1, 1000.0, [391.0, 300.0, 280.0, 270.0, 200.0])
     assert p2.scale_info()["method"].tolist() == [1, 1, 1, 0, 0]
-    with pytest.raises(GhostCwtError) as e:
-        p2.upload()
-    assert e.value.code == _lib.ERR_NO_DEVICE or True   # on a GPU box upload succeeds
+    try:
+        p2.upload()                          # succeeds on a GPU box
+    except GhostCwtError as e:               # fails loudly without one: there is no CPU path
+        assert e.code == _lib.ERR_NO_DEVICE and "no CPU path" in str(e)
+
+
+def test_operator_entry_points_validate_then_need_a_device():
+    """gcwt_fastconv / gcwt_dft / gcwt_analytic_signal: argument errors come back as
+    GCWT_ERR_INVALID / UNSUPPORTED before any device is touched; a valid request on a box
+    without a GPU fails with GCWT_ERR_NO_DEVICE -- never a CPU result."""
+    from ghost_amd import sigtools
+    lib = _lib.lib
+    buf = (ctypes.c_float * 64)()
+    assert lib.gcwt_dft(None, 8, 0, 0, buf, -1) == _lib.ERR_INVALID
+    assert lib.gcwt_dft(buf, 0, 0, 0, buf, -1) == _lib.ERR_INVALID
+    assert lib.gcwt_dft(buf, (1 << 21) + 1, 0, 0, buf, -1) == _lib.ERR_UNSUPPORTED
+    assert lib.gcwt_analytic_signal(buf, 0, 0, buf, -1) == _lib.ERR_INVALID
+    assert b"empty" in lib.gcwt_last_error()
+    assert lib.gcwt_analytic_signal(buf, 16, 8, buf, -1) == _lib.ERR_INVALID
+    assert b"fft_length" in lib.gcwt_last_error()
+    assert lib.gcwt_analytic_signal(buf, 16, (1 << 21) + 1, buf, -1) == _lib.ERR_UNSUPPORTED
+    assert lib.gcwt_fastconv(buf, 8, buf, 4, 0, 7, buf, -1) == _lib.ERR_INVALID
+    x = np.arange(16.0)
+    for call in (lambda: sigtools.analytic_signal_hip(x), lambda: sigtools.chirpz_dft_hip(x),
+                 lambda: sigtools.fastconv_hip(x, np.ones(3))):
+        try:
+            res = call()
+            assert res.shape[0] == 16        # GPU box
+        except GhostCwtError as e:
+            assert e.code == _lib.ERR_NO_DEVICE and "no CPU path" in str(e)
+    # the Python wrappers raise the reference's exceptions before calling down
+    with pytest.raises(ValueError):
+        sigtools.analytic_signal_hip(x, fft_length=8)
+    with pytest.raises(ValueError):
+        sigtools.chirpz_dft_hip(np.zeros((2, 2)))
 
 
 def test_planner_rejects_bad_requests():
