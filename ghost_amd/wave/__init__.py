@@ -2,3 +2,4 @@
 from .wavelet import *      # noqa: F401,F403
 from .morse import *        # noqa: F401,F403
 from .transforms import *   # noqa: F401,F403
+from .morlet import *       # noqa: F401,F403

@@ -14,7 +14,7 @@ import numpy as np
 
 warnings.simplefilter("ignore")
 
-from ghost.wave import Morse                    # reference
+from ghost.wave import Morse, Morlet            # reference
 from ghost.wave import morseutils as mu         # reference
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -59,6 +59,14 @@ def main():
     g["space_opts"] = mu.morsespace(3.0, 20.0, 5000, high=2.0, eta=0.2, pack_num=3, low=0.01,
                                     density=4)
     g["space_g2"] = mu.morsespace(2.0, 8.0, 777, density=1)
+    # Morlet kernels (ghost/wave/morlet.py): default, and a 1 kHz / 40 Hz one re-tuned by setters
+    g["morlet_default"] = Morlet().get_wavelet()
+    mo = Morlet(w0=6, freq=40.0, fs=1000.0)
+    g["morlet_40hz"] = mo.get_wavelet()
+    g["morlet_40hz_scale"] = mo.scale
+    mo.freq = 12.5
+    mo.w0 = 7.0
+    g["morlet_retuned"] = mo.get_wavelet()
     path = os.path.join(HERE, "g10_morse_utils.npz")
     np.savez_compressed(path, **g)
     print("wrote", path, os.path.getsize(path), "bytes")

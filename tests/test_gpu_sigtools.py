@@ -93,3 +93,17 @@ def test_analytic_signal():
         analytic_signal_hip(np.zeros((4, 4)))
     with pytest.raises(ValueError):
         analytic_signal_hip(np.zeros(8), fft_length=4)
+
+
+def test_morlet_scale_through_fastconv():
+    """One Morlet scale = the signal convolved with Morlet.get_wavelet() (the reference's
+    Morlet is a kernel factory for fastconv_*; ghost/wave/morlet.py)."""
+    from ghost_amd.sigtools import fastconv_hip
+    from ghost_amd.wave import Morlet
+    rng = np.random.default_rng(5)
+    fs = 1000.0
+    x = rng.standard_normal(50000) + np.sin(2 * np.pi * 40.0 * np.arange(50000) / fs)
+    k = Morlet(freq=40.0, fs=fs).get_wavelet()
+    ref = convolve(x, k, mode="same")
+    got = fastconv_hip(x, k)
+    assert got.dtype == np.complex64 and _close(got, ref)

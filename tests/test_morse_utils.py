@@ -85,3 +85,19 @@ def test_morsespace(g10):
             mu.morsespace(3.0, 20.0, 1000, **bad)
     with pytest.raises(ValueError):
         mu.morsespace(3.0, 20.0, 1)
+
+
+def test_morlet_kernels(g10):
+    from ghost_amd.wave import Morlet
+    assert _rel(Morlet().get_wavelet(), g10["morlet_default"]) < 1e-13
+    mo = Morlet(w0=6, freq=40.0, fs=1000.0)
+    assert mo.get_wavelet().shape == g10["morlet_40hz"].shape
+    assert _rel(mo.get_wavelet(), g10["morlet_40hz"]) < 1e-13
+    assert abs(mo.scale - float(g10["morlet_40hz_scale"])) < 1e-15
+    mo.freq = 12.5
+    mo.w0 = 7.0
+    assert _rel(mo.get_wavelet(), g10["morlet_retuned"]) < 1e-13
+    assert repr(mo) == "Morlet" and mo.copy().freq == 12.5
+    for attr in ("fs", "w0", "freq"):
+        with pytest.raises(ValueError):
+            setattr(mo, attr, 0)
