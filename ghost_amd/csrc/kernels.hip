@@ -552,6 +552,61 @@ __global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in
   }
 }
 
+// Forward column pass for REAL input, two columns per FFT: z = x[.., 2m] + i x[.., 2m+1]
+// goes through one FFT256 and is split again with Z[k] +- conj(Z[256-k]); only rows
+// k = 0 .. 128 exist afterwards (the mirrored rows are reflected by the row pass).
+// Tile of 32 real columns per workgroup: 128-byte reads, 256-byte writes.  grid (ld/32, C)
+__global__ void __launch_bounds__(256) k_fft_cols256_real2(const float* __restrict__ in, cf* __restrict__ out,
+                                                           int ld, int64_t in_cstride, int64_t out_cstride,
+                                                           int64_t tw_n, const cf* __restrict__ tw256,
+                                                           const double* __restrict__ sums, double inv_n,
+                                                           int64_t n_valid, int64_t n_lead) {
+  __shared__ __attribute__((aligned(16))) cf tile[256 * 17];   // = 16 exchange planes, aliased
+  float* const ex_re = reinterpret_cast<float*>(tile);
+  float* const ex_im = ex_re + 16 * kExCol;
+  const int c = blockIdx.y, col0 = blockIdx.x * 32, tid = threadIdx.x;
+  const float* x = in + (int64_t)c * in_cstride;
+  const float mean = (float)(sums[c] * inv_n);
+  for (int e = tid; e < 4096; e += 256) {
+    const int i = e >> 4, cc = e & 15;
+    const int64_t n = (int64_t)i * ld + col0 + 2 * cc;
+    const int64_t na = min(max(n, n_lead), n_valid - 1), nb = min(max(n + 1, n_lead), n_valid - 1);
+    const float a = x[na], b = x[nb];               // clamped: no branch around the loads
+    tile[i * 17 + cc] = make_float2(n >= n_lead && n < n_valid ? a - mean : 0.f,
+                                    n + 1 >= n_lead && n + 1 < n_valid ? b - mean : 0.f);
+  }
+  __syncthreads();
+  const int s = tid >> 4, t = tid & 15;
+  cf tw[16], v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const cf w = tw256[(t * j) & 255];
+    tw[j] = make_float2(w.x, -w.y);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = tile[(t + 16 * j) * 17 + s];
+  fft256_16t_aliased<-1>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tile[(t + 16 * j) * 17 + s] = v[j];
+  __syncthreads();
+  // split and twiddle: thread = one real column, rows k = k0 + 8 i
+  const int cr = tid & 31, k0 = tid >> 5, m = cr >> 1;
+  const bool odd = cr & 1;
+  cf w = make_float2(1.f, 0.f), st = w;
+  if (tw_n > 0) {
+    w = unit_phase((int64_t)(col0 + cr) * k0, tw_n, -1);
+    st = unit_phase((int64_t)(col0 + cr) * 8, tw_n, -1);
+  }
+  cf* o = out + (int64_t)c * out_cstride + col0 + cr;
+  for (int k = k0; k <= 128; k += 8) {
+    const cf zk = tile[k * 17 + m], zm = tile[((256 - k) & 255) * 17 + m];
+    const cf val = odd ? make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x))
+                       : make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+    o[(int64_t)k * ld] = cmul(val, w);
+    w = cmul(w, st);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Block spectra: XB[blk][k] = scale * FFT_256(x_R[(blk*hop - halo + n) mod M])
 // 16 blocks per workgroup, 16 threads per block.  grid (ceil(nblk/16), C)
@@ -907,6 +962,13 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int 
                            const double* sums, double inv_n, int64_t n_valid, int n_channels,
                            hipStream_t st, int64_t n_lead, int rows_out) {
   if (rows_out <= 0 || rows_out > len) rows_out = len;
+  if (len == 256 && tw256 && sign < 0 && real_in && rows_out == 129 && ld % 32 == 0 && n_valid > 0) {
+    hipLaunchKernelGGL(k_fft_cols256_real2, dim3(ld / 32, n_channels), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(in), out, ld, in_cstride, out_cstride, tw_n, tw256,
+                       sums, inv_n, n_valid, n_lead);
+    GCWT_LAUNCH_CHECK();
+    return hipSuccess;
+  }
   if (len == 256 && tw256) {
     dim3 grid(ld / 16, n_channels), block(256);
     if (sign < 0 && real_in)
