@@ -492,34 +492,24 @@ __global__ void __launch_bounds__(256, 4) k_fft_rows_fast(const cf* __restrict__
   }
 }
 
-// Column pass for len = 256: tile of 16 columns, one FFT256 per column by 16 threads.
+// Column pass for len = 256: 16 columns per workgroup, one FFT256 per column by 16 threads.
+// Lanes run over the columns (16 consecutive complex = 128 bytes per row), so the inputs go
+// from global memory straight into the registers of the thread that transforms them and
+// the outputs straight back: the only LDS traffic is the FFT's own 16 x 16 exchange.  The
+// exchange planes of neighbouring columns are 290 floats apart: with lanes = columns that
+// keeps the 32 lanes of a half-wave on different banks (2 s + t).
+constexpr int kExColD = 290;
+
 template <int SIGN, bool REAL_IN>
-__global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in_, cf* __restrict__ out,
+__global__ void __launch_bounds__(256, 4) k_fft_cols256(const void* __restrict__ in_, cf* __restrict__ out,
                                                      int ld, int64_t in_cstride, int64_t out_cstride,
                                                      int64_t tw_n, const cf* __restrict__ tw256,
                                                      const double* __restrict__ sums, double inv_n,
                                                      int64_t n_valid, int64_t n_lead, int rows_out) {
-  __shared__ __attribute__((aligned(16))) cf tile[256 * 17];   // = 16 exchange planes, aliased
-  float* const ex_re = reinterpret_cast<float*>(tile);
-  float* const ex_im = ex_re + 16 * kExCol;
+  __shared__ float ex_re[16 * kExColD];
+  __shared__ float ex_im[16 * kExColD];
   const int c = blockIdx.y, col0 = blockIdx.x * 16, tid = threadIdx.x;
-  if (REAL_IN) {
-    const float* x = reinterpret_cast<const float*>(in_) + (int64_t)c * in_cstride;
-    const float mean = (float)(sums[c] * inv_n);
-    for (int e = tid; e < 4096; e += 256) {
-      const int i = e >> 4, cc = e & 15;
-      const int64_t n = (int64_t)i * ld + col0 + cc;
-      tile[i * 17 + cc] = make_float2(n >= n_lead && n < n_valid ? x[n] - mean : 0.f, 0.f);
-    }
-  } else {
-    const cf* x = reinterpret_cast<const cf*>(in_) + (int64_t)c * in_cstride;
-    for (int e = tid; e < 4096; e += 256) {
-      const int i = e >> 4, cc = e & 15;
-      tile[i * 17 + cc] = x[(int64_t)i * ld + col0 + cc];
-    }
-  }
-  __syncthreads();
-  const int s = tid >> 4, t = tid & 15;
+  const int s = tid & 15, t = tid >> 4;
   cf tw[16], v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -527,28 +517,33 @@ __global__ void __launch_bounds__(256) k_fft_cols256(const void* __restrict__ in
     if (SIGN < 0) w.y = -w.y;
     tw[j] = w;
   }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) v[j] = tile[(t + 16 * j) * 17 + s];
-  fft256_16t_aliased<SIGN>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
-  {
-    cf w = make_float2(1.f, 0.f), st = w;
-    if (tw_n > 0) {
-      w = unit_phase((int64_t)(col0 + s) * t, tw_n, SIGN);
-      st = unit_phase((int64_t)(col0 + s) * 16, tw_n, SIGN);
-    }
+  if (REAL_IN) {
+    const float* x = reinterpret_cast<const float*>(in_) + (int64_t)c * in_cstride;
+    const float mean = (float)(sums[c] * inv_n);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      cf val = v[j];
-      if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
-      tile[(t + 16 * j) * 17 + s] = val;
+      const int64_t n = (int64_t)(t + 16 * j) * ld + col0 + s;
+      const float a = x[min(max(n, n_lead), n_valid - 1)];   // clamped: no branch around the load
+      v[j] = make_float2(n >= n_lead && n < n_valid ? a - mean : 0.f, 0.f);
     }
+  } else {
+    const cf* x = reinterpret_cast<const cf*>(in_) + (int64_t)c * in_cstride + col0 + s;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = x[(int64_t)(t + 16 * j) * ld];
   }
-  __syncthreads();
-  cf* o = out + (int64_t)c * out_cstride;
-  // real input: rows k and 256 - k are conjugates, the caller asks for 0 .. 128 only
-  for (int e = tid; e < 16 * rows_out; e += 256) {
-    const int k = e >> 4, cc = e & 15;
-    o[(int64_t)k * ld + col0 + cc] = tile[k * 17 + cc];
+  fft256_16t<SIGN>(v, tw, ex_re + s * kExColD, ex_im + s * kExColD, t);
+  cf w = make_float2(1.f, 0.f), st = w;
+  if (tw_n > 0) {
+    w = unit_phase((int64_t)(col0 + s) * t, tw_n, SIGN);
+    st = unit_phase((int64_t)(col0 + s) * 16, tw_n, SIGN);
+  }
+  // real input: rows k and 256 - k are conjugates, the caller may ask for 0 .. 128 only
+  cf* o = out + (int64_t)c * out_cstride + col0 + s;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    cf val = v[j];
+    if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
+    if (t + 16 * j < rows_out) o[(int64_t)(t + 16 * j) * ld] = val;
   }
 }
 
