@@ -82,6 +82,7 @@ __device__ __forceinline__ void dft16(cf v[16]) {
 // ---------------------------------------------------------------------------
 constexpr int kExPitch = 17;
 constexpr int kExCol = 16 * kExPitch;  // floats per column per plane
+constexpr int kExColD = 290;           // same, when the lanes of a wave run over columns (see k_fft_cols256)
 
 template <int SIGN>
 __device__ __forceinline__ void fft256_16t(cf v[16], const cf tw[16], float* ex_re, float* ex_im,
@@ -392,12 +393,11 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
                                                int n_rows, int out_len, int mirror) {
   constexpr int q = 1 << LQ, Q = 256 * q, rows = 16 >> LQ;
   const int tid = threadIdx.x;
-  for (int e = tid; e < 4096; e += 256) {
-    const int rr = e >> (8 + LQ), i = e & (Q - 1);
-    buf[pad32(e)] = row0 + rr < n_rows ? x[(int64_t)(row0 + rr) * in_ld + i] : make_float2(0.f, 0.f);
-  }
-  __syncthreads();
-  const int s = tid >> 4, t = tid & 15;
+  // Lanes run over the 16 interleaved subsequences (row, a) so that each load instruction
+  // reads runs of q consecutive elements per row, straight into the registers of the thread
+  // that transforms them; for q = 1 lanes run along the row instead.
+  const int s = LQ == 0 ? tid >> 4 : tid & 15, t = LQ == 0 ? tid & 15 : tid >> 4;
+  constexpr int col_stride = LQ == 0 ? kExCol : kExColD;
   const int rr = s >> LQ, a = s & (q - 1);
   cf tw[16], v[16];
 #pragma unroll
@@ -406,9 +406,16 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
     if (SIGN < 0) w.y = -w.y;
     tw[j] = w;
   }
+  {
+    const bool live = row0 + rr < n_rows;
+    const cf* xp = x + (int64_t)min(row0 + rr, n_rows - 1) * in_ld + q * t + a;   // clamped row
 #pragma unroll
-  for (int j = 0; j < 16; ++j) v[j] = buf[pad32(rr * Q + q * (t + 16 * j) + a)];
-  fft256_16t_aliased<SIGN>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
+    for (int j = 0; j < 16; ++j) {
+      const cf u = xp[q * 16 * j];
+      v[j] = live ? u : make_float2(0.f, 0.f);
+    }
+  }
+  fft256_16t<SIGN>(v, tw, ex_re + s * col_stride, ex_im + s * col_stride, t);
   if (q == 1) {
     const int row = row0 + rr;
     if (row < n_rows) {
@@ -427,6 +434,7 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
     }
     return;
   }
+  __syncthreads();   // the element buffer below aliases the exchange planes
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int kb = t + 16 * j;
@@ -476,10 +484,11 @@ __global__ void __launch_bounds__(256, 4) k_fft_rows_fast(const cf* __restrict__
                                                        int64_t tw_n, const cf* __restrict__ tw4096,
                                                        const cf* __restrict__ tw256, float scale,
                                                        int n_rows, int out_len, int mirror) {
-  // 16 exchange planes (16 x 272 complex) alias the 4096(+128 pad)-element data buffer
-  __shared__ __attribute__((aligned(16))) cf buf[16 * kExCol];
+  // the exchange planes (2 x 16 x 290 floats) alias the 4096(+128 pad)-element buffer of
+  // the second stage
+  __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
   float* const ex_re = reinterpret_cast<float*>(buf);
-  float* const ex_im = ex_re + 16 * kExCol;
+  float* const ex_im = ex_re + 16 * kExColD;
   const cf* x = in + (int64_t)blockIdx.y * in_cstride;
   cf* o = out + (int64_t)blockIdx.y * out_cstride;
   const int row0 = blockIdx.x * (16 >> lq);
@@ -498,7 +507,6 @@ __global__ void __launch_bounds__(256, 4) k_fft_rows_fast(const cf* __restrict__
 // the outputs straight back: the only LDS traffic is the FFT's own 16 x 16 exchange.  The
 // exchange planes of neighbouring columns are 290 floats apart: with lanes = columns that
 // keeps the 32 lanes of a half-wave on different banks (2 s + t).
-constexpr int kExColD = 290;
 
 template <int SIGN, bool REAL_IN>
 __global__ void __launch_bounds__(256, 4) k_fft_cols256(const void* __restrict__ in_, cf* __restrict__ out,
