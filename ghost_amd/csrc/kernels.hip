@@ -564,22 +564,15 @@ __global__ void __launch_bounds__(256) k_fft_cols256_real2(const float* __restri
                                                            int64_t tw_n, const cf* __restrict__ tw256,
                                                            const double* __restrict__ sums, double inv_n,
                                                            int64_t n_valid, int64_t n_lead) {
-  __shared__ __attribute__((aligned(16))) cf tile[256 * 17];   // = 16 exchange planes, aliased
+  // exchange planes (lanes over columns: 290-float column stride) aliased by the 256 x 17
+  // tile the split stage reads
+  __shared__ __attribute__((aligned(16))) cf tile[16 * kExColD];
   float* const ex_re = reinterpret_cast<float*>(tile);
-  float* const ex_im = ex_re + 16 * kExCol;
+  float* const ex_im = ex_re + 16 * kExColD;
   const int c = blockIdx.y, col0 = blockIdx.x * 32, tid = threadIdx.x;
   const float* x = in + (int64_t)c * in_cstride;
   const float mean = (float)(sums[c] * inv_n);
-  for (int e = tid; e < 4096; e += 256) {
-    const int i = e >> 4, cc = e & 15;
-    const int64_t n = (int64_t)i * ld + col0 + 2 * cc;
-    const int64_t na = min(max(n, n_lead), n_valid - 1), nb = min(max(n + 1, n_lead), n_valid - 1);
-    const float a = x[na], b = x[nb];               // clamped: no branch around the loads
-    tile[i * 17 + cc] = make_float2(n >= n_lead && n < n_valid ? a - mean : 0.f,
-                                    n + 1 >= n_lead && n + 1 < n_valid ? b - mean : 0.f);
-  }
-  __syncthreads();
-  const int s = tid >> 4, t = tid & 15;
+  const int s = tid & 15, t = tid >> 4;
   cf tw[16], v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -587,8 +580,15 @@ __global__ void __launch_bounds__(256) k_fft_cols256_real2(const float* __restri
     tw[j] = make_float2(w.x, -w.y);
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) v[j] = tile[(t + 16 * j) * 17 + s];
-  fft256_16t_aliased<-1>(v, tw, ex_re + s * kExCol, ex_im + s * kExCol, t);
+  for (int j = 0; j < 16; ++j) {
+    const int64_t n = (int64_t)(t + 16 * j) * ld + col0 + 2 * s;
+    const int64_t na = min(max(n, n_lead), n_valid - 1), nb = min(max(n + 1, n_lead), n_valid - 1);
+    const float a = x[na], b = x[nb];               // clamped: no branch around the loads
+    v[j] = make_float2(n >= n_lead && n < n_valid ? a - mean : 0.f,
+                       n + 1 >= n_lead && n + 1 < n_valid ? b - mean : 0.f);
+  }
+  fft256_16t<-1>(v, tw, ex_re + s * kExColD, ex_im + s * kExColD, t);
+  __syncthreads();   // the tile aliases the planes
 #pragma unroll
   for (int j = 0; j < 16; ++j) tile[(t + 16 * j) * 17 + s] = v[j];
   __syncthreads();
