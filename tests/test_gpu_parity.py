@@ -141,6 +141,50 @@ def test_edge_shapes_against_oracle():
     assert np.all(a == 0)
 
 
+def test_seeded_random_layouts_against_oracle():
+    """Twelve seeded random problems: channel counts, lengths (down to a handful of
+    samples), several epochs with gaps, sampling rates, mixed direct/spectral scales, every
+    output mode, forced time blocks."""
+    rng = np.random.default_rng(20261003)
+    for case in range(12):
+        fs = float(rng.choice([250.0, 1000.0, 2000.0, 30000.0]))
+        n_ch = int(rng.integers(1, 5))
+        n = int(rng.choice([9, 64, 300, 1000, 2049, 7777, 20000, 33000]))
+        x = rng.standard_normal((n_ch, n)).astype(np.float32)
+        x += rng.uniform(-3, 3, (n_ch, 1)).astype(np.float32)
+        # epochs: 1-3 pieces covering parts of [0, n)
+        cuts = np.sort(rng.choice(np.arange(1, n), size=min(n - 1, int(rng.integers(0, 5))),
+                                  replace=False)) if n > 4 else np.array([], int)
+        edges = [0, *cuts.tolist(), n]
+        eb = [[a, b] for a, b in zip(edges[:-1], edges[1:]) if rng.random() < 0.8 or b - a == n]
+        if not eb:
+            eb = [[0, n]]
+        # frequencies between ~40 cycles per shortest epoch (or 0.002 fs) and 0.45 fs
+        shortest = min(b - a for a, b in eb)
+        lo = max(0.002 * fs, 12.0 * fs / max(shortest, 24))
+        f = np.sort(np.exp(rng.uniform(np.log(lo), np.log(0.45 * fs), int(rng.integers(1, 7)))))[::-1] \
+            if lo < 0.45 * fs else np.array([0.4 * fs])
+        output = ["complex", "amplitude", "power"][case % 3]
+        kw = dict(epoch_bounds=eb, output=output)
+        if case % 4 == 3 and n >= 20000:
+            kw["max_fft_log2"] = 13
+        ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, np.array(eb))
+                        for c in range(n_ch)])
+        if output == "amplitude":
+            ref = np.abs(ref)
+        elif output == "power":
+            ref = np.abs(ref) ** 2
+        try:
+            p, got = _plan(x, fs, f, **kw)
+        except Exception as e:           # a layout the planner refuses must say so, not crash
+            assert "UNSUPPORTED" in repr(e) or getattr(e, "code", 0) == -2, (case, repr(e))
+            continue
+        scale = np.abs(ref).max(axis=2, keepdims=True)
+        scale[scale == 0] = 1.0
+        err = (np.abs(got - ref) / scale).max()
+        assert err < (2 * TOL if output == "power" else TOL), (case, fs, n, eb, f, output, err)
+
+
 def test_gap_between_epochs_is_zero():
     from ghost_amd.synthetic import lfp_channel
     fs = 1000.0
