@@ -68,6 +68,7 @@ def _load():
         "gcwt_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
         "gcwt_device_memset": (C.c_int, [vp, C.c_int, C.c_size_t]),
         "gcwt_device_synchronize": (C.c_int, []),
+        "gcwt_device_memory": (C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "gcwt_plan_create": (C.c_int, [C.POINTER(vp), C.POINTER(Params)]),
         "gcwt_plan_destroy": (None, [vp]),
         "gcwt_plan_get_info": (C.c_int, [vp, C.POINTER(PlanInfo)]),

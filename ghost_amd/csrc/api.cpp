@@ -189,6 +189,12 @@ int gcwt_device_name(int device, char* buf, size_t buflen) {
 }
 
 int gcwt_set_device(int device) { HIP_TRY(hipSetDevice(device)); return GCWT_OK; }
+
+int gcwt_device_memory(size_t* free_bytes, size_t* total_bytes) {
+  if (!free_bytes || !total_bytes) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+  return GCWT_OK;
+}
 int gcwt_device_malloc(void** ptr, size_t bytes) { HIP_TRY(hipMalloc(ptr, bytes ? bytes : 1)); return GCWT_OK; }
 int gcwt_device_free(void* ptr) { HIP_TRY(hipFree(ptr)); return GCWT_OK; }
 int gcwt_memcpy_h2d(void* dst, const void* src, size_t bytes) {

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import lib, check
 
-__all__ = ["CwtPlan", "DeviceBuffer", "device_count", "device_name"]
+__all__ = ["CwtPlan", "DeviceBuffer", "device_count", "device_name", "device_memory"]
 
 
 def device_count():
@@ -24,6 +24,13 @@ def device_name(device=0):
     buf = C.create_string_buffer(256)
     check(lib.gcwt_device_name(device, buf, 256))
     return buf.value.decode()
+
+
+def device_memory():
+    """(free, total) bytes of the current device."""
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    check(lib.gcwt_device_memory(C.byref(free), C.byref(total)))
+    return free.value, total.value
 
 
 class DeviceBuffer:

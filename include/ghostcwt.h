@@ -121,6 +121,8 @@ int gcwt_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int gcwt_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int gcwt_device_memset(void* dst, int value, size_t bytes);
 int gcwt_device_synchronize(void);
+/* Free and total bytes of the current device's memory (for sizing time blocks). */
+int gcwt_device_memory(size_t* free_bytes, size_t* total_bytes);
 
 /* Planning: host only, touches no device.  Replaces the per-call setup of
  * transforms.py:179-185 (wavelet lengths, output allocation) and decides, per

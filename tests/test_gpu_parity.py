@@ -185,6 +185,34 @@ def test_seeded_random_layouts_against_oracle():
         assert err < (2 * TOL if output == "power" else TOL), (case, fs, n, eb, f, output, err)
 
 
+def test_plans_give_their_memory_back():
+    """Create / run / close plans of several layouts (host and device results, time blocks,
+    the sigtools operators): the device's free memory returns to where it was."""
+    from ghost_amd.engine import CwtPlan, DeviceBuffer, device_memory
+    from ghost_amd.sigtools import analytic_signal_hip, fastconv_hip
+    from ghost_amd.synthetic import lfp
+    fs, n = 1000.0, 60000
+    x = lfp(4, n, fs)
+    warm = CwtPlan(n, 4, fs, [100.0, 10.0]); warm.execute(x); warm.close()
+    analytic_signal_hip(x[0][:5001])
+    free0, total = device_memory()
+    assert total > 200e9                      # 288 GB part
+    for it in range(6):
+        kw = dict(output=["amplitude", "complex"][it % 2])
+        if it % 3 == 2:
+            kw["max_fft_log2"] = 13
+        p = CwtPlan(n, 4, fs, np.geomspace(300.0, 3.0, 10 + it), **kw)
+        p.execute(x, wide=bool(it & 1))
+        xb = DeviceBuffer(x.nbytes); xb.upload(x)
+        ob = DeviceBuffer(p.info["out_bytes"])
+        p.execute_device(xb, ob)
+        xb.free(); ob.free(); p.close()
+        fastconv_hip(x[0], np.ones(100))
+        analytic_signal_hip(x[1][:5001])
+    free1, _ = device_memory()
+    assert abs(free1 - free0) < 64 << 20, (free0, free1)
+
+
 def test_gap_between_epochs_is_zero():
     from ghost_amd.synthetic import lfp_channel
     fs = 1000.0
