@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -31,6 +32,20 @@ int set_err(int code, const std::string& msg) {
 int hip_err(hipError_t e, const char* what) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
   return e == hipErrorOutOfMemory ? GCWT_ERR_NOMEM : GCWT_ERR_HIP;
+}
+
+// Nothing may unwind across the C ABI: entry points that allocate run inside this.
+template <typename F>
+int guarded(F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return set_err(GCWT_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception& e) {
+    return set_err(GCWT_ERR_INVALID, std::string("internal error: ") + e.what());
+  } catch (...) {
+    return set_err(GCWT_ERR_INVALID, "internal error");
+  }
 }
 
 #define HIP_TRY(call)                                  \
@@ -208,7 +223,7 @@ int gcwt_device_memset(void* dst, int value, size_t bytes) {
 }
 int gcwt_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return GCWT_OK; }
 
-int gcwt_plan_create(gcwt_plan** out, const gcwt_params* params) {
+static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   if (!out || !params) return set_err(GCWT_ERR_INVALID, "NULL argument");
   *out = nullptr;
   gcwt_plan* p = new (std::nothrow) gcwt_plan();
@@ -282,7 +297,7 @@ int gcwt_plan_set_row_pitch(gcwt_plan* plan, int64_t pitch_samples) {
   return GCWT_OK;
 }
 
-int gcwt_plan_upload(gcwt_plan* p) {
+static int gcwt_plan_upload_impl(gcwt_plan* p) {
   if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
   if (p->uploaded) return GCWT_OK;
   int ndev = 0;
@@ -633,12 +648,12 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   return GCWT_OK;
 }
 
-int gcwt_execute(gcwt_plan* p, const void* x, void* out, int flags) {
+static int gcwt_execute_impl(gcwt_plan* p, const void* x, void* out, int flags) {
   if (!p || !x || !out) return set_err(GCWT_ERR_INVALID, "NULL argument");
   return execute_range(p, x, out, 0, p->hp.prm.n_samples, flags & ~GCWT_REUSE_MEANS);
 }
 
-int gcwt_execute_block(gcwt_plan* p, const void* x, void* out, int64_t start, int64_t length,
+static int gcwt_execute_block_impl(gcwt_plan* p, const void* x, void* out, int64_t start, int64_t length,
                        int flags) {
   if (!p || !x || !out) return set_err(GCWT_ERR_INVALID, "NULL argument");
   if (start < 0 || length <= 0 || start + length > p->hp.prm.n_samples)
@@ -660,7 +675,7 @@ int gcwt_plan_segment_info(const gcwt_plan* p, int segment, int64_t* core_start,
   return GCWT_OK;
 }
 
-int gcwt_fastconv(const float* signal, int64_t n, const float* kernel, int64_t m,
+static int gcwt_fastconv_impl(const float* signal, int64_t n, const float* kernel, int64_t m,
                   int kernel_is_complex, int mode, float* out, int device) {
   if (!signal || !kernel || !out || n <= 0 || m <= 0) return set_err(GCWT_ERR_INVALID, "bad argument");
   if (mode < 0 || mode > 2) return set_err(GCWT_ERR_INVALID, "Mode must be 'full', 'same', or 'valid'");
@@ -769,6 +784,29 @@ int gcwt_get_timings(const gcwt_plan* p, gcwt_timings* t) {
   if (!p->have_timings) return set_err(GCWT_ERR_INVALID, "no profiled execute yet");
   *t = p->last;
   return GCWT_OK;
+}
+
+// ---- exception-safe entry points ------------------------------------------
+int gcwt_plan_create(gcwt_plan** out, const gcwt_params* params) {
+  return guarded([&] { return gcwt_plan_create_impl(out, params); });
+}
+
+int gcwt_plan_upload(gcwt_plan* p) {
+  return guarded([&] { return gcwt_plan_upload_impl(p); });
+}
+
+int gcwt_execute(gcwt_plan* p, const void* x, void* out, int flags) {
+  return guarded([&] { return gcwt_execute_impl(p, x, out, flags); });
+}
+
+int gcwt_execute_block(gcwt_plan* p, const void* x, void* out, int64_t start, int64_t length,
+                       int flags) {
+  return guarded([&] { return gcwt_execute_block_impl(p, x, out, start, length, flags); });
+}
+
+int gcwt_fastconv(const float* signal, int64_t n, const float* kernel, int64_t m,
+                  int kernel_is_complex, int mode, float* out, int device) {
+  return guarded([&] { return gcwt_fastconv_impl(signal, n, kernel, m, kernel_is_complex, mode, out, device); });
 }
 
 // ---- debug hooks (include/ghostcwt_debug.h) --------------------------------

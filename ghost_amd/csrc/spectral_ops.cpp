@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -101,15 +102,25 @@ int check_device(int device) {
   return GCWT_OK;
 }
 
+// nothing may unwind across the C ABI
+template <typename F>
+int guarded(F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return fail(GCWT_ERR_NOMEM, "out of host memory");
+  } catch (...) {
+    return fail(GCWT_ERR_INVALID, "internal error");
+  }
+}
+
 int engine_error(const ChirpEngine& e) {
   return fail(GCWT_ERR_HIP, std::string(e.where) + ": " + hipGetErrorString(e.err));
 }
 
 }  // namespace
 
-extern "C" {
-
-int gcwt_dft(const float* x, int64_t n, int is_complex, int inverse, float* out, int device) {
+static int dft_impl(const float* x, int64_t n, int is_complex, int inverse, float* out, int device) {
   if (!x || !out || n <= 0) return fail(GCWT_ERR_INVALID, "bad argument");
   if (2 * n - 1 > (int64_t)kRowLen * kMaxP1)
     return fail(GCWT_ERR_UNSUPPORTED, "DFT length exceeds 2^21");
@@ -131,7 +142,7 @@ int gcwt_dft(const float* x, int64_t n, int is_complex, int inverse, float* out,
   return good ? GCWT_OK : engine_error(e);
 }
 
-int gcwt_analytic_signal(const float* signal, int64_t n, int64_t fft_length, float* out,
+static int analytic_impl(const float* signal, int64_t n, int64_t fft_length, float* out,
                          int device) {
   if (!signal || !out) return fail(GCWT_ERR_INVALID, "bad argument");
   if (n <= 0) return fail(GCWT_ERR_INVALID, "Cannot compute analytic signal on an empty array");
@@ -161,6 +172,17 @@ int gcwt_analytic_signal(const float* signal, int64_t n, int64_t fft_length, flo
       e.ok(hipMemcpyAsync(out, e.out, sizeof(float2) * n, hipMemcpyDeviceToHost, e.st), "copy out") &&
       e.ok(hipStreamSynchronize(e.st), "sync");
   return good ? GCWT_OK : engine_error(e);
+}
+
+extern "C" {
+
+int gcwt_dft(const float* x, int64_t n, int is_complex, int inverse, float* out, int device) {
+  return guarded([&] { return dft_impl(x, n, is_complex, inverse, out, device); });
+}
+
+int gcwt_analytic_signal(const float* signal, int64_t n, int64_t fft_length, float* out,
+                         int device) {
+  return guarded([&] { return analytic_impl(signal, n, fft_length, out, device); });
 }
 
 }  // extern "C"
