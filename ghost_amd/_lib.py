@@ -91,6 +91,7 @@ def _load():
         "gcwt_comm_broadcast_bank": (C.c_int, [vp, vp, C.c_int]),
         # test-only hooks (include/ghostcwt_debug.h)
         "gcwt_debug_level_count": (C.c_int, [vp]),
+        "gcwt_debug_batch_of": (C.c_int, [vp, C.c_int, i32p, i32p]),
         "gcwt_debug_level_info": (C.c_int, [vp, C.c_int, C.c_int, i32p, i32p, i32p, i32p, i64p]),
         "gcwt_debug_fetch": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int64]),
     }

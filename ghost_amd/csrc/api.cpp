@@ -314,9 +314,11 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
 
   const bool any_spectral = hp.n_direct < S;
   if (any_spectral) {
-    if ((rc = dev_alloc(&p->d_x, (size_t)(C * hp.max_p)))) return bail(rc);
-    if ((rc = dev_alloc(&p->d_xr, (size_t)(C * hp.max_xr)))) return bail(rc);
-    if ((rc = dev_alloc(&p->d_xb, (size_t)(C * hp.max_xb)))) return bail(rc);
+    // one workspace slot per (segment of a batch, channel)
+    const int64_t slots = C * hp.max_batch;
+    if ((rc = dev_alloc(&p->d_x, (size_t)(slots * hp.max_p)))) return bail(rc);
+    if ((rc = dev_alloc(&p->d_xr, (size_t)(slots * hp.max_xr)))) return bail(rc);
+    if ((rc = dev_alloc(&p->d_xb, (size_t)(slots * hp.max_xb)))) return bail(rc);
   }
   if ((rc = dev_alloc(&p->d_bank, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_gain, (size_t)S * B))) return bail(rc);
@@ -377,6 +379,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   p->ep_dev.resize(hp.epochs.size());
   for (size_t e = 0; e < hp.epochs.size(); ++e) {
     const EpochPlan& ep = hp.epochs[e];
+    if (ep.batch_count == 0) continue;     // shares the tables of its batch's first segment
     std::vector<SynthItemDev> items(ep.items.size());
     for (size_t i = 0; i < items.size(); ++i)
       items[i] = {ep.items[i].level, ep.items[i].scale, ep.items[i].blk0, ep.items[i].nblk};
@@ -462,24 +465,44 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
 
   const bool any_spectral = hp.n_direct < S;
   const bool fast_fft = !getenv("GHOSTCWT_SLOW_FFT");
-  for (size_t e = 0; any_spectral && e < hp.epochs.size(); ++e) {
-    const EpochPlan& ep = hp.epochs[e];
-    // output window of this segment, segment-local: core of the segment, cut to the range
-    const int64_t w_lo = std::max(ep.core0, r0) - ep.start, w_hi = std::min(ep.core1, r1) - ep.start;
-    if (w_hi <= w_lo) continue;
+  for (size_t e0 = 0; any_spectral && e0 < hp.epochs.size();) {
+    // one batch: segments e0 .. e0 + count - 1 share the FFT length and the level grids;
+    // those with something to write in [r0, r1) become extra sets of "channels"
+    const EpochPlan& ep = hp.epochs[e0];
+    const size_t count = (size_t)std::max(1, ep.batch_count);
+    SegIn sin{};
+    SegOut sout{};
+    int nb = 0;
+    for (size_t i = 0; i < count; ++i) {
+      const EpochPlan& m = hp.epochs[e0 + i];
+      // output window of the segment, segment-local: its core, cut to the range
+      const int64_t w_lo = std::max(m.core0, r0) - m.start, w_hi = std::min(m.core1, r1) - m.start;
+      if (w_hi <= w_lo) continue;
+      sin.x_off[nb] = m.start;
+      sin.n_valid[nb] = m.ne;
+      sin.n_lead[nb] = m.lead;
+      sout.seg_col[nb] = m.start - r0;
+      sout.w_lo[nb] = w_lo;
+      sout.w_hi[nb] = w_hi;
+      ++nb;
+    }
+    e0 += count;
+    if (nb == 0) continue;
+    sin.n_channels = sout.n_channels = C;
+    const int slots = C * nb;
     const int64_t P = ep.p;
     const int P1 = ep.p1;
-    // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
     // The input is real, so rows k1 and P1 - k1 of the k1-major spectrum mirror each other:
     // the fast path builds rows 0 .. P1/2 only and writes the rest as their reflections.
     const bool hermitian = fast_fft && P1 >= 4;
     const int rows_a = hermitian ? P1 / 2 + 1 : P1;
-    RUN(ST_FWD, launch_fft_cols(-1, true, dx + ep.start, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0,
-                                p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n,
-                                ep.ne, C, st, ep.lead, rows_a));
+    // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
+    RUN(ST_FWD, launch_fft_cols_batch(dx, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0, p->d_tw4096,
+                                      fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n, sin, nb, st,
+                                      rows_a));
     // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]; only X[k < P/2] is ever read
     RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, rows_a, kRowLen, kRowLen, P, P, 0,
-                                p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st,
+                                p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, st,
                                 kRowLen / 2, hermitian ? P1 : 0));
     for (size_t l = 0; l < hp.levels.size(); ++l) {
       const LevelPlan& lp = hp.levels[l];
@@ -490,56 +513,53 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         // x_R[Q m1 + m2] = sum_{j1} e^{2 pi i j1 m1/P1} e^{2 pi i j1 m2/M} sum_{j2} X~[j1][j2] e^{2 pi i j2 m2/Q}
         RUN(ST_DECIM, launch_fft_rows(+1, p->d_x, xr, Q, P1, kRowLen, Q, P, hp.max_xr,
                                       P1 > 1 ? el.m : 0, p->d_tw4096,
-                                      fast_fft ? p->d_tw256 : nullptr, 1.0f, C, st));
+                                      fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, st));
         if (P1 > 1)
           RUN(ST_DECIM, launch_fft_cols(+1, false, xr, xr, P1, Q, hp.max_xr, hp.max_xr, 0,
                                         p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums,
-                                        inv_n, 0, C, st));
+                                        inv_n, 0, slots, st));
       } else {
         // M = P/R <= 8192: rows j1 < n1 of X~, q leading entries each
         const int n1 = (int)std::min<int64_t>(P1, el.m);
         const int q = (int)(el.m / n1);
-        RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, C, st));
+        RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, slots, st));
       }
       const float scale = (float)(1.0 / ((double)hp.block * (double)P));
       RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.blk_lo,
-                                     el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, C, st));
+                                     el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, slots, st));
     }
+    const EpochDev& dev = p->ep_dev[ep.batch_first];
     if (p->use_synth16 || !hp.halo_static) {
       SynthArgs a{};
       a.xb = p->d_xb;
       a.bank = p->d_bank;
       a.tw256 = p->d_tw256;
       a.level_tw = p->d_level_tw;
-      a.items = p->ep_dev[e].items;
-      a.levels = p->ep_dev[e].levels;
+      a.items = dev.items;
+      a.levels = dev.levels;
       a.out = dout;
       a.xb_cstride = hp.max_xb;
       a.row_len = row_len;
-      a.seg_col = ep.start - r0;
-      a.w_lo = w_lo;
-      a.w_hi = w_hi;
       a.n_scales = S;
-      RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), C, st));
+      a.seg = sout;
+      RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), slots, st));
     } else {
       Synth7Args a7{};
       a7.xb = p->d_xb;
       a7.bank = p->d_bank;
       a7.tw256 = p->d_tw256;
       a7.level_tw = p->d_level_tw;
-      a7.items = p->ep_dev[e].items7;
-      a7.levels = p->ep_dev[e].levels7;
+      a7.items = dev.items7;
+      a7.levels = dev.levels7;
       a7.scale_list = p->d_scale_list;
       a7.gain = p->d_gain;
       a7.level_half_tw = p->d_half_tw;
       a7.out = dout;
       a7.xb_cstride = hp.max_xb;
       a7.row_len = row_len;
-      a7.seg_col = ep.start - r0;
-      a7.w_lo = w_lo;
-      a7.w_hi = w_hi;
       a7.n_scales = S;
-      RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, p->ep_dev[e].n_items7, C, st));
+      a7.seg = sout;
+      RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, dev.n_items7, slots, st));
     }
     if (p->profiling) p->last.synth_launches++;
   }
@@ -828,6 +848,16 @@ int gcwt_debug_level_info(const gcwt_plan* p, int epoch, int level, int32_t* dec
   return GCWT_OK;
 }
 
+int gcwt_debug_batch_of(const gcwt_plan* p, int segment, int32_t* first, int32_t* count) {
+  if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  if (segment < 0 || segment >= (int)p->hp.epochs.size())
+    return set_err(GCWT_ERR_INVALID, "segment out of range");
+  const int f = p->hp.epochs[segment].batch_first;
+  if (first) *first = f;
+  if (count) *count = p->hp.epochs[f].batch_count;
+  return GCWT_OK;
+}
+
 int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, float* dst,
                      int64_t max_complex) {
   if (!p || !dst) return set_err(GCWT_ERR_INVALID, "NULL argument");
@@ -836,18 +866,20 @@ int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, 
   if (epoch < 0 || epoch >= (int)hp.epochs.size() || channel < 0 || channel >= hp.prm.n_channels)
     return set_err(GCWT_ERR_INVALID, "epoch/channel out of range");
   const EpochPlan& ep = hp.epochs[epoch];
+  // workspace slot of (segment, channel) after a full execute: position in its batch
+  const int64_t slot = (int64_t)(epoch - ep.batch_first) * hp.prm.n_channels + channel;
   const float2* src = nullptr;
   int64_t n = 0;
   if (what == GCWT_DEBUG_SPECTRUM) {
-    src = p->d_x + (int64_t)channel * ep.p;
+    src = p->d_x + slot * ep.p;
     n = ep.p;
   } else {
     if (level < 0 || level >= (int)hp.levels.size()) return set_err(GCWT_ERR_INVALID, "level out of range");
     if (what == GCWT_DEBUG_DECIMATED) {
-      src = p->d_xr + (int64_t)channel * hp.max_xr + ep.lv[level].xr_offset;
+      src = p->d_xr + slot * hp.max_xr + ep.lv[level].xr_offset;
       n = ep.lv[level].m;
     } else if (what == GCWT_DEBUG_BLOCK_SPECTRA) {
-      src = p->d_xb + (int64_t)channel * hp.max_xb + ep.lv[level].xb_offset;
+      src = p->d_xb + slot * hp.max_xb + ep.lv[level].xb_offset;
       n = (int64_t)ep.lv[level].nblk * hp.block;
     } else {
       return set_err(GCWT_ERR_INVALID, "unknown buffer");

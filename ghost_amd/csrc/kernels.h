@@ -27,6 +27,23 @@ struct DirectScale {
   int32_t pad;
 };
 
+// Segments launched together (planner.h: batches).  blockIdx.y = segment * n_channels +
+// channel; every workspace array simply has n_channels * n_segments "channels", only the
+// kernels that touch the caller's arrays need the per-segment numbers below.
+constexpr int kSegBatch = 16;
+struct SegIn {                       // forward column pass: where the segment's samples are
+  int64_t x_off[kSegBatch];          // offset of segment sample 0 inside a channel's row
+  int64_t n_valid[kSegBatch];        // segment-local samples [n_lead, n_valid) exist, the
+  int64_t n_lead[kSegBatch];         //   rest read as zero
+  int32_t n_channels, pad;
+};
+struct SegOut {                      // synthesis: where the segment's results go
+  int64_t seg_col[kSegBatch];        // column of segment sample 0 in an out row (may be < 0)
+  int64_t w_lo[kSegBatch];           // segment-local samples [w_lo, w_hi) are written
+  int64_t w_hi[kSegBatch];
+  int32_t n_channels, pad;
+};
+
 struct SynthItemDev {
   int32_t level, scale, blk0, nblk;
 };
@@ -47,10 +64,9 @@ struct SynthArgs {
   float* out;
   int64_t xb_cstride;
   int64_t row_len;       // samples per (channel, scale) row of out
-  int64_t seg_col;       // column of the segment's sample 0 in an out row (may be negative)
-  int64_t w_lo, w_hi;    // segment-local samples [w_lo, w_hi) are written
   int32_t n_scales;
   int32_t pad;
+  SegOut seg;
 };
 
 struct Synth7Item {
@@ -78,10 +94,9 @@ struct Synth7Args {
   float* out;
   int64_t xb_cstride;
   int64_t row_len;       // samples per (channel, scale) row of out
-  int64_t seg_col;       // column of the segment's sample 0 in an out row (may be negative)
-  int64_t w_lo, w_hi;    // segment-local samples [w_lo, w_hi) are written
   int32_t n_scales;
   int32_t pad;
+  SegOut seg;
 };
 
 hipError_t launch_synth7(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
@@ -98,6 +113,11 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, float2* out, 
                            int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
                            const float2* tw4096, const float2* tw256, const double* sums, double inv_n, int64_t n_valid,
                            int n_channels, hipStream_t st, int64_t n_lead = 0, int rows_out = 0);
+// forward pass of a batch of segments: real input, grid.y = segs.n_channels * n_segments
+hipError_t launch_fft_cols_batch(const float* in, float2* out, int len, int ld, int64_t in_cstride,
+                                 int64_t out_cstride, int64_t tw_n, const float2* tw4096,
+                                 const float2* tw256, const double* sums, double inv_n,
+                                 const SegIn& segs, int n_segments, hipStream_t st, int rows_out);
 hipError_t launch_fft_rows(int sign, const float2* in, float2* out, int len, int64_t n_rows,
                            int64_t in_ld, int64_t out_ld, int64_t in_cstride, int64_t out_cstride,
                            int64_t tw_n, const float2* tw4096, const float2* tw256, float scale,

@@ -256,15 +256,17 @@ __global__ void __launch_bounds__(256) k_fft_cols(const void* __restrict__ in_, 
                                                   int64_t out_cstride, int64_t tw_n,
                                                   const cf* __restrict__ tw4096,
                                                   const double* __restrict__ sums, double inv_n,
-                                                  int64_t n_valid, int64_t n_lead) {
+                                                  const SegIn segs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* buf = reinterpret_cast<cf*>(smem);
-  const int c = blockIdx.y;
+  const int c = blockIdx.y;               // workspace slot: segment * n_channels + channel
   const int col0 = blockIdx.x * 16;
   const int total = len * 16;
   if (REAL_IN) {
-    const float* x = reinterpret_cast<const float*>(in_) + (int64_t)c * in_cstride;
-    const float mean = (float)(sums[c] * inv_n);
+    const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
+    const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+    const float* x = reinterpret_cast<const float*>(in_) + (int64_t)ch * in_cstride + segs.x_off[g];
+    const float mean = (float)(sums[ch] * inv_n);
     for (int e = threadIdx.x; e < total; e += 256) {
       const int i = e >> 4, cc = e & 15;
       const int64_t n = (int64_t)i * ld + col0 + cc;
@@ -513,10 +515,10 @@ __global__ void __launch_bounds__(256, 4) k_fft_cols256(const void* __restrict__
                                                      int ld, int64_t in_cstride, int64_t out_cstride,
                                                      int64_t tw_n, const cf* __restrict__ tw256,
                                                      const double* __restrict__ sums, double inv_n,
-                                                     int64_t n_valid, int64_t n_lead, int rows_out) {
+                                                     const SegIn segs, int rows_out) {
   __shared__ float ex_re[16 * kExColD];
   __shared__ float ex_im[16 * kExColD];
-  const int c = blockIdx.y, col0 = blockIdx.x * 16, tid = threadIdx.x;
+  const int c = blockIdx.y, col0 = blockIdx.x * 16, tid = threadIdx.x;   // c: workspace slot
   const int s = tid & 15, t = tid >> 4;
   cf tw[16], v[16];
 #pragma unroll
@@ -526,8 +528,10 @@ __global__ void __launch_bounds__(256, 4) k_fft_cols256(const void* __restrict__
     tw[j] = w;
   }
   if (REAL_IN) {
-    const float* x = reinterpret_cast<const float*>(in_) + (int64_t)c * in_cstride;
-    const float mean = (float)(sums[c] * inv_n);
+    const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
+    const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+    const float* x = reinterpret_cast<const float*>(in_) + (int64_t)ch * in_cstride + segs.x_off[g];
+    const float mean = (float)(sums[ch] * inv_n);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int64_t n = (int64_t)(t + 16 * j) * ld + col0 + s;
@@ -563,15 +567,17 @@ __global__ void __launch_bounds__(256) k_fft_cols256_real2(const float* __restri
                                                            int ld, int64_t in_cstride, int64_t out_cstride,
                                                            int64_t tw_n, const cf* __restrict__ tw256,
                                                            const double* __restrict__ sums, double inv_n,
-                                                           int64_t n_valid, int64_t n_lead) {
+                                                           const SegIn segs) {
   // exchange planes (lanes over columns: 290-float column stride) aliased by the 256 x 17
   // tile the split stage reads
   __shared__ __attribute__((aligned(16))) cf tile[16 * kExColD];
   float* const ex_re = reinterpret_cast<float*>(tile);
   float* const ex_im = ex_re + 16 * kExColD;
-  const int c = blockIdx.y, col0 = blockIdx.x * 32, tid = threadIdx.x;
-  const float* x = in + (int64_t)c * in_cstride;
-  const float mean = (float)(sums[c] * inv_n);
+  const int c = blockIdx.y, col0 = blockIdx.x * 32, tid = threadIdx.x;   // c: workspace slot
+  const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
+  const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+  const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
+  const float mean = (float)(sums[ch] * inv_n);
   const int s = tid & 15, t = tid >> 4;
   cf tw[16], v[16];
 #pragma unroll
@@ -661,7 +667,9 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
 
   const SynthItemDev it = a.items[blockIdx.x];
   const SynthLevelDev lv = a.levels[it.level];
-  const int c = blockIdx.y;
+  const int c = blockIdx.y;               // workspace slot: segment * n_channels + channel
+  const int seg = c / a.seg.n_channels, ch = c - seg * a.seg.n_channels;
+  const int64_t w_lo = a.seg.w_lo[seg], w_hi = a.seg.w_hi[seg];
   const int R = lv.decimation, hop = lv.hop, halo = lv.halo;
   const int colw = threadIdx.x >> 4, t = threadIdx.x & 15;
 
@@ -676,7 +684,7 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
 
   const cf* xb = a.xb + (int64_t)c * a.xb_cstride + lv.xb_offset;
   const cf* ltw = a.level_tw + lv.tw_offset;
-  float* out = a.out + (((int64_t)c * a.n_scales + it.scale) * a.row_len + a.seg_col) * kElem;
+  float* out = a.out + (((int64_t)ch * a.n_scales + it.scale) * a.row_len + a.seg.seg_col[seg]) * kElem;
 
   const int ncols = it.nblk * R;
   // per batch geometry of the staged tile
@@ -739,7 +747,7 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
       }
       for (int q = threadIdx.x; q < count; q += 256) {
         const int64_t n = n0 + (int64_t)(q >> 4) * row_stride + (q & 15);
-        if (n >= a.w_lo && n < a.w_hi) {
+        if (n >= w_lo && n < w_hi) {
           if (kElem == 1) out[n] = tile[q];
           else { out[2 * n] = tile[2 * q]; out[2 * n + 1] = tile[2 * q + 1]; }
         }
@@ -959,29 +967,59 @@ hipError_t launch_build_direct(cf* psi, const DirectScale* sc, int n_direct, int
   return hipSuccess;
 }
 
+static hipError_t launch_fft_cols_segs(int sign, bool real_in, const void* in, cf* out, int len, int ld,
+                                       int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
+                                       const cf* tw4096, const cf* tw256, const double* sums,
+                                       double inv_n, const SegIn& segs, int n_segments, hipStream_t st,
+                                       int rows_out);
+
 hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int len, int ld,
                            int64_t in_cstride, int64_t out_cstride, int64_t tw_n, const cf* tw4096,
                            const cf* tw256,
                            const double* sums, double inv_n, int64_t n_valid, int n_channels,
                            hipStream_t st, int64_t n_lead, int rows_out) {
+  SegIn one{};
+  one.n_valid[0] = n_valid;
+  one.n_lead[0] = n_lead;
+  one.n_channels = n_channels;
+  return launch_fft_cols_segs(sign, real_in, in, out, len, ld, in_cstride, out_cstride, tw_n, tw4096,
+                              tw256, sums, inv_n, one, 1, st, rows_out);
+}
+
+hipError_t launch_fft_cols_batch(const float* in, cf* out, int len, int ld, int64_t in_cstride,
+                                 int64_t out_cstride, int64_t tw_n, const cf* tw4096, const cf* tw256,
+                                 const double* sums, double inv_n, const SegIn& segs, int n_segments,
+                                 hipStream_t st, int rows_out) {
+  return launch_fft_cols_segs(-1, true, in, out, len, ld, in_cstride, out_cstride, tw_n, tw4096, tw256,
+                              sums, inv_n, segs, n_segments, st, rows_out);
+}
+
+static hipError_t launch_fft_cols_segs(int sign, bool real_in, const void* in, cf* out, int len, int ld,
+                                       int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
+                                       const cf* tw4096, const cf* tw256, const double* sums,
+                                       double inv_n, const SegIn& segs, int n_segments, hipStream_t st,
+                                       int rows_out) {
+  const int n_channels = segs.n_channels * n_segments;   // workspace slots
+  bool all_valid = true;
+  for (int g = 0; g < n_segments; ++g) all_valid = all_valid && segs.n_valid[g] > 0;
   if (rows_out <= 0 || rows_out > len) rows_out = len;
-  if (len == 256 && tw256 && sign < 0 && real_in && rows_out == 129 && ld % 32 == 0 && n_valid > 0) {
+  if (len == 256 && tw256 && sign < 0 && real_in && rows_out == 129 && ld % 32 == 0 && all_valid) {
     hipLaunchKernelGGL(k_fft_cols256_real2, dim3(ld / 32, n_channels), dim3(256), 0, st,
                        reinterpret_cast<const float*>(in), out, ld, in_cstride, out_cstride, tw_n, tw256,
-                       sums, inv_n, n_valid, n_lead);
+                       sums, inv_n, segs);
     GCWT_LAUNCH_CHECK();
     return hipSuccess;
   }
   if (len == 256 && tw256) {
     dim3 grid(ld / 16, n_channels), block(256);
     if (sign < 0 && real_in)
-      hipLaunchKernelGGL((k_fft_cols256<-1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead, rows_out);
+      hipLaunchKernelGGL((k_fft_cols256<-1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, segs, rows_out);
     else if (sign < 0)
-      hipLaunchKernelGGL((k_fft_cols256<-1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead, rows_out);
+      hipLaunchKernelGGL((k_fft_cols256<-1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, segs, rows_out);
     else if (real_in)
-      hipLaunchKernelGGL((k_fft_cols256<1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead, rows_out);
+      hipLaunchKernelGGL((k_fft_cols256<1, true>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, segs, rows_out);
     else
-      hipLaunchKernelGGL((k_fft_cols256<1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, n_valid, n_lead, rows_out);
+      hipLaunchKernelGGL((k_fft_cols256<1, false>), grid, block, 0, st, in, out, ld, in_cstride, out_cstride, tw_n, tw256, sums, inv_n, segs, rows_out);
     GCWT_LAUNCH_CHECK();
     return hipSuccess;
   }
@@ -996,7 +1034,7 @@ hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int 
       if (e != hipSuccess) return e;                                                              \
     }                                                                                             \
     hipLaunchKernelGGL((k_fft_cols<S, RI>), grid, block, lds, st, in, out, len, l2, ld,           \
-                       in_cstride, out_cstride, tw_n, tw4096, sums, inv_n, n_valid, n_lead);              \
+                       in_cstride, out_cstride, tw_n, tw4096, sums, inv_n, segs);                        \
   }
   if (sign < 0 && real_in) GCWT_COLS(-1, true)
   else if (sign < 0) GCWT_COLS(-1, false)

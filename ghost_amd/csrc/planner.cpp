@@ -2,6 +2,8 @@
 #include "planner.h"
 
 #include <algorithm>
+#include <climits>
+#include <cstdlib>
 #include <cmath>
 #include <map>
 
@@ -177,10 +179,9 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     hp->level_twiddle_total += (int64_t)kSynthCols * lp.decimation;
   }
 
-  // per-epoch level grids and synthesis work items
+  // per-segment block ranges of every level
   for (EpochPlan& ep : hp->epochs) {
     ep.lv.resize(hp->levels.size());
-    int64_t xr = 0, xb = 0;
     for (size_t l = 0; l < hp->levels.size(); ++l) {
       const LevelPlan& lp = hp->levels[l];
       EpochLevel& el = ep.lv[l];
@@ -190,27 +191,66 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       const int64_t span = (int64_t)lp.hop * lp.decimation;
       el.blk_lo = (int)(w_lo / span);
       el.nblk = (int)((w_hi + span - 1) / span) - el.blk_lo;
-      el.xr_offset = xr;
-      el.xb_offset = xb;
-      xr += el.m;
-      xb += (int64_t)el.nblk * B;
-      const int group = std::max(1, 64 / std::min(lp.decimation, 64));
-      for (int b0 = 0; b0 < el.nblk; b0 += group) {
-        for (int s : lp.scales) {
-          SynthItem it{(int32_t)l, (int32_t)s, (int32_t)b0,
-                       (int32_t)std::min(group, el.nblk - b0)};
-          ep.items.push_back(it);
-        }
-      }
     }
-    ep.xr_total = xr;
-    ep.xb_total = xb;
+  }
+  // Batches: consecutive segments of one FFT length run as one launch set.  They share the
+  // level grids (the union of their block ranges: a block past a segment's own range only
+  // produces samples outside its window, which the stores drop) and each owns a slot of
+  // the workspace, so the batch size is bounded by a memory budget.
+  const int64_t C = prm.n_channels;
+  int64_t budget = (int64_t)6 << 30;
+  if (const char* e = getenv("GHOSTCWT_BATCH_BYTES")) budget = std::max<int64_t>(0, atoll(e));
+  for (size_t first = 0; first < hp->epochs.size();) {
+    EpochPlan& lead = hp->epochs[first];
+    int64_t blocks = 0;
+    for (size_t l = 0; l < hp->levels.size(); ++l) blocks += (int64_t)lead.lv[l].nblk * B;
+    const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks);   // X + x_R (< P) + XB, roughly
+    int cap = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, budget / std::max<int64_t>(1, per_slot)));
+    size_t count = 1;
+    while (first + count < hp->epochs.size() && (int)count < cap && hp->epochs[first + count].p == lead.p)
+      ++count;
+    // shared grids
+    std::vector<EpochLevel> lv(hp->levels.size());
+    std::vector<SynthItem> items;
+    int64_t xr = 0, xb = 0;
+    for (size_t l = 0; l < hp->levels.size(); ++l) {
+      const LevelPlan& lp = hp->levels[l];
+      int lo = INT32_MAX, hi = 0;
+      for (size_t i = 0; i < count; ++i) {
+        const EpochLevel& el = hp->epochs[first + i].lv[l];
+        lo = std::min(lo, el.blk_lo);
+        hi = std::max(hi, el.blk_lo + el.nblk);
+      }
+      EpochLevel& g = lv[l];
+      g.m = lead.p / lp.decimation;
+      g.blk_lo = lo;
+      g.nblk = hi - lo;
+      g.xr_offset = xr;
+      g.xb_offset = xb;
+      xr += g.m;
+      xb += (int64_t)g.nblk * B;
+      const int group = std::max(1, 64 / std::min(lp.decimation, 64));
+      for (int b0 = 0; b0 < g.nblk; b0 += group)
+        for (int sc : lp.scales)
+          items.push_back(SynthItem{(int32_t)l, (int32_t)sc, (int32_t)b0,
+                                    (int32_t)std::min(group, g.nblk - b0)});
+    }
+    for (size_t i = 0; i < count; ++i) {
+      EpochPlan& ep = hp->epochs[first + i];
+      ep.lv = lv;
+      ep.items = items;
+      ep.xr_total = xr;
+      ep.xb_total = xb;
+      ep.batch_first = (int)first;
+      ep.batch_count = i == 0 ? (int)count : 0;
+    }
     hp->max_xr = std::max(hp->max_xr, xr);
     hp->max_xb = std::max(hp->max_xb, xb);
+    hp->max_batch = std::max(hp->max_batch, (int)count);
+    first += count;
   }
 
-  const int64_t C = prm.n_channels;
-  hp->workspace_bytes = 8 * C * (hp->max_p + hp->max_xr + hp->max_xb)   // X, x_R, XB
+  hp->workspace_bytes = 8 * C * hp->max_batch * (hp->max_p + hp->max_xr + hp->max_xb)   // X, x_R, XB
                         + 8 * (int64_t)prm.n_freqs * B                  // bank
                         + 8 * (hp->direct_total + hp->level_twiddle_total + kRowLen + 256)
                         + 16 * C;

@@ -18,6 +18,7 @@ namespace gcwt {
 constexpr int kRowLen = 4096;      // row length of the two-pass big FFT (P = P1 * 4096)
 constexpr int kMaxP1 = 1024;       // P <= 2^22
 constexpr int kMaxDecimation = 16384;
+constexpr int kMaxBatch = 16;                // segments per launch set (kernels.h: kSegBatch)
 constexpr int kMaxTwoPassDecimation = 256;   // above it the level IFFT uses the small-size kernel
 constexpr int kSynthCols = 16;     // columns (block, r) per batch of the 16-column kernel
 constexpr int kSynthWide = 32;      // columns per batch of the production kernel
@@ -64,9 +65,13 @@ struct EpochPlan {
   int epoch = 0;
   int64_t p = 0;                   // FFT length of this epoch
   int p1 = 0;                      // p = p1 * kRowLen
-  std::vector<EpochLevel> lv;      // one per HostPlan::levels
+  std::vector<EpochLevel> lv;      // one per HostPlan::levels; shared by the segment's batch
   std::vector<SynthItem> items;
   int64_t xr_total = 0, xb_total = 0;  // per-channel complex elements
+  // Segments of equal FFT length are launched together, each as an extra set of "channels"
+  // (many short epochs, or the time blocks of a long one): batch_first is the first segment
+  // of this one's batch, batch_count (set on that first segment) how many follow it.
+  int batch_first = 0, batch_count = 1;
 };
 
 struct HostPlan {
@@ -88,6 +93,7 @@ struct HostPlan {
   int64_t level_twiddle_total = 0;
   int64_t max_p = 0, max_xr = 0, max_xb = 0;
   int max_fft_log2 = 22;
+  int max_batch = 1;               // largest batch_count in the plan: workspace slots per channel
   size_t out_elem_bytes = 4;
   int64_t workspace_bytes = 0;
 };

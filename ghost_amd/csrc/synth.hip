@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
 
   const Synth7Item it = a.items[blockIdx.x];
   const Synth7Level lv = a.levels[it.level];
-  const int c = blockIdx.y;
+  const int c = blockIdx.y;               // workspace slot: segment * n_channels + channel
+  const int seg = c / a.seg.n_channels, ch = c - seg * a.seg.n_channels;
   const int R = lv.decimation, lg = lv.log2r, hop = lv.hop, halo = lv.halo;
   const int tid = threadIdx.x;
   const int colw = tid >> 4, t = tid & 15;
@@ -167,10 +168,11 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   // dropped by the hardware range check, so the store loop carries no bound tests.
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;   // floats per output sample
   const int64_t n_b = (int64_t)(lv.blk_base + it.blk0) * hop * R;   // first sample of the block group
-  const int64_t w_len = a.w_hi - a.w_lo;
+  const int64_t w_lo = a.seg.w_lo[seg];
+  const int64_t w_len = a.seg.w_hi[seg] - w_lo;
   const unsigned ext_bytes = w_len > 0 ? (unsigned)(w_len * (4 * kElem)) : 0u;
-  float* const out0 = a.out + ((int64_t)c * a.n_scales * a.row_len + a.seg_col + a.w_lo) * kElem;
-  const unsigned voff0 = (unsigned)(((int)(n_b - a.w_lo) + off0) * (4 * kElem));
+  float* const out0 = a.out + ((int64_t)ch * a.n_scales * a.row_len + a.seg.seg_col[seg] + w_lo) * kElem;
+  const unsigned voff0 = (unsigned)(((int)(n_b - w_lo) + off0) * (4 * kElem));
   const unsigned vstep = (unsigned)(m1step * (4 * kElem));
   const float* const st_rd = stage + t;
   __syncthreads();

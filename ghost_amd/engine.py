@@ -221,6 +221,16 @@ class CwtPlan:
                         "nblk": nb.value, "m": m.value})
         return res
 
+    def debug_batches(self):
+        """[(first_segment, count)] of the launch batches the plan's segments form."""
+        res, seg, n = [], 0, lib.gcwt_plan_segment_count(self._handle)
+        while seg < n:
+            first, count = C.c_int32(), C.c_int32()
+            check(lib.gcwt_debug_batch_of(self._handle, seg, C.byref(first), C.byref(count)))
+            res.append((first.value, count.value))
+            seg = first.value + max(1, count.value)
+        return res
+
     def debug_fetch(self, what, channel=0, epoch=0, level=0):
         lv = self.debug_levels(epoch)
         if what == 0:

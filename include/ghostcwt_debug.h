@@ -19,6 +19,9 @@ enum {
 int gcwt_debug_level_count(const gcwt_plan* plan);
 int gcwt_debug_level_info(const gcwt_plan* plan, int epoch, int level, int32_t* decimation,
                           int32_t* halo, int32_t* hop, int32_t* nblk, int64_t* m);
+/* Segments of equal FFT length are launched together: first segment and size of the batch
+ * that `segment` belongs to. */
+int gcwt_debug_batch_of(const gcwt_plan* plan, int segment, int32_t* first, int32_t* count);
 int gcwt_debug_fetch(gcwt_plan* plan, int what, int channel, int epoch, int level, float* dst,
                      int64_t max_complex);
 

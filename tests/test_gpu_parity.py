@@ -185,6 +185,33 @@ def test_seeded_random_layouts_against_oracle():
         assert err < (2 * TOL if output == "power" else TOL), (case, fs, n, eb, f, output, err)
 
 
+def test_batched_epochs_against_oracle():
+    """40 epochs of uneven length with unused gaps between some of them: launched 16 at a
+    time as extra 'channels'.  Every epoch must equal its own 'same' convolution, and a
+    block request that touches only part of a batch must equal the slice."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp
+    fs, n = 1000.0, 120000
+    x = lfp(2, n, fs) + np.array([[0.4], [-1.1]], np.float32)
+    eb = [[i * 3000 + (i % 3) * 11, i * 3000 + 2000 + 37 * (i % 5)] for i in range(40)]
+    f = [320.0, 140.0, 61.0, 33.0]                 # one direct scale, three decimation levels
+    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, np.array(eb)) for c in range(2)])
+    p = CwtPlan(n, 2, fs, f, epoch_bounds=eb, output="complex")
+    assert p.debug_batches() == [(0, 16), (16, 16), (32, 8)]
+    got = p.execute(x)
+    scale = np.abs(ref).max(axis=2, keepdims=True)
+    assert (np.abs(got - ref) / scale).max() < TOL
+    inside = np.zeros(n, bool)
+    for a, b in eb:
+        inside[a:b] = True
+    assert np.all(got[:, :, ~inside] == 0)         # samples of no epoch (transforms.py:185)
+    # range covering the tail of one batch and the head of the next, cutting epochs in half
+    blk = p.execute_block(x, 40000, 23456)
+    np.testing.assert_array_equal(blk, got[:, :, 40000:63456])
+    pa = CwtPlan(n, 2, fs, f, epoch_bounds=eb, output="amplitude")
+    assert (np.abs(pa.execute(x) - np.abs(ref)) / scale).max() < TOL
+
+
 def test_plans_give_their_memory_back():
     """Create / run / close plans of several layouts (host and device results, time blocks,
     the sigtools operators): the device's free memory returns to where it was."""

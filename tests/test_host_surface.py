@@ -307,6 +307,28 @@ def test_time_blocks_tile_the_epochs():
     assert p.scale_info()["decimation"].tolist() == [32, 2048, 16384]
 
 
+def test_segments_of_equal_fft_length_are_batched(monkeypatch):
+    """Many short epochs (or the time blocks of a long one) become extra 'channels' of one
+    launch set, up to 16 at a time and within a workspace budget."""
+    fs = 1000.0
+    eb = [[i * 3000, i * 3000 + 2000 + 37 * (i % 5)] for i in range(40)]    # P = 4096 each
+    p = CwtPlan(120000, 2, fs, [100.0, 40.0], epoch_bounds=eb)
+    assert p.debug_batches() == [(0, 16), (16, 16), (32, 8)]
+    lv0 = p.debug_levels(epoch=0)
+    assert lv0 == p.debug_levels(epoch=15)                  # members share the level grids
+    assert p.info["workspace_bytes"] > 16 * 2 * 4096 * 8
+    # epochs of different FFT lengths never share a batch
+    eb2 = [[0, 3000], [3000, 6000], [6000, 26000], [26000, 29000]]
+    p2 = CwtPlan(30000, 1, fs, [100.0, 40.0], epoch_bounds=eb2)
+    assert p2.debug_batches() == [(0, 2), (2, 1), (3, 1)]
+    # time blocks of one long epoch batch too, until the budget says stop
+    p3 = CwtPlan(200000, 1, fs, [100.0, 40.0], max_fft_log2=13)
+    assert p3.debug_batches()[0] == (0, 16) and len(p3.segments()) > 16
+    monkeypatch.setenv("GHOSTCWT_BATCH_BYTES", "1")
+    p4 = CwtPlan(200000, 1, fs, [100.0, 40.0], max_fft_log2=13)
+    assert all(c == 1 for _, c in p4.debug_batches())
+
+
 def test_output_adapter():
     from ghost_amd.formats import output_numpy_or_asa
     d = np.zeros((10, 3))
