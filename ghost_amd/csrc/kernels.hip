@@ -671,6 +671,12 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
   const int seg = c / a.seg.n_channels, ch = c - seg * a.seg.n_channels;
   const int64_t w_lo = a.seg.w_lo[seg], w_hi = a.seg.w_hi[seg];
   const int R = lv.decimation, hop = lv.hop, halo = lv.halo;
+  {
+    // union grids of a batch: nothing to do when these blocks keep no sample in the window
+    const int64_t span = (int64_t)hop * R;
+    const int64_t first = (int64_t)(lv.blk_base + it.blk0) * span;
+    if (first + (int64_t)it.nblk * span <= w_lo || first >= w_hi) return;
+  }
   const int colw = threadIdx.x >> 4, t = threadIdx.x & 15;
 
   cf tw[16];

@@ -106,6 +106,14 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   const int c = blockIdx.y;               // workspace slot: segment * n_channels + channel
   const int seg = c / a.seg.n_channels, ch = c - seg * a.seg.n_channels;
   const int R = lv.decimation, lg = lv.log2r, hop = lv.hop, halo = lv.halo;
+  {
+    // The level grids are the union over the batch's segments: leave at once if this
+    // group of blocks keeps no sample inside this segment's window (workgroup-uniform).
+    const int64_t span = (int64_t)hop * R;
+    const int64_t first = (int64_t)(lv.blk_base + it.blk0) * span;
+    const int64_t last = first + (int64_t)(R > NCOL ? 1 : NCOL / R) * span;
+    if (last <= a.seg.w_lo[seg] || first >= a.seg.w_hi[seg]) return;
+  }
   const int tid = threadIdx.x;
   const int colw = tid >> 4, t = tid & 15;
   const bool wide = R > NCOL;
