@@ -564,14 +564,28 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     if (p->profiling) p->last.synth_launches++;
   }
   if (hp.n_direct > 0) {
+    DirectEpochs eps{};
+    eps.n_channels = C;
+    int ne = 0;
+    auto flush = [&]() -> int {
+      if (ne > 0)
+        RUN(ST_DIRECT, launch_direct(mode, dx, dout, p->d_psi, p->d_direct_sc, hp.n_direct, p->d_sums,
+                                     inv_n, N, S, eps, ne, r0, row_len, st));
+      ne = 0;
+      return GCWT_OK;
+    };
     for (size_t i = 0; i + 1 < hp.bounds.size(); i += 2) {
       const int64_t e0 = hp.bounds[i], e1 = hp.bounds[i + 1];
       const int64_t g_lo = std::max(e0, r0), g_hi = std::min(e1, r1);
-      if (g_hi > g_lo)
-        RUN(ST_DIRECT, launch_direct(mode, dx, dout, p->d_psi, p->d_direct_sc, hp.n_direct,
-                                     p->d_sums, inv_n, N, S, e0, e1 - e0, g_lo, g_hi, r0, row_len,
-                                     C, st));
+      if (g_hi <= g_lo) continue;
+      eps.epoch_start[ne] = e0;
+      eps.epoch_len[ne] = e1 - e0;
+      eps.g_lo[ne] = g_lo;
+      eps.g_hi[ne] = g_hi;
+      if (++ne == kSegBatch) { int rc_ = flush(); if (rc_) return rc_; }
     }
+    int rc_ = flush();
+    if (rc_) return rc_;
   }
 #undef RUN
   return GCWT_OK;

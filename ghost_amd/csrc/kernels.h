@@ -129,11 +129,15 @@ hipError_t launch_block_fft(const float2* xr, float2* xb, int64_t m, int hop, in
 hipError_t launch_synth(int mode, const SynthArgs& a, int n_items, int n_channels, hipStream_t st);
 // epoch [epoch_start, epoch_start + epoch_len); samples [g_lo, g_hi) of it are computed and
 // written at column (n - col0) of rows of row_len samples
+struct DirectEpochs {                // time-domain scales: epochs handled by one launch
+  int64_t epoch_start[kSegBatch], epoch_len[kSegBatch];
+  int64_t g_lo[kSegBatch], g_hi[kSegBatch];   // samples of the recording to produce
+  int32_t n_channels, pad;
+};
 hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi,
                          const DirectScale* sc, int n_direct, const double* sums, double inv_n,
-                         int64_t n_samples, int n_scales, int64_t epoch_start, int64_t epoch_len,
-                         int64_t g_lo, int64_t g_hi, int64_t col0, int64_t row_len, int n_channels,
-                         hipStream_t st);
+                         int64_t n_samples, int n_scales, const DirectEpochs& eps, int n_epochs,
+                         int64_t col0, int64_t row_len, hipStream_t st);
 hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_t p1_stride,
                               int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,
                               int n_channels, hipStream_t st);

@@ -765,7 +765,8 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
 
 // ---------------------------------------------------------------------------
 // Direct scales: W[n] = sum_j (x[n + (L-1)/2 - j] - mean) psi[j] inside the epoch
-// (convolution.py:68-87 'same' crop; transforms.py:202-204).  grid (ceil(ne/256), n_direct, C)
+// (convolution.py:68-87 'same' crop; transforms.py:202-204).
+// grid (ceil(longest range/256), n_direct, n_epochs * C): up to 16 epochs per launch
 // ---------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, float* __restrict__ out,
@@ -773,13 +774,14 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
                                                 const DirectScale* __restrict__ sc,
                                                 const double* __restrict__ sums, double inv_n,
                                                 int64_t n_samples, int n_scales,
-                                                int64_t epoch_start, int64_t epoch_len, int64_t g_lo,
-                                                int64_t g_hi, int64_t col0, int64_t row_len) {
+                                                const DirectEpochs eps, int64_t col0,
+                                                int64_t row_len) {
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
   const DirectScale p = sc[blockIdx.y];
-  const int c = blockIdx.z;
-  const int64_t gn = g_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;   // sample index in the recording
-  if (gn >= g_hi) return;
+  const int e = blockIdx.z / eps.n_channels, c = blockIdx.z - e * eps.n_channels;
+  const int64_t epoch_start = eps.epoch_start[e], epoch_len = eps.epoch_len[e];
+  const int64_t gn = eps.g_lo[e] + (int64_t)blockIdx.x * 256 + threadIdx.x;   // sample of the recording
+  if (gn >= eps.g_hi[e]) return;
   const int64_t n = gn - epoch_start;                                  // index in the epoch
   const float mean = (float)(sums[c] * inv_n);
   const float* xe = x + (int64_t)c * n_samples + epoch_start;
@@ -1106,14 +1108,15 @@ hipError_t launch_synth(int mode, const SynthArgs& a, int n_items, int n_channel
 
 hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, const DirectScale* sc,
                          int n_direct, const double* sums, double inv_n, int64_t n_samples,
-                         int n_scales, int64_t epoch_start, int64_t epoch_len, int64_t g_lo,
-                         int64_t g_hi, int64_t col0, int64_t row_len, int n_channels,
-                         hipStream_t st) {
-  if (n_direct == 0 || g_hi <= g_lo) return hipSuccess;
-  dim3 grid((unsigned)((g_hi - g_lo + 255) / 256), n_direct, n_channels), block(256);
+                         int n_scales, const DirectEpochs& eps, int n_epochs, int64_t col0,
+                         int64_t row_len, hipStream_t st) {
+  int64_t longest = 0;
+  for (int e = 0; e < n_epochs; ++e) longest = std::max(longest, eps.g_hi[e] - eps.g_lo[e]);
+  if (n_direct == 0 || n_epochs == 0 || longest <= 0) return hipSuccess;
+  dim3 grid((unsigned)((longest + 255) / 256), n_direct, eps.n_channels * n_epochs), block(256);
 #define GCWT_DIRECT(M)                                                                       \
   hipLaunchKernelGGL((k_direct<M>), grid, block, 0, st, x, out, psi, sc, sums, inv_n,        \
-                     n_samples, n_scales, epoch_start, epoch_len, g_lo, g_hi, col0, row_len)
+                     n_samples, n_scales, eps, col0, row_len)
   if (mode == GCWT_OUT_AMPLITUDE_F32) GCWT_DIRECT(GCWT_OUT_AMPLITUDE_F32);
   else if (mode == GCWT_OUT_POWER_F32) GCWT_DIRECT(GCWT_OUT_POWER_F32);
   else GCWT_DIRECT(GCWT_OUT_COMPLEX_C64);
