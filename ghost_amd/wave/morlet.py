@@ -9,7 +9,7 @@ import copy
 
 import numpy as np
 
-from .wavelet import Wavelet
+from .wavelet import Positive, Wavelet
 
 __all__ = ["Morlet"]
 
@@ -43,37 +43,12 @@ class Morlet(Wavelet):
     def copy(self):
         return copy.deepcopy(self)
 
-    @property
-    def fs(self):
-        return self._fs
+    # every parameter is positive and re-samples the wavelet when it changes
+    fs = Positive("Sampling rate must be positive", after="_changed")
+    w0 = Positive("Frequency ratio must be positive", after="_changed")
+    freq = Positive("The wavelet frequency must be positive", after="_changed")
 
-    @fs.setter
-    def fs(self, sample_rate):
-        if sample_rate <= 0:
-            raise ValueError("Sampling rate must be positive")
-        self._fs = sample_rate
-        self._recompute()
-
-    @property
-    def w0(self):
-        return self._w0
-
-    @w0.setter
-    def w0(self, norm_freq):
-        if norm_freq <= 0:
-            raise ValueError("Frequency ratio must be positive")
-        self._w0 = norm_freq
-        self._recompute()
-
-    @property
-    def freq(self):
-        return self._freq
-
-    @freq.setter
-    def freq(self, freq):
-        if freq <= 0:
-            raise ValueError("The wavelet frequency must be positive")
-        self._freq = freq
+    def _changed(self, _value):
         self._recompute()
 
     @property

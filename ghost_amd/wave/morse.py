@@ -9,7 +9,7 @@ import copy
 
 import numpy as np
 
-from .wavelet import Wavelet
+from .wavelet import Positive, Wavelet
 from . import morseutils
 
 __all__ = ["Morse"]
@@ -63,59 +63,21 @@ class Morse(Wavelet):
     def _hz_to_norm_radians(self, val):
         return val / (self._fs / 2) * np.pi
 
-    @property
-    def fs(self):
-        return self._fs
+    # Validated parameters.  The range tests of the reference's frequency setters only ever
+    # reject values <= 0 (morse.py:158, :174), so "positive" is the whole contract.
+    fs = Positive("fs must be positive but got {}")
+    gamma = Positive("gamma must be positive")
+    beta = Positive("beta must be positive")
+    frequency = Positive("The frequency must be between 0 and the Nyquist frequency"
+                         " but got {} (fs = {fs})", after="_peak_from_hz", store="_freq")
+    norm_radian_freq = Positive("The normalized radian frequency must be between 0 and the"
+                                " Nyquist frequency pi but got {}", after="_peak_from_radians")
 
-    @fs.setter
-    def fs(self, val):
-        if not val > 0:
-            raise ValueError("fs must be positive but got {}".format(val))
-        self._fs = val
+    def _peak_from_hz(self, hz):
+        self._norm_radian_freq = self._hz_to_norm_radians(hz)
 
-    @property
-    def frequency(self):
-        return self._freq
-
-    @frequency.setter
-    def frequency(self, val):
-        if not val > 0:          # the reference's range test only ever rejects <= 0 (morse.py:158)
-            raise ValueError("The frequency must be between 0 and the Nyquist frequency {} Hz"
-                             " but got {}".format(self._fs / 2, val))
-        self._freq = val
-        self._norm_radian_freq = self._hz_to_norm_radians(val)
-
-    @property
-    def norm_radian_freq(self):
-        return self._norm_radian_freq
-
-    @norm_radian_freq.setter
-    def norm_radian_freq(self, val):
-        if not val > 0:          # morse.py:174
-            raise ValueError("The normalized radian frequency must be between 0 and the"
-                             " Nyquist frequency pi but got {}".format(val))
-        self._norm_radian_freq = val
-        self._freq = self._norm_radians_to_hz(val)
-
-    @property
-    def gamma(self):
-        return self._gamma
-
-    @gamma.setter
-    def gamma(self, val):
-        if not val > 0:
-            raise ValueError("gamma must be positive")
-        self._gamma = val
-
-    @property
-    def beta(self):
-        return self._beta
-
-    @beta.setter
-    def beta(self, val):
-        if not val > 0:
-            raise ValueError("beta must be positive")
-        self._beta = val
+    def _peak_from_radians(self, omega):
+        self._freq = self._norm_radians_to_hz(omega)
 
     @property
     def time_bandwidth(self):
