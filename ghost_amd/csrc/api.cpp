@@ -446,20 +446,27 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
 
   if (!reuse_means) RUN(ST_MEAN, launch_channel_sum(dx, N, C, p->d_sums, st));
 
-  // samples outside every epoch are zero (transforms.py:185)
+  // samples outside every epoch are zero (transforms.py:185): one launch per gap, or one
+  // fill of the whole result when there are many of them
   {
-    int64_t cursor = r0;
-    std::vector<std::pair<int64_t, int64_t>> eps;
+    std::vector<std::pair<int64_t, int64_t>> eps, gaps;
     for (size_t i = 0; i + 1 < hp.bounds.size(); i += 2) eps.push_back({hp.bounds[i], hp.bounds[i + 1]});
     std::sort(eps.begin(), eps.end());
+    int64_t cursor = r0;
     for (size_t i = 0; i <= eps.size(); ++i) {
       const int64_t gap_end = std::min(r1, i < eps.size() ? eps[i].first : N);
-      if (gap_end > cursor) {
-        he = launch_zero_range(dout, row_len * elem, (int64_t)C * S, (cursor - r0) * elem,
-                               (gap_end - cursor) * elem, st);
+      if (gap_end > cursor) gaps.push_back({cursor, gap_end});
+      if (i < eps.size()) cursor = std::max(cursor, std::min(r1, eps[i].second));
+    }
+    if (gaps.size() > 8) {
+      he = hipMemsetAsync(dout, 0, sizeof(float) * (size_t)elem * (size_t)row_len * (size_t)C * (size_t)S, st);
+      if (he != hipSuccess) return hip_err(he, "zero fill");
+    } else {
+      for (const auto& g : gaps) {
+        he = launch_zero_range(dout, row_len * elem, (int64_t)C * S, (g.first - r0) * elem,
+                               (g.second - g.first) * elem, st);
         if (he != hipSuccess) return hip_err(he, "zero_range");
       }
-      if (i < eps.size()) cursor = std::max(cursor, std::min(r1, eps[i].second));
     }
   }
 
