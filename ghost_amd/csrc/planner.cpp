@@ -206,6 +206,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     for (size_t l = 0; l < hp->levels.size(); ++l) blocks += (int64_t)lead.lv[l].nblk * B;
     const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks);   // X + x_R (< P) + XB, roughly
     int cap = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, budget / std::max<int64_t>(1, per_slot)));
+    cap = (int)std::max<int64_t>(1, std::min<int64_t>(cap, 65535 / C));   // grid.y = segments * channels
     size_t count = 1;
     while (first + count < hp->epochs.size() && (int)count < cap && hp->epochs[first + count].p == lead.p)
       ++count;
