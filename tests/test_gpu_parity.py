@@ -212,6 +212,28 @@ def test_batched_epochs_against_oracle():
     assert (np.abs(pa.execute(x) - np.abs(ref)) / scale).max() < TOL
 
 
+def test_integration_stub_from_the_docs_runs():
+    """INTEGRATION.md shows the ctypes stub a ghost maintainer would add; run exactly that
+    text against the built library."""
+    import os
+    import re
+    from conftest import ROOT
+    from ghost_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, numpy as np.*?)```", text, re.S).group(1)
+    code = code.replace('C.CDLL("libghostcwt.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    from ghost_amd.synthetic import lfp_channel
+    fs, n = 1000.0, 8192
+    x = lfp_channel(n, fs, 3)
+    f = np.array([150.0, 40.0, 12.0])
+    amp = ns["cwt_amplitude"](x, fs, f, [[0, n]])
+    assert amp.dtype == np.float64 and amp.shape == (3, n)
+    ref = np.abs(orc.cwt_complex(x.astype(np.float64), fs, f))
+    assert rel_err(amp, ref).max() < TOL
+
+
 def test_plans_give_their_memory_back():
     """Create / run / close plans of several layouts (host and device results, time blocks,
     the sigtools operators): the device's free memory returns to where it was."""
