@@ -13,6 +13,6 @@ print("waves %.0f  wave_quadcycles %.3g  per-wave cycles %.0f"%(vals['SQ_WAVES']
 for k in ('SQ_WAIT_ANY','SQ_WAIT_INST_ANY','SQ_ACTIVE_INST_ANY','SQ_WAIT_INST_LDS'): print("  %-20s %.1f%%"%(k,100*vals[k]/wc))
 cyc=vals['GRBM_GUI_ACTIVE']/8
 print("gpu cycles %.3g"%cyc)
-print("VALU insts %.3g -> SIMD busy %.1f%%"%(vals['SQ_INSTS_VALU'], 100*vals['SQ_INSTS_VALU']*2/1024/cyc))
+print("VALU insts %.3g -> SIMD busy %.1f%%"%(vals['SQ_INSTS_VALU'], 100*vals["SQ_ACTIVE_INST_VALU"]*4/1024/cyc))
 print("LDS insts %.3g, LDS idx active/CU %.1f%% , bank conflict share %.1f%%"%(vals['SQ_INSTS_LDS'],100*vals['SQ_LDS_IDX_ACTIVE']/256/cyc, 100*vals['SQ_LDS_BANK_CONFLICT']/vals['SQ_LDS_IDX_ACTIVE']))
 print("VMEM rd %.3g wr %.3g SALU %.3g"%(vals['SQ_INSTS_VMEM_RD'],vals['SQ_INSTS_VMEM_WR'],vals['SQ_INSTS_SALU']))
