@@ -565,6 +565,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       a7.xb_cstride = hp.max_xb;
       a7.row_len = row_len;
       a7.n_scales = S;
+      a7.drop_stores = getenv("GHOSTCWT_SYNTH_DROP_STORES") != nullptr;   // tools/stage_times.py ablation
       a7.seg = sout;
       RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, dev.n_items7, slots, st));
     }

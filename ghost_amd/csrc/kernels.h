@@ -95,7 +95,7 @@ struct Synth7Args {
   int64_t xb_cstride;
   int64_t row_len;       // samples per (channel, scale) row of out
   int32_t n_scales;
-  int32_t pad;
+  int32_t drop_stores;   // measurement only: stores get an empty range (kernel time without HBM writes)
   SegOut seg;
 };
 

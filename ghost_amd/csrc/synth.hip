@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   const int64_t n_b = (int64_t)(lv.blk_base + it.blk0) * hop * R;   // first sample of the block group
   const int64_t w_lo = a.seg.w_lo[seg];
   const int64_t w_len = a.seg.w_hi[seg] - w_lo;
-  const unsigned ext_bytes = w_len > 0 ? (unsigned)(w_len * (4 * kElem)) : 0u;
+  const unsigned ext_bytes = w_len > 0 && !a.drop_stores ? (unsigned)(w_len * (4 * kElem)) : 0u;
   float* const out0 = a.out + ((int64_t)ch * a.n_scales * a.row_len + a.seg.seg_col[seg] + w_lo) * kElem;
   const unsigned voff0 = (unsigned)(((int)(n_b - w_lo) + off0) * (4 * kElem));
   const unsigned vstep = (unsigned)(m1step * (4 * kElem));
