@@ -1,0 +1,62 @@
+"""Randomised soak of the whole path against the oracle: many layouts (channels, lengths,
+epochs with gaps, sampling rates, frequency ranges down to large decimations, forced time
+blocks, output modes, block requests).  Prints the worst relative error per case; exits
+non-zero on the first case over the 1e-5 gate.  SOAK_N cases (default 60), SOAK_SEED."""
+import os, sys, time; sys.path.insert(0, '.')
+import numpy as np
+from ghost_amd.engine import CwtPlan
+from oracle import ghost_oracle as orc
+
+TOL = 1e-5
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "7")))
+n_cases = int(os.environ.get("SOAK_N", "60"))
+worst = 0.0
+t_start = time.time()
+for case in range(n_cases):
+    fs = float(rng.choice([200.0, 1000.0, 1250.0, 30000.0]))
+    n_ch = int(rng.integers(1, 4))
+    n = int(rng.choice([17, 500, 4096, 4097, 10000, 33333, 70000, 150000]))
+    x = (rng.standard_normal((n_ch, n)) * rng.uniform(0.1, 50) + rng.uniform(-100, 100, (n_ch, 1))).astype(np.float32)
+    k = int(rng.integers(0, 7))
+    cuts = np.sort(rng.choice(np.arange(1, n), size=min(n - 1, k), replace=False)) if n > 8 else np.array([], int)
+    edges = [0, *cuts.tolist(), n]
+    eb = [[a + int(rng.integers(0, 3)), b] for a, b in zip(edges[:-1], edges[1:]) if b - a > 3 and rng.random() < 0.85]
+    if not eb:
+        eb = [[0, n]]
+    shortest = min(b - a for a, b in eb)
+    lo = max(1e-4 * fs, 10.0 * fs / max(shortest, 20))
+    hi = 0.47 * fs
+    ns = int(rng.integers(1, 9))
+    f = np.sort(np.exp(rng.uniform(np.log(lo), np.log(hi), ns)))[::-1] if lo < hi else np.array([0.4 * fs])
+    output = ["complex", "amplitude", "power"][int(rng.integers(0, 3))]
+    kw = dict(epoch_bounds=eb, output=output)
+    if rng.random() < 0.35:
+        kw["max_fft_log2"] = int(rng.choice([12, 13, 14, 16]))
+    try:
+        p = CwtPlan(n, n_ch, fs, f, **kw)
+    except Exception as e:
+        print("case %2d: plan refused: %s" % (case, str(e)[:90]), flush=True)
+        continue
+    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, np.array(eb)) for c in range(n_ch)])
+    if output == "amplitude":
+        ref = np.abs(ref)
+    elif output == "power":
+        ref = np.abs(ref) ** 2
+    got = p.execute(x)
+    scale = np.abs(ref).max(axis=2, keepdims=True)
+    scale[scale == 0] = 1.0
+    err = float((np.abs(got - ref) / scale).max())
+    a = int(rng.integers(0, n)); ln = int(rng.integers(1, n - a + 1))
+    blk = p.execute_block(x, a, ln)
+    same = np.array_equal(blk, got[:, :, a:a + ln])
+    si = p.scale_info()
+    tol = 2 * TOL if output == "power" else TOL
+    print("case %2d: fs %7.0f ch %d n %6d ep %d scales %d R<=%5d direct %d segs %3d %-9s err %.2e block %s" %
+          (case, fs, n_ch, n, len(eb), f.size, si["decimation"].max(), int((si["method"] == 1).sum()),
+           len(p.segments()), output, err, "ok" if same else "DIFFERS"), flush=True)
+    worst = max(worst, err / (tol / TOL))
+    if err > tol or not same:
+        print("FAILED", dict(fs=fs, n=n, eb=eb, f=f.tolist(), kw=kw))
+        sys.exit(1)
+    p.close()
+print("worst %.2e over %d cases in %.0f s" % (worst, n_cases, time.time() - t_start))
