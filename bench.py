@@ -142,7 +142,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_synth7", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel_ms": round(k_ms, 4),
-                         "algorithmic_bytes": alg_bytes},
+                         "algorithmic_bytes": alg_bytes,
+                         "limited_by": "package power (1.3 of 1.4 kW, sclk ~1.9 GHz with the HBM "
+                                       "writes on: DESIGN.md 5, profiles/r01_power.txt)"},
             "stages_ms": {k: round(float(v), 4) for k, v in stage_ms.items() if k.endswith("_ms")},
             "whole_job_frac_of_hbm_peak": round(world and alg_bytes * args.steps / elapsed / 1e9
                                                 / HBM_PEAK_GBS, 4),
