@@ -234,6 +234,38 @@ def test_integration_stub_from_the_docs_runs():
     assert rel_err(amp, ref).max() < TOL
 
 
+def test_fallback_synthesis_kernel(monkeypatch):
+    """k_synth (16 columns, staged tile) serves the layouts the production kernel does not:
+    block halos above 32 (a long kernel on a short epoch caps the decimation) and levels
+    with more than 256 scales; GHOSTCWT_SYNTH16=1 forces it everywhere."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp
+    fs = 1000.0
+    x = lfp(2, 1500, fs)
+    f = [100.0, 10.0]                                   # L = 1395 on P = 4096: R capped at 16
+    p = CwtPlan(1500, 2, fs, f, output="complex")
+    assert p.scale_info()["halo"].max() > 32
+    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f) for c in range(2)])
+    assert rel_err(p.execute(x), ref).max() < TOL
+    # 300 scales inside one octave -> one level with more than 256 scales
+    x1 = lfp(1, 6000, fs)
+    f2 = np.geomspace(68.0, 36.0, 300)
+    p2 = CwtPlan(6000, 1, fs, f2, output="amplitude")
+    assert len(set(p2.scale_info()["decimation"].tolist())) == 1
+    ref2 = np.abs(orc.cwt_complex(x1[0].astype(np.float64), fs, f2))
+    assert rel_err(p2.execute(x1)[0], ref2).max() < TOL
+    # forced, on a multi-epoch (batched) layout, every output mode
+    monkeypatch.setenv("GHOSTCWT_SYNTH16", "1")
+    xs = lfp(2, 20000, fs)
+    eb = [[i * 2000, i * 2000 + 1900] for i in range(10)]
+    f3 = [150.0, 60.0, 25.0]
+    ref3 = np.stack([orc.cwt_complex(xs[c].astype(np.float64), fs, f3, np.array(eb)) for c in range(2)])
+    for output, want in (("complex", ref3), ("amplitude", np.abs(ref3)), ("power", np.abs(ref3) ** 2)):
+        p3 = CwtPlan(20000, 2, fs, f3, epoch_bounds=eb, output=output)
+        sc = np.abs(want).max(axis=2, keepdims=True)
+        assert (np.abs(p3.execute(xs) - want) / sc).max() < 2 * TOL, output
+
+
 def test_plans_give_their_memory_back():
     """Create / run / close plans of several layouts (host and device results, time blocks,
     the sigtools operators): the device's free memory returns to where it was."""
