@@ -266,6 +266,25 @@ def test_fallback_synthesis_kernel(monkeypatch):
         assert (np.abs(p3.execute(xs) - want) / sc).max() < 2 * TOL, output
 
 
+def test_sixteen_column_build_of_the_production_kernel(monkeypatch):
+    """GHOSTCWT_SYNTH_COLS=16 and GHOSTCWT_SLOW_FFT=1 select the other instantiations
+    (k_synth7<.,16>, radix-2 FFT passes): same gate."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp
+    fs, n = 1000.0, 40000
+    x = lfp(2, n, fs)
+    f = [200.0, 90.0, 30.0, 11.0, 4.0]
+    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f) for c in range(2)])
+    monkeypatch.setenv("GHOSTCWT_SYNTH_COLS", "16")
+    for output, want in (("complex", ref), ("amplitude", np.abs(ref))):
+        p = CwtPlan(n, 2, fs, f, output=output)
+        assert rel_err(p.execute(x), want).max() < TOL
+    monkeypatch.delenv("GHOSTCWT_SYNTH_COLS")
+    monkeypatch.setenv("GHOSTCWT_SLOW_FFT", "1")
+    p = CwtPlan(n, 2, fs, f, output="complex")
+    assert rel_err(p.execute(x), ref).max() < TOL
+
+
 def test_plans_give_their_memory_back():
     """Create / run / close plans of several layouts (host and device results, time blocks,
     the sigtools operators): the device's free memory returns to where it was."""
