@@ -285,6 +285,32 @@ def test_sixteen_column_build_of_the_production_kernel(monkeypatch):
     assert rel_err(p.execute(x), ref).max() < TOL
 
 
+def test_device_resident_output_with_row_pitch():
+    """Device in, device out (what bench.py times), with rows padded to a pitch so that
+    every row starts on a 128-byte boundary although N is odd; the pad is left alone."""
+    from ghost_amd.engine import CwtPlan, DeviceBuffer
+    from ghost_amd.synthetic import lfp
+    fs, n, pitch = 1000.0, 10001, 10016
+    x = lfp(2, n, fs)
+    f = [180.0, 55.0, 14.0]
+    p = CwtPlan(n, 2, fs, f, output="amplitude")
+    want = p.execute(x)
+    p.set_row_pitch(pitch)
+    xb = DeviceBuffer(x.nbytes); xb.upload(x)
+    ob = DeviceBuffer(2 * 3 * pitch * 4)
+    ob.upload(np.full((2, 3, pitch), -7.0, np.float32))
+    p.execute_device(xb, ob)
+    got = ob.download((2, 3, pitch), np.float32)
+    np.testing.assert_array_equal(got[:, :, :n], want)
+    assert np.all(got[:, :, n:] == -7.0)
+    p.set_row_pitch(0)                                   # dense rows again
+    ob2 = DeviceBuffer(2 * 3 * n * 4)
+    p.execute_device(xb, ob2)
+    np.testing.assert_array_equal(ob2.download((2, 3, n), np.float32), want)
+    with pytest.raises(Exception):
+        p.set_row_pitch(100); p.execute_device(xb, ob)   # pitch shorter than the rows
+
+
 def test_plans_give_their_memory_back():
     """Create / run / close plans of several layouts (host and device results, time blocks,
     the sigtools operators): the device's free memory returns to where it was."""
