@@ -5,6 +5,9 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
@@ -61,6 +64,21 @@ Rccl& rccl() {
   return r;
 }
 
+// RCCL prints a version banner on stdout when it initialises.  A benchmark's stdout is
+// its result line, so anything RCCL says during set-up is sent to stderr instead.
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() {
+    fflush(stdout);
+    saved = dup(STDOUT_FILENO);
+    if (saved >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
+  }
+  ~StdoutToStderr() {
+    fflush(stdout);
+    if (saved >= 0) { dup2(saved, STDOUT_FILENO); close(saved); }
+  }
+};
+
 }  // namespace
 
 struct gcwt_comm {
@@ -90,7 +108,11 @@ int gcwt_comm_unique_id(void* id128) {
   Rccl& r = rccl();
   if (!r.ok) return cerr_(GCWT_ERR_COMM, "librccl not found or incomplete");
   ncclUniqueId id;
-  ncclResult_t rc = r.GetUniqueId(&id);
+  ncclResult_t rc;
+  {
+    StdoutToStderr quiet;
+    rc = r.GetUniqueId(&id);
+  }
   if (rc != 0) return nccl_fail("ncclGetUniqueId", rc);
   static_assert(sizeof(ncclUniqueId) == GCWT_COMM_ID_BYTES, "unique id size");
   memcpy(id128, &id, sizeof(id));
@@ -109,7 +131,11 @@ int gcwt_comm_create(gcwt_comm** out, int rank, int n_ranks, const void* id128) 
   c->n_ranks = n_ranks;
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
-  ncclResult_t rc = r.CommInitRank(&c->comm, n_ranks, id, rank);
+  ncclResult_t rc;
+  {
+    StdoutToStderr quiet;
+    rc = r.CommInitRank(&c->comm, n_ranks, id, rank);
+  }
   if (rc != 0) { delete c; return nccl_fail("ncclCommInitRank", rc); }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void**)&c->d_val, sizeof(double)) != hipSuccess) {
