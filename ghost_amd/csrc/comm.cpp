@@ -139,7 +139,7 @@ int gcwt_comm_create(gcwt_comm** out, int rank, int n_ranks, const void* id128) 
   if (rc != 0) { delete c; return nccl_fail("ncclCommInitRank", rc); }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void**)&c->d_val, sizeof(double)) != hipSuccess) {
-    r.CommDestroy(c->comm);
+    { StdoutToStderr quiet; r.CommDestroy(c->comm); }
     delete c;
     return cerr_(GCWT_ERR_HIP, "communicator scratch allocation failed");
   }
@@ -151,7 +151,7 @@ void gcwt_comm_destroy(gcwt_comm* c) {
   if (!c) return;
   if (c->d_val) (void)hipFree(c->d_val);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->comm) rccl().CommDestroy(c->comm);
+  if (c->comm) { StdoutToStderr quiet; rccl().CommDestroy(c->comm); }
   delete c;
 }
 
@@ -159,7 +159,11 @@ int gcwt_comm_allreduce_max(gcwt_comm* c, double* value) {
   if (!c || !value) return cerr_(GCWT_ERR_INVALID, "NULL argument");
   if (hipMemcpyAsync(c->d_val, value, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess)
     return cerr_(GCWT_ERR_HIP, "copy to device failed");
-  ncclResult_t rc = rccl().AllReduce(c->d_val, c->d_val, 1, kNcclFloat64, kNcclMax, c->comm, c->stream);
+  ncclResult_t rc;
+  {
+    StdoutToStderr quiet;
+    rc = rccl().AllReduce(c->d_val, c->d_val, 1, kNcclFloat64, kNcclMax, c->comm, c->stream);
+  }
   if (rc != 0) return nccl_fail("ncclAllReduce", rc);
   if (hipMemcpyAsync(value, c->d_val, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize(c->stream) != hipSuccess)
@@ -179,7 +183,11 @@ int gcwt_comm_broadcast_bank(gcwt_comm* c, gcwt_plan* plan, int root) {
   size_t bytes = 0;
   float2* bank = gcwt_internal_bank_ptr(plan, &bytes);
   hipStream_t st = gcwt_internal_stream(plan);
-  ncclResult_t nr = rccl().Broadcast(bank, bank, bytes, kNcclUint8, root, c->comm, st);
+  ncclResult_t nr;
+  {
+    StdoutToStderr quiet;
+    nr = rccl().Broadcast(bank, bank, bytes, kNcclUint8, root, c->comm, st);
+  }
   if (nr != 0) return nccl_fail("ncclBroadcast", nr);
   if ((rc = gcwt_internal_refresh_bank(plan))) return rc;   // |H| table follows the bank
   if (hipStreamSynchronize(st) != hipSuccess) return cerr_(GCWT_ERR_HIP, "broadcast did not complete");
