@@ -9,14 +9,14 @@ import os
 
 __all__ = ["lib", "GhostCwtError", "check", "Params", "PlanInfo", "Timings", "LIB_PATH",
            "OUT_AMPLITUDE", "OUT_POWER", "OUT_COMPLEX", "X_ON_DEVICE", "OUT_ON_DEVICE", "OUT_F64",
-           "SCALE_SPECTRAL", "SCALE_DIRECT", "ERR_INVALID", "ERR_UNSUPPORTED", "ERR_NO_DEVICE"]
+           "SCALE_SPECTRAL", "SCALE_DIRECT", "SCALE_FULLBAND", "ERR_INVALID", "ERR_UNSUPPORTED", "ERR_NO_DEVICE"]
 
 LIB_PATH = os.environ.get("GHOSTCWT_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "libghostcwt.so")
 
 OUT_AMPLITUDE, OUT_POWER, OUT_COMPLEX = 0, 1, 2
 X_ON_DEVICE, OUT_ON_DEVICE, REUSE_MEANS, OUT_F64 = 1, 2, 4, 8
-SCALE_SPECTRAL, SCALE_DIRECT = 0, 1
+SCALE_SPECTRAL, SCALE_DIRECT, SCALE_FULLBAND = 0, 1, 2
 ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_COMM = -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
 
@@ -40,13 +40,13 @@ class PlanInfo(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("n_levels", C.c_int32), ("n_spectral", C.c_int32),
                 ("n_direct", C.c_int32), ("block", C.c_int32), ("max_decimation", C.c_int32),
                 ("fft_length", C.c_int64), ("workspace_bytes", C.c_int64),
-                ("out_bytes", C.c_int64)]
+                ("out_bytes", C.c_int64), ("n_fullband", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Timings(C.Structure):
     _fields_ = [("mean_ms", C.c_float), ("fwd_fft_ms", C.c_float), ("decimate_ms", C.c_float),
                 ("block_fft_ms", C.c_float), ("synth_ms", C.c_float), ("direct_ms", C.c_float),
-                ("total_ms", C.c_float), ("synth_launches", C.c_int32), ("reserved", C.c_int32)]
+                ("total_ms", C.c_float), ("synth_launches", C.c_int32), ("fullband_ms", C.c_float)]
 
 
 def _load():
@@ -73,6 +73,7 @@ def _load():
         "gcwt_plan_destroy": (None, [vp]),
         "gcwt_plan_get_info": (C.c_int, [vp, C.POINTER(PlanInfo)]),
         "gcwt_plan_scale_info": (C.c_int, [vp, i32p, i32p, i32p, i32p, i64p]),
+        "gcwt_plan_scale_support": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i32p]),
         "gcwt_plan_set_profiling": (C.c_int, [vp, C.c_int]),
         "gcwt_plan_set_row_pitch": (C.c_int, [vp, C.c_int64]),
         "gcwt_plan_upload": (C.c_int, [vp]),
@@ -93,6 +94,7 @@ def _load():
         "gcwt_debug_level_count": (C.c_int, [vp]),
         "gcwt_debug_batch_of": (C.c_int, [vp, C.c_int, i32p, i32p]),
         "gcwt_debug_level_info": (C.c_int, [vp, C.c_int, C.c_int, i32p, i32p, i32p, i32p, i64p]),
+        "gcwt_debug_exact_gain": (C.c_int, [vp, C.c_int, i64p, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
         "gcwt_debug_fetch": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int64]),
     }
     for name, (res, args) in sig.items():

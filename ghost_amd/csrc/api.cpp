@@ -15,6 +15,7 @@
 #include "../../include/ghostcwt_debug.h"
 #include "host_out.h"
 #include "kernels.h"
+#include "morse_exact.h"
 #include "planner.h"
 
 using namespace gcwt;
@@ -62,7 +63,7 @@ struct EpochDev {
   int n_items7 = 0;
 };
 
-enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_COUNT };
+enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_FULLBAND, ST_COUNT };
 
 }  // namespace
 
@@ -82,6 +83,9 @@ struct gcwt_plan {
   float* d_gain = nullptr;    // [S][B] |H|
   float2* d_half_tw = nullptr; // [levels][256] exp(-i pi k/(256 R))
   float2* d_psi = nullptr;    // direct kernels
+  double* d_amps = nullptr;   // kept spectrum samples A_j of every scale (planner.h: amps)
+  float2* d_z = nullptr;      // [C][max_p]   full-band scales: spectrum * response, then its IFFT
+  float2* d_hfull = nullptr;  // [max_p]      full-band response of the scale in hand
   float2* d_tw4096 = nullptr; // exp(-2 pi i j/4096), j < 2048
   float2* d_tw256 = nullptr;  // exp(+2 pi i q/256)
   float2* d_level_tw = nullptr;
@@ -127,7 +131,7 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
-  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_bank); fr(p->d_gain); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
+  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
@@ -259,7 +263,9 @@ int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info) {
   info->abi_version = GCWT_ABI_VERSION;
   info->n_levels = (int32_t)hp.levels.size();
   info->n_direct = hp.n_direct;
-  info->n_spectral = (int32_t)hp.scales.size() - hp.n_direct;
+  info->n_spectral = (int32_t)hp.scales.size() - hp.n_direct - hp.n_fullband;
+  info->n_fullband = hp.n_fullband;
+  info->reserved = 0;
   info->block = hp.block;
   int r = 1;
   for (const auto& l : hp.levels) r = std::max(r, l.decimation);
@@ -281,6 +287,18 @@ int gcwt_plan_scale_info(const gcwt_plan* plan, int32_t* method, int32_t* decima
     if (halo) halo[i] = s.level >= 0 ? hp.levels[s.level].halo : 0;
     if (hop) hop[i] = s.level >= 0 ? hp.levels[s.level].hop : 0;
     if (length) length[i] = s.length;
+  }
+  return GCWT_OK;
+}
+
+int gcwt_plan_scale_support(const gcwt_plan* plan, double* theta_hi, double* support, int32_t* n_bins) {
+  if (!plan) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  const HostPlan& hp = plan->hp;
+  for (size_t i = 0; i < hp.scales.size(); ++i) {
+    const ScalePlan& s = hp.scales[i];
+    if (theta_hi) theta_hi[i] = s.theta_hi;
+    if (support) support[i] = s.support;
+    if (n_bins) n_bins[i] = s.n_bins;
   }
   return GCWT_OK;
 }
@@ -312,14 +330,19 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   auto bail = [&](int code) { free_dev(p); return code; };
 
-  const bool any_spectral = hp.n_direct < S;
-  if (any_spectral) {
+  const bool any_fft = hp.n_direct < S;   // spectral or full-band scales: they share X
+  if (any_fft) {
     // one workspace slot per (segment of a batch, channel)
     const int64_t slots = C * hp.max_batch;
     if ((rc = dev_alloc(&p->d_x, (size_t)(slots * hp.max_p)))) return bail(rc);
     if ((rc = dev_alloc(&p->d_xr, (size_t)(slots * hp.max_xr)))) return bail(rc);
     if ((rc = dev_alloc(&p->d_xb, (size_t)(slots * hp.max_xb)))) return bail(rc);
+    if (hp.n_fullband > 0) {
+      if ((rc = dev_alloc(&p->d_z, (size_t)(slots * hp.max_p)))) return bail(rc);
+      if ((rc = dev_alloc(&p->d_hfull, (size_t)hp.max_p))) return bail(rc);
+    }
   }
+  if ((rc = upload_vec(&p->d_amps, hp.amps, p->stream))) return bail(rc);
   if ((rc = dev_alloc(&p->d_bank, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_gain, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_psi, (size_t)hp.direct_total))) return bail(rc);
@@ -350,7 +373,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   std::vector<DirectScale> dsc(hp.n_direct);
   for (int i = 0; i < S; ++i) {
     const ScalePlan& s = hp.scales[i];
-    bsc[i] = {s.omega, s.half_delay, s.decimation, s.method == GCWT_SCALE_SPECTRAL ? 1 : 0};
+    bsc[i] = {s.omega, s.half_delay, s.length, s.amp_offset, s.bin_lo, s.n_bins, s.decimation,
+              s.method == GCWT_SCALE_SPECTRAL ? 1 : 0};
     if (s.method == GCWT_SCALE_DIRECT)
       dsc[s.direct_index] = {s.omega, s.length, banker_round_half(s.length), s.direct_offset, i, 0};
   }
@@ -408,11 +432,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     if ((rc = upload_vec(&p->ep_dev[e].levels7, lv7, p->stream))) return bail(rc);
   }
 
-  hipError_t he = launch_build_bank(p->d_bank, p->d_bank_sc, S, B, hp.prm.gamma, hp.prm.beta, hp.w0,
-                                    p->stream);
+  hipError_t he = launch_build_bank(p->d_bank, p->d_gain, p->d_bank_sc, p->d_amps, S, B, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_bank"));
-  he = launch_bank_gain(p->d_bank, p->d_gain, S, p->stream);
-  if (he != hipSuccess) return bail(hip_err(he, "bank_gain"));
   he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, hp.prm.gamma,
                            hp.prm.beta, hp.w0, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_direct"));
@@ -470,9 +491,9 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     }
   }
 
-  const bool any_spectral = hp.n_direct < S;
+  const bool any_fft = hp.n_direct < S;
   const bool fast_fft = !getenv("GHOSTCWT_SLOW_FFT");
-  for (size_t e0 = 0; any_spectral && e0 < hp.epochs.size();) {
+  for (size_t e0 = 0; any_fft && e0 < hp.epochs.size();) {
     // one batch: segments e0 .. e0 + count - 1 share the FFT length and the level grids;
     // those with something to write in [r0, r1) become extra sets of "channels"
     const EpochPlan& ep = hp.epochs[e0];
@@ -501,7 +522,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     const int P1 = ep.p1;
     // The input is real, so rows k1 and P1 - k1 of the k1-major spectrum mirror each other:
     // the fast path builds rows 0 .. P1/2 only and writes the rest as their reflections.
-    const bool hermitian = fast_fft && P1 >= 4;
+    // Full-band scales read every bin, so a plan that has any builds the whole spectrum.
+    const bool hermitian = fast_fft && P1 >= 4 && hp.n_fullband == 0;
     const int rows_a = hermitian ? P1 / 2 + 1 : P1;
     // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
     RUN(ST_FWD, launch_fft_cols_batch(dx, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0, p->d_tw4096,
@@ -510,7 +532,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     // pass B: rows over n2 -> X~[k1][k2] = X[k1 + P1 k2]; only X[k < P/2] is ever read
     RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, rows_a, kRowLen, kRowLen, P, P, 0,
                                 p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, st,
-                                kRowLen / 2, hermitian ? P1 : 0));
+                                hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0));
     for (size_t l = 0; l < hp.levels.size(); ++l) {
       const LevelPlan& lp = hp.levels[l];
       const EpochLevel& el = ep.lv[l];
@@ -536,7 +558,9 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
                                      el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, slots, st));
     }
     const EpochDev& dev = p->ep_dev[ep.batch_first];
-    if (p->use_synth16 || !hp.halo_static) {
+    if (hp.levels.empty()) {
+      // full-band scales only: no decimated levels to synthesise
+    } else if (p->use_synth16 || !hp.halo_static) {
       SynthArgs a{};
       a.xb = p->d_xb;
       a.bank = p->d_bank;
@@ -569,7 +593,20 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       a7.seg = sout;
       RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, dev.n_items7, slots, st));
     }
-    if (p->profiling) p->last.synth_launches++;
+    if (p->profiling && !hp.levels.empty()) p->last.synth_launches++;
+    // full-band scales: W = IFFT_P(X H_s), one scale at a time for every slot of the batch
+    for (int i = 0; i < S && hp.n_fullband > 0; ++i) {
+      if (hp.scales[i].method != GCWT_SCALE_FULLBAND) continue;
+      RUN(ST_FULLBAND, launch_fullband_filter(p->d_hfull, p->d_bank_sc, i, p->d_amps, P1, st));
+      RUN(ST_FULLBAND, launch_fullband_mul(p->d_x, p->d_hfull, p->d_z, P, slots, st));
+      // inverse: rows over k2 with the W_P^(k1 n2) twiddle, then columns over k1 -> natural order
+      RUN(ST_FULLBAND, launch_fft_rows(+1, p->d_z, p->d_z, kRowLen, P1, kRowLen, kRowLen, P, P,
+                                       P1 > 1 ? P : 0, p->d_tw4096, p->d_tw256, 1.0f, slots, st));
+      if (P1 > 1)
+        RUN(ST_FULLBAND, launch_fft_cols(+1, false, p->d_z, p->d_z, P1, kRowLen, P, P, 0, p->d_tw4096,
+                                         p->d_tw256, p->d_sums, inv_n, 0, slots, st));
+      RUN(ST_FULLBAND, launch_fullband_store(mode, p->d_z, dout, P, i, S, row_len, sout, nb, st));
+    }
   }
   if (hp.n_direct > 0) {
     DirectEpochs eps{};
@@ -590,7 +627,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       eps.epoch_len[ne] = e1 - e0;
       eps.g_lo[ne] = g_lo;
       eps.g_hi[ne] = g_hi;
-      if (++ne == kSegBatch) { int rc_ = flush(); if (rc_) return rc_; }
+      // grid.z = epochs * channels of one launch stays within 65535
+      if (++ne == kSegBatch || (int64_t)(ne + 1) * C > 65535) { int rc_ = flush(); if (rc_) return rc_; }
     }
     int rc_ = flush();
     if (rc_) return rc_;
@@ -685,6 +723,7 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
     p->last.block_fft_ms = acc[ST_BLOCK];
     p->last.synth_ms = acc[ST_SYNTH];
     p->last.direct_ms = acc[ST_DIRECT];
+    p->last.fullband_ms = acc[ST_FULLBAND];
     p->have_timings = true;
   }
   return GCWT_OK;
@@ -880,6 +919,16 @@ int gcwt_debug_batch_of(const gcwt_plan* p, int segment, int32_t* first, int32_t
   return GCWT_OK;
 }
 
+int gcwt_debug_exact_gain(const gcwt_plan* p, int scale, const int64_t* a, int64_t b, int64_t n,
+                          double* gain) {
+  if (!p || !a || !gain || b <= 0) return set_err(GCWT_ERR_INVALID, "bad argument");
+  if (scale < 0 || scale >= (int)p->hp.scales.size()) return set_err(GCWT_ERR_INVALID, "scale out of range");
+  const ScalePlan& s = p->hp.scales[scale];
+  for (int64_t i = 0; i < n; ++i)
+    gain[i] = exact_gain(p->hp.amps.data() + s.amp_offset, s.bin_lo, s.n_bins, s.length, a[i], b);
+  return GCWT_OK;
+}
+
 int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, float* dst,
                      int64_t max_complex) {
   if (!p || !dst) return set_err(GCWT_ERR_INVALID, "NULL argument");
@@ -916,7 +965,7 @@ int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, 
 
 // accessors for comm.cpp
 int gcwt_internal_refresh_bank(gcwt_plan* p) {   // derived tables follow a (broadcast) bank
-  hipError_t he = launch_bank_gain(p->d_bank, p->d_gain, p->hp.prm.n_freqs, p->stream);
+  hipError_t he = launch_bank_gain(p->d_bank, p->d_gain, p->d_bank_sc, p->hp.prm.n_freqs, p->stream);
   if (he != hipSuccess) return hip_err(he, "bank_gain");
   return GCWT_OK;
 }

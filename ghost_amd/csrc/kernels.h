@@ -14,6 +14,9 @@ constexpr int kRowLenDev = 4096;
 struct BankScale {
   double omega;
   double half_delay;
+  int64_t length;      // L of the reference kernel (morse.py:108-122)
+  int64_t amp_offset;  // kept spectrum samples A_j: amps[amp_offset .. + n_bins), bins bin_lo ..
+  int32_t bin_lo, n_bins;
   int32_t decimation;
   int32_t spectral;
 };
@@ -104,9 +107,19 @@ hipError_t launch_synth7(int mode, int ncol, const Synth7Args& a, int n_items, i
 
 hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,
                               hipStream_t st);
-hipError_t launch_build_bank(float2* bank, const BankScale* sc, int n_scales, int B, double gamma,
-                             double beta, double w0, hipStream_t st);
-hipError_t launch_bank_gain(const float2* bank, float* gain, int n_scales, hipStream_t st);
+hipError_t launch_build_bank(float2* bank, float* gain, const BankScale* sc, const double* amps,
+                             int n_scales, int B, hipStream_t st);
+hipError_t launch_bank_gain(const float2* bank, float* gain, const BankScale* sc, int n_scales,
+                            hipStream_t st);
+// full-band scales (exact.hip): H[k] / P on the k1-major grid of a P-point spectrum, the
+// product with a batch of spectra, and the crop / |.| / store of the inverse transform
+hipError_t launch_fullband_filter(float2* h, const BankScale* sc, int scale, const double* amps,
+                                  int p1, hipStream_t st);
+hipError_t launch_fullband_mul(const float2* x, const float2* h, float2* z, int64_t p, int n_slots,
+                               hipStream_t st);
+hipError_t launch_fullband_store(int mode, const float2* y, float* out, int64_t p, int scale,
+                                 int n_scales, int64_t row_len, const SegOut& seg, int n_segments,
+                                 hipStream_t st);
 hipError_t launch_build_direct(float2* psi, const DirectScale* sc, int n_direct, int64_t max_len,
                                double gamma, double beta, double w0, hipStream_t st);
 hipError_t launch_fft_cols(int sign, bool real_in, const void* in, float2* out, int len, int ld,

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "morse_exact.h"
 
 namespace gcwt {
 
@@ -150,35 +151,44 @@ __global__ void __launch_bounds__(256) k_channel_sum(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------
-// filter bank: H[s][k] = 2 exp(-b ln w0 + w0^g + b ln w - w^g) exp(-i theta d)
-//   theta = 2 pi k / (B R_s), w = theta w0 / omega_s   (morseutils.py:116-117, 130-131)
+// filter bank: H[s][k] = G_s(theta) exp(-i theta d),  theta = 2 pi k / (B R_s), where G_s
+// is the exact (real) response of the L-tap kernel the reference convolves with
+// (morse_exact.h; morseutils.py:117-149 + convolution.py:68-87) and d the half-sample
+// delay of even L.  gain[s][k] = G_s(theta), signed.
 // grid (S), block (B)
 // ---------------------------------------------------------------------------
-__global__ void k_build_bank(cf* __restrict__ bank, const BankScale* __restrict__ sc, int B,
-                             double gamma, double beta, double w0) {
+__global__ void k_build_bank(cf* __restrict__ bank, float* __restrict__ gain,
+                             const BankScale* __restrict__ sc, const double* __restrict__ amps,
+                             int B) {
   const int s = blockIdx.x;
   const int k = threadIdx.x;
   const BankScale p = sc[s];
   cf h = make_float2(0.f, 0.f);
-  if (p.spectral && k > 0) {
-    const double theta = 2.0 * M_PI * (double)k / ((double)B * (double)p.decimation);
-    const double w = theta * (w0 / p.omega);
-    const double ln = -beta * log(w0) + pow(w0, gamma) + beta * log(w) - pow(w, gamma);
-    const double amp = 2.0 * exp(ln);
+  float g = 0.f;
+  if (p.spectral) {
+    const int64_t b = (int64_t)B * p.decimation;
+    const double gd = exact_gain(amps + p.amp_offset, p.bin_lo, p.n_bins, p.length, k, b);
     double sn, cs;
-    sincos(-theta * p.half_delay, &sn, &cs);
-    h = make_float2((float)(amp * cs), (float)(amp * sn));
+    sincospi(-2.0 * (double)k / (double)b * p.half_delay, &sn, &cs);
+    h = make_float2((float)(gd * cs), (float)(gd * sn));
+    g = (float)gd;
   }
   bank[(int64_t)s * B + k] = h;
+  gain[(int64_t)s * B + k] = g;
 }
 
-// gain[s][k] = |H_s[k]|: the production synthesis kernel multiplies by the real gain and
-// folds the half-sample phase of even-length kernels into its persistent operand.
+// gain[s][k] = G_s = H_s[k] exp(+i theta d) (real) from a bank that arrived by broadcast:
+// the production synthesis kernel multiplies by the real gain and folds the half-sample
+// phase of even-length kernels into its persistent operand.
 // grid (S), block (256)
-__global__ void k_bank_gain(const cf* __restrict__ bank, float* __restrict__ gain) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const cf h = bank[i];
-  gain[i] = sqrtf(h.x * h.x + h.y * h.y);
+__global__ void k_bank_gain(const cf* __restrict__ bank, float* __restrict__ gain,
+                            const BankScale* __restrict__ sc) {
+  const int s = blockIdx.x, k = threadIdx.x;
+  const BankScale p = sc[s];
+  const cf h = bank[(int64_t)s * 256 + k];
+  float sn, cs;
+  sincospif((float)(2.0 * (double)k / (256.0 * (double)p.decimation) * p.half_delay), &sn, &cs);
+  gain[(int64_t)s * 256 + k] = h.x * cs - h.y * sn;
 }
 
 // ---------------------------------------------------------------------------
@@ -953,15 +963,16 @@ hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double*
   return hipSuccess;
 }
 
-hipError_t launch_build_bank(cf* bank, const BankScale* sc, int n_scales, int B, double gamma,
-                             double beta, double w0, hipStream_t st) {
-  hipLaunchKernelGGL(k_build_bank, dim3(n_scales), dim3(B), 0, st, bank, sc, B, gamma, beta, w0);
+hipError_t launch_build_bank(cf* bank, float* gain, const BankScale* sc, const double* amps,
+                             int n_scales, int B, hipStream_t st) {
+  hipLaunchKernelGGL(k_build_bank, dim3(n_scales), dim3(B), 0, st, bank, gain, sc, amps, B);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }
 
-hipError_t launch_bank_gain(const cf* bank, float* gain, int n_scales, hipStream_t st) {
-  hipLaunchKernelGGL(k_bank_gain, dim3(n_scales), dim3(256), 0, st, bank, gain);
+hipError_t launch_bank_gain(const cf* bank, float* gain, const BankScale* sc, int n_scales,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(k_bank_gain, dim3(n_scales), dim3(256), 0, st, bank, gain, sc);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

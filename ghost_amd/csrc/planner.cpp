@@ -1,5 +1,6 @@
 // planner.cpp -- see planner.h
 #include "planner.h"
+#include "morse_exact.h"
 
 #include <algorithm>
 #include <climits>
@@ -29,6 +30,95 @@ static void band_edges(double gamma, double beta, double eps, double* u_lo, doub
   *u_hi = hi;
 }
 
+// Bins of the reference's L-point spectrum grid that matter: A_j above 1e-18 of the peak,
+// among the kept bins 1 .. round(L/2)-1 (morseutils.py:178; Python's round: half to even).
+static int64_t round_half_even_half(int64_t L) {   // round(L / 2)
+  if (L % 2 == 0) return L / 2;
+  const int64_t lo = L / 2;
+  return (lo % 2 == 0) ? lo : lo + 1;
+}
+
+static void scale_bins(const HostPlan& hp, ScalePlan* sp, std::vector<double>* amp) {
+  const int64_t L = sp->length, K = round_half_even_half(L);
+  const double per_u = sp->omega * (double)L / (2.0 * M_PI);   // bins per unit of u = theta/omega
+  int64_t lo = std::max<int64_t>(1, (int64_t)std::floor(hp.u_lo * per_u));
+  int64_t hi = std::min<int64_t>(K - 1, (int64_t)std::ceil(hp.u_hi * per_u));
+  amp->clear();
+  sp->bin_lo = (int32_t)lo;
+  for (int64_t j = lo; j <= hi; ++j)
+    amp->push_back(morse_amplitude(2.0 * M_PI * (double)j / (double)L, sp->omega, hp.prm.gamma,
+                                   hp.prm.beta, hp.w0));
+  sp->n_bins = (int32_t)amp->size();
+}
+
+// Measures, on the exact response G of the reference's kernel (morse_exact.h):
+//  * theta_hi: above it (and all the way round to 2 pi, i.e. through the negative
+//    frequencies) |G| stays below band_tol of the peak.  G is probed where its side lobes
+//    peak, half-way between grid bins: every half-bin of the upper skirt, then geometric
+//    steps out to Nyquist and, from the other end, out from just below 2 pi -- the side
+//    lobes of the L-tap truncation decay like 1/|theta - band|, smoothly, on both sides.
+//  * support: the distance from the kernel's centre beyond which less than support_tol of
+//    its energy (L2) lies.  |psi| is the envelope of an analytic signal, so it is smooth
+//    and sampled on a coarse grid from the kernel's end inwards.
+static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) {
+  const int64_t L = sp->length;
+  const int32_t nb = sp->n_bins, j0 = sp->bin_lo;
+  sp->band_ok = false;
+  sp->theta_hi = 2.0 * M_PI;
+  sp->support = 0.5 * (double)L;
+  if (nb == 0) return;
+  double pk = 0.0, energy = 0.0;
+  int32_t i_pk = 0;
+  for (int32_t i = 0; i < nb; ++i) {
+    if (amp[i] > pk) { pk = amp[i]; i_pk = i; }
+    energy += amp[i] * amp[i];
+  }
+  const double lim = hp.band_tol * pk;
+  auto env = [&](int64_t m) {   // |G| at half-bin m + 1/2: theta = 2 pi (2m + 1) / (2 L)
+    return std::fabs(exact_gain(amp, j0, nb, L, 2 * m + 1, 2 * L));
+  };
+  // highest probed half-bin with |G| above the limit
+  int64_t top = -1;
+  const int64_t m_pk = j0 + i_pk, m_skirt = std::min<int64_t>(L - 1, (int64_t)j0 + nb + 2);
+  for (int64_t m = m_pk; m <= m_skirt; ++m)
+    if (env(m) > lim) top = m;
+  // from the skirt up to Nyquist and from just below 2 pi down to Nyquist, geometric
+  for (int side = 0; side < 2 && m_skirt < L - 1; ++side) {
+    double step = 1.0;
+    for (double off = 1.0; ; off += step, step *= 1.12) {
+      const int64_t o = (int64_t)off;
+      const int64_t m = side == 0 ? m_skirt + o : L - o;
+      if (side == 0 && m > L / 2) break;
+      if (side == 1 && (m <= L / 2 || m <= m_skirt)) break;
+      if (env(m) > lim) top = std::max(top, m);
+    }
+  }
+  sp->theta_hi = 2.0 * M_PI * (double)(top + 1) / (double)L;
+  sp->band_ok = sp->theta_hi <= M_PI;
+
+  // |psi(centre + t)|^2 = |(1/L) sum_j A_j e^{i theta_j t}|^2, same on both sides (A real);
+  // total energy (1/L) sum A_j^2 (Parseval).  Walk in from t = L/2 until the tails hold
+  // support_tol^2 of it.
+  const int kProbes = 48;
+  const double h = 0.25 * (double)L / kProbes, total = energy / (double)L;
+  double tail = 0.0;
+  sp->support = 0.25 * (double)L;
+  for (int q = 0; q < kProbes; ++q) {
+    const double t = 0.5 * (double)L - ((double)q + 0.5) * h;
+    double re = 0.0, im = 0.0;
+    for (int32_t i = 0; i < nb; ++i) {
+      const double ph = 2.0 * M_PI * std::fmod((double)(j0 + i) * t / (double)L, 1.0);
+      re += amp[i] * std::cos(ph);
+      im += amp[i] * std::sin(ph);
+    }
+    tail += 2.0 * h * (re * re + im * im) / ((double)L * (double)L);
+    if (tail > hp.support_tol * hp.support_tol * total) {
+      sp->support = std::min(0.5 * (double)L, t + 0.5 * h);
+      break;
+    }
+  }
+}
+
 static int64_t next_pow2(int64_t v) {
   int64_t p = 1;
   while (p < v) p <<= 1;
@@ -51,8 +141,9 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
 
   hp->prm = prm;
   hp->block = 256;
-  hp->band_eps = prm.band_eps > 0 ? prm.band_eps : 1e-9;
-  if (hp->band_eps > 1e-3) return fail(GCWT_ERR_INVALID, "band_eps too large");
+  hp->band_tol = prm.band_eps > 0 ? prm.band_eps : 2e-7;
+  if (hp->band_tol > 1e-3) return fail(GCWT_ERR_INVALID, "band_eps too large");
+  if (const char* e = getenv("GHOSTCWT_SUPPORT_TOL")) hp->support_tol = atof(e);
   hp->freqs.assign(prm.freqs_hz, prm.freqs_hz + prm.n_freqs);
   hp->out_elem_bytes = prm.out_mode == GCWT_OUT_COMPLEX_C64 ? 8 : 4;
 
@@ -72,11 +163,20 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   const double g = prm.gamma, b = prm.beta;
   hp->w0 = std::exp((std::log(b) - std::log(g)) / g);                 // morseutils.py:315
   hp->base_length = (2.0 * std::sqrt(2.0) * std::sqrt(g * b)) / hp->w0 * 4.0;  // morse.py:115
-  band_edges(g, b, hp->band_eps, &hp->u_lo, &hp->u_hi);
+  band_edges(g, b, 1e-18, &hp->u_lo, &hp->u_hi);
 
+  // Per scale: the reference's kernel length, its kept spectrum samples, and what the
+  // exact response of that kernel allows (analyse_scale).  A scale is
+  //   SPECTRAL  when its response is below band_tol on [theta_hi, 2 pi) with
+  //             theta_hi <= pi -- the band fits a decimation R >= 2 -- and its support
+  //             fits the 256-sample decimated block;
+  //   DIRECT    otherwise, when the kernel is short (the top of the default grid, where
+  //             the filter reaches Nyquist: L <= 52 for gamma, beta = 3, 20);
+  //   FULLBAND  otherwise: one FFT convolution over the whole band -- wavelets whose
+  //             L-tap truncation leaks everywhere (small beta), any length.
   const int B = hp->block;
   hp->scales.resize(prm.n_freqs);
-  int64_t lmax_spec = 1;
+  std::vector<double> amp;
   for (int i = 0; i < prm.n_freqs; ++i) {
     ScalePlan& sp = hp->scales[i];
     sp.freq_hz = hp->freqs[i];
@@ -84,26 +184,68 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     sp.omega = sp.freq_hz / (prm.fs / 2.0) * M_PI;                    // transforms.py:408-410
     sp.length = (int64_t)std::ceil(hp->w0 / sp.omega * hp->base_length);  // morse.py:118-122
     if (sp.length < 1) sp.length = 1;
+    if (sp.length > ((int64_t)1 << 40)) return fail(GCWT_ERR_UNSUPPORTED, "kernel length beyond 2^40");
     sp.half_delay = (double)(sp.length - 1) / 2.0 - (double)((sp.length - 1) / 2);
-    if (hp->u_hi * sp.omega > M_PI) {
-      sp.method = GCWT_SCALE_DIRECT;
-      sp.direct_index = hp->n_direct++;
-      sp.direct_offset = hp->direct_total;
-      hp->direct_total += sp.length;
-      if (sp.length > 65536)
-        return fail(GCWT_ERR_UNSUPPORTED, "a scale whose filter reaches Nyquist has a kernel "
-                                          "longer than 65536 taps");
-    } else {
-      sp.method = GCWT_SCALE_SPECTRAL;
-      lmax_spec = std::max(lmax_spec, sp.length);
-    }
+    scale_bins(*hp, &sp, &amp);
+    sp.amp_offset = (int64_t)hp->amps.size();
+    hp->amps.insert(hp->amps.end(), amp.begin(), amp.end());
+    hp->max_bins = std::max(hp->max_bins, (int)sp.n_bins);
+    analyse_scale(*hp, &sp, amp.data());
+    sp.method = sp.band_ok ? GCWT_SCALE_SPECTRAL
+                           : (sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND);
   }
 
-  // segments: one per epoch, or overlapping time blocks when an epoch needs a longer FFT
+  // Decimation of every spectral candidate needs the shortest FFT of the plan, which needs
+  // the longest kernel that goes through an FFT: two rounds (a candidate that turns out not
+  // to fit its block moves to the other paths and may shorten the FFTs).
   hp->max_fft_log2 = prm.max_fft_log2 == 0 ? 22 : prm.max_fft_log2;
   if (hp->max_fft_log2 < 12 || hp->max_fft_log2 > 22)
     return fail(GCWT_ERR_INVALID, "max_fft_log2 must be 0 or 12..22");
   const int64_t pmax = (int64_t)1 << hp->max_fft_log2;
+  auto fft_of = [&](int64_t e0, int64_t e1, int64_t lmax) {
+    return std::max<int64_t>(kRowLen, next_pow2(e1 - (e0 & ~(int64_t)63) + lmax));
+  };
+  auto longest_fft_kernel = [&]() {
+    int64_t l = 1;
+    for (const ScalePlan& sp : hp->scales)
+      if (sp.method != GCWT_SCALE_DIRECT) l = std::max(l, sp.length);
+    return l;
+  };
+  for (int round = 0; round < 4; ++round) {
+    const int64_t lmax = longest_fft_kernel();
+    int64_t pmin = INT64_MAX;
+    for (int e = 0; e < n_ep; ++e)
+      pmin = std::min(pmin, std::min(pmax, fft_of(hp->bounds[2 * e], hp->bounds[2 * e + 1], lmax)));
+    const int r_cap = (int)std::min<int64_t>(kMaxDecimation, pmin / B);
+    bool moved = false;
+    for (ScalePlan& sp : hp->scales) {
+      if (sp.method != GCWT_SCALE_SPECTRAL) continue;
+      int r = 2;   // theta_hi <= pi holds here, so R = 2 always fits
+      while (2 * r <= r_cap && sp.theta_hi * (2.0 * r) <= 2.0 * M_PI) r *= 2;
+      sp.decimation = r;
+      // decimated samples discarded at each block edge: the kernel's measured support
+      int halo = std::max((int)std::ceil(sp.support / (double)r) + 2, 16);
+      if (r == 2) halo += halo & 1;   // keeps halo*R a multiple of 4: 16-byte aligned tile runs
+      if (B - 2 * halo < 32) {        // does not fit the block at the largest decimation it allows
+        sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
+        moved = true;
+      }
+    }
+    if (!moved) break;
+  }
+  int64_t lmax_spec = longest_fft_kernel();
+  for (int i = 0; i < prm.n_freqs; ++i) {
+    ScalePlan& sp = hp->scales[i];
+    if (sp.method == GCWT_SCALE_DIRECT) {
+      sp.direct_index = hp->n_direct++;
+      sp.direct_offset = hp->direct_total;
+      hp->direct_total += sp.length;
+    } else if (sp.method == GCWT_SCALE_FULLBAND) {
+      sp.fullband_index = hp->n_fullband++;
+    }
+  }
+
+  // segments: one per epoch, or overlapping time blocks when an epoch needs a longer FFT
   int64_t pmin = INT64_MAX;
   for (int e = 0; e < n_ep; ++e) {
     const int64_t e0 = hp->bounds[2 * e], e1 = hp->bounds[2 * e + 1];
@@ -139,15 +281,14 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   const int n_seg = (int)hp->epochs.size();
   (void)n_seg;
 
-  // decimation factor per spectral scale, levels
+  // levels: one per decimation factor in use
   const int r_cap = (int)std::min<int64_t>(kMaxDecimation, pmin / B);
   std::map<int, int> level_of_r;
   for (int i = 0; i < prm.n_freqs; ++i) {
     ScalePlan& sp = hp->scales[i];
     if (sp.method != GCWT_SCALE_SPECTRAL) continue;
-    int r = 2;  // u_hi*omega <= pi holds here, so R = 2 always fits
-    while (2 * r <= r_cap && hp->u_hi * sp.omega * (2.0 * r) <= 2.0 * M_PI) r *= 2;
-    sp.decimation = r;
+    const int r = sp.decimation;
+    if (r > r_cap) return fail(GCWT_ERR_UNSUPPORTED, "internal: decimation beyond the shortest FFT");
     auto it = level_of_r.find(r);
     if (it == level_of_r.end()) {
       LevelPlan lp;
@@ -159,12 +300,10 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     sp.level = it->second;
     LevelPlan& lp = hp->levels[sp.level];
     lp.scales.push_back(i);
-    // decimated samples discarded at each block edge: half the kernel's effective support.
-    // The reference length L is "4 footprints to be safe" (morse.py:113-116); beyond
-    // 0.82 L/2 the wavelet is below 2e-5 of its peak and the wrap-around error of the
-    // block convolution stays below 3e-7 of the row maximum (tests/test_host_surface.py).
-    int halo = (int)std::ceil(hp->halo_frac * (double)sp.length / (2.0 * r)) + 2;
-    halo = std::max(halo, 16);
+    // Decimated samples discarded at each block edge: the kernel's measured support (the
+    // reference length L is "4 footprints to be safe", morse.py:113-116; what lies beyond
+    // `support` holds less than support_tol of the kernel's energy), plus two.
+    int halo = std::max((int)std::ceil(sp.support / (double)r) + 2, 16);
     if (r == 2) halo += halo & 1;   // keeps halo*R a multiple of 4: 16-byte aligned tile runs
     lp.halo = std::max(lp.halo, halo);
   }
@@ -172,8 +311,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     lp.hop = B - 2 * lp.halo;
     if (lp.hop < 32)
       return fail(GCWT_ERR_UNSUPPORTED,
-                  "a wavelet is too long for the 256-sample decimated block at the largest "
-                  "decimation this build supports (256): lowest frequency too low for fs");
+                  "internal: a spectral scale does not fit its 256-sample decimated block");
     if (lp.halo > 32 || lp.scales.size() > 256) hp->halo_static = false;   // fast kernel's limits
     lp.twiddle_offset = hp->level_twiddle_total;
     hp->level_twiddle_total += (int64_t)kSynthCols * lp.decimation;
@@ -204,7 +342,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     EpochPlan& lead = hp->epochs[first];
     int64_t blocks = 0;
     for (size_t l = 0; l < hp->levels.size(); ++l) blocks += (int64_t)lead.lv[l].nblk * B;
-    const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks);   // X + x_R (< P) + XB, roughly
+    const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks + (hp->n_fullband > 0 ? lead.p : 0));   // X + x_R (< P) + XB (+ Z), roughly
     int cap = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, budget / std::max<int64_t>(1, per_slot)));
     cap = (int)std::max<int64_t>(1, std::min<int64_t>(cap, 65535 / C));   // grid.y = segments * channels
     size_t count = 1;
@@ -252,6 +390,8 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   }
 
   hp->workspace_bytes = 8 * C * hp->max_batch * (hp->max_p + hp->max_xr + hp->max_xb)   // X, x_R, XB
+                        + (hp->n_fullband > 0 ? 8 * (C * hp->max_batch + 1) * hp->max_p : 0)  // Z, H
+                        + 8 * (int64_t)hp->amps.size()
                         + 8 * (int64_t)prm.n_freqs * B                  // bank
                         + 8 * (hp->direct_total + hp->level_twiddle_total + kRowLen + 256)
                         + 16 * C;

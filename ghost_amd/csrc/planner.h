@@ -1,8 +1,10 @@
 // planner.h -- host-side planning for the CWT engine (no device code).
 //
-// Decides, for every analysis frequency, how it is evaluated (closed-form
-// spectral filter on a decimated block grid, or literal time-domain kernel),
-// and lays out the per-epoch FFT sizes, decimation levels and block grids.
+// Decides, for every analysis frequency, how it is evaluated -- the exact response of
+// the reference's L-tap kernel on a decimated block grid, the literal kernel in the time
+// domain, or a full-band FFT convolution -- from the MEASURED support of that kernel in
+// frequency and in time (morse_exact.h), and lays out the per-epoch FFT sizes,
+// decimation levels and block grids.
 // Mirrors the set-up part of ghost/wave/transforms.py:179-185 and the length
 // rule of ghost/wave/morse.py:108-122; the block/decimation layout is this
 // engine's own.
@@ -22,6 +24,7 @@ constexpr int kMaxBatch = 16;                // segments per launch set (kernels
 constexpr int kMaxTwoPassDecimation = 256;   // above it the level IFFT uses the small-size kernel
 constexpr int kSynthCols = 16;     // columns (block, r) per batch of the 16-column kernel
 constexpr int kSynthWide = 32;      // columns per batch of the production kernel
+constexpr int kDirectMaxLen = 512;  // longest kernel the time-domain path takes
 
 struct ScalePlan {
   double freq_hz = 0, omega = 0;   // omega = f / (fs/2) * pi   (transforms.py:408-410)
@@ -32,6 +35,16 @@ struct ScalePlan {
   double half_delay = 0;           // d = (L-1)/2 - (L-1)//2
   int direct_index = -1;           // index among direct scales
   int64_t direct_offset = 0;       // offset of psi in the direct-kernel buffer (complex elems)
+  int fullband_index = -1;         // index among full-band scales
+  // kept spectrum samples A_j of the reference kernel that are not negligible (1e-18 of
+  // the largest): bins bin_lo .. bin_lo + n_bins - 1, values HostPlan::amps[amp_offset ..]
+  int32_t bin_lo = 0, n_bins = 0;
+  int64_t amp_offset = 0;
+  // measured on the exact response (planner.cpp: analyse_scale)
+  double theta_hi = 0;             // |G| <= band_tol * peak for theta in [theta_hi, 2 pi)
+  double support = 0;              // samples either side of the centre that hold all but
+                                   // support_tol of the kernel's energy (L2)
+  bool band_ok = false;            // theta_hi <= pi: some decimation R >= 2 is exact to band_tol
 };
 
 struct LevelPlan {
@@ -79,16 +92,19 @@ struct HostPlan {
   std::vector<double> freqs;
   std::vector<int64_t> bounds;
   int block = 256;                 // B
-  double band_eps = 1e-9;
+  double band_tol = 2e-7;          // out-of-band response tolerated, relative to the peak
+  double support_tol = 4.5e-6;     // kernel energy (L2, relative) a block halo may cut off
   double w0 = 0;                   // (beta/gamma)^(1/gamma)          (morseutils.py:315)
   double base_length = 0;          // 2 sqrt2 sqrt(gamma beta)/w0 * 4 (morse.py:115-116)
-  double u_lo = 0, u_hi = 0;       // filter support [u_lo, u_hi] * omega at band_eps
+  double u_lo = 0, u_hi = 0;       // continuous spectrum above 1e-18 of its peak on [u_lo, u_hi] * omega
+  std::vector<double> amps;        // A_j of every scale, back to back
   std::vector<ScalePlan> scales;
   std::vector<LevelPlan> levels;
   std::vector<EpochPlan> epochs;   // segments, in time order
   bool halo_static = true;         // every level has 16 <= halo <= 32 (fast synthesis kernel)
-  double halo_frac = 0.82;         // kernel support kept, as a fraction of the reference length L
   int n_direct = 0;
+  int n_fullband = 0;
+  int max_bins = 0;                // largest n_bins
   int64_t direct_total = 0;        // complex elements of all direct kernels
   int64_t level_twiddle_total = 0;
   int64_t max_p = 0, max_xr = 0, max_xb = 0;

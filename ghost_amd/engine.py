@@ -129,7 +129,14 @@ class CwtPlan:
         check(lib.gcwt_plan_scale_info(self._handle, method.ctypes.data_as(i32p),
                                        dec.ctypes.data_as(i32p), halo.ctypes.data_as(i32p),
                                        hop.ctypes.data_as(i32p), length.ctypes.data_as(i64p)))
-        return {"method": method, "decimation": dec, "halo": halo, "hop": hop, "length": length}
+        theta_hi = np.zeros(s, np.float64)
+        support = np.zeros(s, np.float64)
+        n_bins = np.zeros(s, np.int32)
+        f64p = C.POINTER(C.c_double)
+        check(lib.gcwt_plan_scale_support(self._handle, theta_hi.ctypes.data_as(f64p),
+                                          support.ctypes.data_as(f64p), n_bins.ctypes.data_as(i32p)))
+        return {"method": method, "decimation": dec, "halo": halo, "hop": hop, "length": length,
+                "theta_hi": theta_hi, "support": support, "n_bins": n_bins}
 
     # -- device -----------------------------------------------------------
     def upload(self):
@@ -230,6 +237,14 @@ class CwtPlan:
             res.append((first.value, count.value))
             seg = first.value + max(1, count.value)
         return res
+
+    def debug_exact_gain(self, scale, a, b):
+        """G of one scale's reference kernel at theta = 2 pi a / b (host evaluation)."""
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        out = np.empty(a.size, dtype=np.float64)
+        check(lib.gcwt_debug_exact_gain(self._handle, int(scale), a.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        int(b), a.size, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
 
     def debug_fetch(self, what, channel=0, epoch=0, level=0):
         lv = self.debug_levels(epoch)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GCWT_ABI_VERSION 1
+#define GCWT_ABI_VERSION 2
 
 typedef enum {
   GCWT_OK = 0,
@@ -47,11 +47,15 @@ typedef enum {
   GCWT_OUT_COMPLEX_C64 = 2    /* W         float32 pairs (re,im) [C][S][N]       */
 } gcwt_out_mode;
 
-/* How a scale is evaluated (reported by gcwt_plan_scale_info). */
+/* How a scale is evaluated (reported by gcwt_plan_scale_info).  Every method computes
+ * the convolution with the reference's own L-tap kernel (morseutils.py:117-149): the
+ * choice is made per scale from the measured support of that kernel's exact response. */
 typedef enum {
-  GCWT_SCALE_SPECTRAL = 0, /* closed-form one-sided filter, decimated block IFFT */
-  GCWT_SCALE_DIRECT = 1    /* literal L-tap kernel, time-domain (filter not
-                              negligible at Nyquist: SURVEY.md A.3)              */
+  GCWT_SCALE_SPECTRAL = 0, /* exact response on a decimated band, block IFFT (fast path) */
+  GCWT_SCALE_DIRECT = 1,   /* literal L-tap kernel, time domain: short kernels whose
+                              response reaches Nyquist           */
+  GCWT_SCALE_FULLBAND = 2  /* one FFT convolution over the whole band: kernels whose
+                              truncation leaks at every frequency (small beta)   */
 } gcwt_scale_method;
 
 enum {
@@ -78,7 +82,8 @@ typedef struct {
   const int64_t* epoch_bounds; /* [2E] start,stop index pairs (transforms.py:202) */
   int32_t device;              /* HIP ordinal; -1 = leave the current device      */
   int32_t block;               /* decimated block length B; 0 = default (256)     */
-  double band_eps;             /* filter treated as 0 below eps*peak; 0 = 1e-9    */
+  double band_eps;             /* response the fast path may ignore outside a scale's
+                                  band, relative to the peak; 0 = 2e-7             */
   int32_t max_fft_log2;        /* longest FFT the plan may use, 12..22; 0 = 22.  Epochs
                                   that need more are cut into overlapping time blocks  */
   int32_t reserved;
@@ -93,6 +98,8 @@ typedef struct {
   int64_t fft_length;          /* P of the longest epoch                          */
   int64_t workspace_bytes;     /* device workspace the plan will allocate         */
   int64_t out_bytes;           /* size of the out buffer gcwt_execute fills       */
+  int32_t n_fullband;          /* scales on the full-band path                    */
+  int32_t reserved;
 } gcwt_plan_info;
 
 /* Stage timings of the last gcwt_execute on a plan created with profiling on,
@@ -106,7 +113,7 @@ typedef struct {
   float direct_ms;      /* time-domain scales                                     */
   float total_ms;       /* first kernel start to last kernel end                  */
   int32_t synth_launches;
-  int32_t reserved;
+  float fullband_ms;    /* full-band scales (filter, product, inverse FFT, store) */
 } gcwt_timings;
 
 /* Library / device ------------------------------------------------------- */
@@ -134,6 +141,13 @@ int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info);
  * reference kernel length L of morse.py:108-122. */
 int gcwt_plan_scale_info(const gcwt_plan* plan, int32_t* method, int32_t* decimation,
                          int32_t* halo, int32_t* hop, int64_t* length);
+/* What the planner measured on each scale's exact response (arrays of length S, any may
+ * be NULL): theta_hi, the radian frequency above which (through the negative
+ * frequencies, up to 2 pi) the response stays below band_eps of its peak; support, the
+ * distance in samples from the kernel's centre that a block halo must cover; n_bins, the
+ * spectrum samples of morseutils.py:130-131 the kernel is built from. */
+int gcwt_plan_scale_support(const gcwt_plan* plan, double* theta_hi, double* support,
+                            int32_t* n_bins);
 int gcwt_plan_set_profiling(gcwt_plan* plan, int enabled);
 /* Row pitch, in samples, of DEVICE output buffers (0 = dense rows of N, or of the block
  * length).  Rows whose byte offset is not a multiple of 128 make every store straddle

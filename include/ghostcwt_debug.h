@@ -24,6 +24,11 @@ int gcwt_debug_level_info(const gcwt_plan* plan, int epoch, int level, int32_t* 
 int gcwt_debug_batch_of(const gcwt_plan* plan, int segment, int32_t* first, int32_t* count);
 int gcwt_debug_fetch(gcwt_plan* plan, int what, int channel, int epoch, int level, float* dst,
                      int64_t max_complex);
+/* The exact (real) response G of one scale's reference kernel at theta = 2 pi a[i] / b,
+ * i < n, evaluated on the HOST by the same code the device bank builder runs
+ * (csrc/morse_exact.h).  Needs no GPU. */
+int gcwt_debug_exact_gain(const gcwt_plan* plan, int scale, const int64_t* a, int64_t b, int64_t n,
+                          double* gain);
 
 #ifdef __cplusplus
 }

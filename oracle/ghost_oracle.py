@@ -40,7 +40,7 @@ __all__ = [
     "morse_freq_bounds", "morse_lengths", "morse_kernel",
     "overlap_add_convolve", "contiguous_segments", "frequency_grid",
     "hz_to_rad", "rad_to_hz", "cwt_complex", "cwt_amplitude",
-    "spectral_filter", "cwt_complex_spectral",
+    "spectral_filter", "cwt_complex_spectral", "kernel_response",
 ]
 
 # --------------------------------------------------------------------------
@@ -278,6 +278,19 @@ def spectral_filter(theta, omega, length, gamma=3.0, beta=20.0):
     amp = np.where(theta > 0, amp, 0.0)
     d = (length - 1) / 2 - (length - 1) // 2
     return amp * np.exp(-1j * theta * d)
+
+
+def kernel_response(theta, omega, length, gamma=3.0, beta=20.0):
+    """Frequency response of the L-tap kernel the reference convolves with, as the
+    'same' crop positions it: H(theta) = sum_n psi[n] exp(-i theta (n - (L-1)//2)), psi from
+    ``morse_kernel`` (morseutils.py:149) and the offset from convolution.py:85.  Direct
+    O(L) sum per frequency.  For (gamma, beta) = (3, 20) it equals ``spectral_filter`` to
+    ~6e-9 of the peak; for heavier-tailed wavelets only this one is what the reference
+    applies."""
+    theta = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+    psi, _ = morse_kernel(length, omega, gamma, beta)
+    n = np.arange(int(length)) - (int(length) - 1) // 2
+    return np.exp(-1j * np.outer(theta, n)) @ psi
 
 
 def cwt_complex_spectral(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0,

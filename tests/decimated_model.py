@@ -1,12 +1,19 @@
 """NumPy model of the algorithm the HIP engine runs (test helper, float64).
 
-Decimate-then-block formulation:
-  X      = FFT_P(x - mean, zero padded)                      one per channel/epoch
-  x_R    = IFFT_{P/R}(X[0:P/R]) / R                          analytic low-pass, rate fs/R
-  XB_b   = FFT_B(x_R[b*hop - Lh : b*hop - Lh + B])           block spectra (circular index)
-  y[R*m + r] = IFFT_B(XB_b * H_s(2 pi k/(B R)) * exp(2 pi i k r/(B R)))[m]
-valid for Lh <= m < B - Lh.  Used on the CPU to check the maths and the planner
-against the literal oracle before any kernel runs.
+Per scale the engine's planner picks one of three evaluations of the SAME quantity, the
+convolution with the reference's L-tap kernel:
+
+  spectral   X = FFT_P(x - mean, zero padded); x_R = IFFT_{P/R}(X[0:P/R]) / R;
+             XB_b = FFT_B(x_R[b*hop - Lh : b*hop - Lh + B]) (circular index);
+             y[R*m + r] = IFFT_B(XB_b * H_s(2 pi k/(B R)) * exp(2 pi i k r/(B R)))[m],
+             kept for Lh <= m < B - Lh
+  full-band  y = IFFT_P(X * H_s(2 pi k/P))[0:N_e]
+  direct     the literal kernel, time domain
+
+with H_s the exact response of the reference's kernel (``exact_gain`` below, the
+closed form csrc/morse_exact.h evaluates).  The decisions (method, R, halo, hop) are
+taken from the planner itself (``CwtPlan.scale_info``), so this model checks on the CPU,
+against the literal oracle, both the maths and what the planner decided.
 """
 import math
 
@@ -16,82 +23,85 @@ from scipy.fft import fft, ifft
 from oracle import ghost_oracle as orc
 
 
-def band_edges(gamma, beta, eps):
-    """u_lo < 1 < u_hi with Psi(u*w0)/Psi(w0) = eps (bisection on the log gain)."""
-    w0c = beta / gamma  # w0**gamma
-
-    def lg(u):
-        return beta * math.log(u) - w0c * (u ** gamma - 1.0)
-
-    target = math.log(eps)
-    lo, hi = 1e-9, 1.0
-    for _ in range(200):
-        mid = 0.5 * (lo + hi)
-        if lg(mid) < target:
-            lo = mid
-        else:
-            hi = mid
-    u_lo = lo
-    lo, hi = 1.0, 64.0
-    for _ in range(200):
-        mid = 0.5 * (lo + hi)
-        if lg(mid) < target:
-            hi = mid
-        else:
-            lo = mid
-    return u_lo, hi
+def kept_bins(omega, length, gamma, beta):
+    """(j, A_j): the spectrum samples the reference kernel is built from
+    (morseutils.py:117, :130-131, :178), without the ones below 1e-18 of the peak."""
+    L = int(length)
+    w0 = orc.morse_peak_freq(gamma, beta)
+    j = np.arange(1, round(L / 2))
+    w = 2 * np.pi * j / L * w0 / omega
+    amp = 2 * np.exp(-beta * np.log(w0) + w0 ** gamma + beta * np.log(w) - w ** gamma)
+    keep = amp > amp.max() * 1e-18 if amp.size else np.zeros(0, bool)
+    return j[keep], amp[keep]
 
 
-def plan_scale(omega, length, p_big, B, gamma, beta, eps):
-    """(method, R, Lh, hop) for one scale."""
-    _, u_hi = band_edges(gamma, beta, eps)
-    if u_hi * omega > math.pi:
-        return ("direct", 1, 0, 0)
-    r = 1
-    while u_hi * omega * (2 * r) <= math.pi * 2 and 2 * r <= p_big // B:
-        r *= 2
-    # r is the largest power of two with u_hi*omega <= 2 pi / r
-    lh = max(int(math.ceil(0.82 * length / (2.0 * r))) + 2, 16)
-    hop = B - 2 * lh
-    return ("spectral", r, lh, hop)
+def exact_gain(theta, omega, length, gamma=3.0, beta=20.0):
+    """G(theta), real: H = exp(-i theta d) G is the response of the reference's kernel;
+    G(theta) = (1/L) sum_j A_j sin(L (theta_j - theta)/2) / sin((theta_j - theta)/2)."""
+    L = int(length)
+    j, amp = kept_bins(omega, L, gamma, beta)
+    theta = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+    d = 2 * np.pi * j[None, :] / L - theta[:, None]
+    num, den = np.sin(L * d / 2), np.sin(d / 2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(np.abs(den) < 1e-13, L * np.cos(L * d / 2) / np.cos(d / 2), num / den)
+    return (ratio * amp[None, :]).sum(axis=1) / L
 
 
-def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0,
-                  B=256, eps=1e-9):
+def exact_response(theta, omega, length, gamma=3.0, beta=20.0):
+    theta = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+    d = (length - 1) / 2 - (length - 1) // 2
+    return exact_gain(theta, omega, length, gamma, beta) * np.exp(-1j * theta * d)
+
+
+def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=256, plan=None):
+    """Model output, complex128 (S, N).  ``plan``: a CwtPlan for the same layout (made
+    here when omitted; planning needs no GPU)."""
+    from ghost_amd.engine import CwtPlan
     x = np.asarray(x).squeeze().astype(np.float64)
     x = x - x.mean()
     n = x.size
     if epoch_bounds is None:
         epoch_bounds = np.array([[0, n]])
     freqs_hz = np.atleast_1d(np.asarray(freqs_hz, dtype=np.float64))
+    if plan is None:
+        plan = CwtPlan(n, 1, fs, freqs_hz, gamma=gamma, beta=beta, epoch_bounds=epoch_bounds)
+    si = plan.scale_info()
     omegas = orc.hz_to_rad(freqs_hz, fs)
     lengths = orc.morse_lengths(omegas, gamma, beta)
+    assert np.array_equal(lengths, si["length"])
     out = np.zeros((len(freqs_hz), n), dtype=np.complex128)
+    fft_len = {(a, b): p for (a, b, p) in plan.segments()}
     for start, stop in epoch_bounds:
         ne = stop - start
-        p_big = max(1 << int(math.ceil(math.log2(ne + int(lengths.max())))), 2 * B)
-        X = fft(x[start:stop], n=p_big)
+        p_big = fft_len[(start, stop)]                 # whole epochs only (no time blocks here)
+        lead = start - (start & ~63)                   # segments start on multiples of 64 samples
+        X = fft(np.concatenate([np.zeros(lead), x[start:stop]]), n=p_big)
         xr_cache = {}
         for i, (om, L) in enumerate(zip(omegas, lengths)):
-            method, R, lh, hop = plan_scale(om, L, p_big, B, gamma, beta, eps)
-            if method == "direct":
+            method = si["method"][i]
+            if method == 1:
                 psi, _ = orc.morse_kernel(L, om, gamma, beta)
                 out[i, start:stop] = orc.overlap_add_convolve(x[start:stop], psi)
                 continue
-            assert hop > 0, (R, lh)
+            if method == 2:
+                H = exact_response(2 * np.pi * np.arange(p_big) / p_big, om, L, gamma, beta)
+                out[i, start:stop] = ifft(X * H)[lead:lead + ne]
+                continue
+            R, lh, hop = int(si["decimation"][i]), int(si["halo"][i]), int(si["hop"][i])
             M = p_big // R
             if R not in xr_cache:
                 xr_cache[R] = ifft(X[:M]) / R
             xr = xr_cache[R]
             k = np.arange(B)
-            H = orc.spectral_filter(2 * np.pi * k / (B * R), om, L, gamma, beta)
+            H = exact_response(2 * np.pi * k / (B * R), om, L, gamma, beta)
             tw = np.exp(2j * np.pi * np.outer(k, np.arange(R)) / (B * R))
-            nblk = int(math.ceil(math.ceil(ne / R) / hop))
+            nblk = int(math.ceil(math.ceil((lead + ne) / R) / hop))
             y = np.zeros(R * nblk * hop, dtype=np.complex128)
             for b in range(nblk):
                 idx = (b * hop - lh + np.arange(B)) % M
                 XB = fft(xr[idx])
                 blk = ifft((XB * H)[:, None] * tw, axis=0)        # [m, r]
                 y[R * b * hop: R * (b + 1) * hop] = blk[lh:lh + hop].reshape(-1)
-            out[i, start:stop] = y[:ne]
+            out[i, start:stop] = y[lead:lead + ne]
     return out

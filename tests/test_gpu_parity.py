@@ -516,3 +516,65 @@ def test_low_frequencies_at_high_sampling_rate():
     assert p.scale_info()["length"][0] == 418430 and p.scale_info()["decimation"][0] == 8192
     ref = np.abs(orc.cwt_complex(x.astype(np.float64), fs, [1.0, 30.0]))
     assert rel_err(a[0], ref).max() < TOL
+
+
+GB_PAIRS = [(3, 8), (3, 4), (3, 2), (2, 8), (4, 30), (1, 5)]
+
+
+@pytest.mark.parametrize("gamma,beta", GB_PAIRS)
+def test_other_morse_parameters_inner_loop(golden, gamma, beta):
+    """G11, driver D2: complex coefficients of the reference run with
+    Morse(gamma=, beta=) (ghost/wave/morse.py:14-51, morseutils.py:93-151).  Light-tailed
+    wavelets stay on the decimated path; heavy-tailed ones (3,4), (3,2), (2,8), (1,5) go
+    through the time-domain and full-band paths -- same gate either way."""
+    g = golden("g11_gamma_beta.npz")
+    tag = "g%d_b%d" % (gamma, beta)
+    p, c = _plan(g["x"], float(g["fs"]), g["frequencies"], output="complex", gamma=gamma, beta=beta)
+    si = p.scale_info()
+    np.testing.assert_array_equal(si["length"], g["lengths_" + tag])
+    err = rel_err(c[0][:, g["cols"]], g["complex_cols_" + tag])
+    print(tag, "methods", si["method"].tolist(), "err", err)
+    assert err.max() < TOL
+    p2, a = _plan(g["x"], float(g["fs"]), g["frequencies"], output="amplitude", gamma=gamma, beta=beta)
+    assert rel_err(a[0][:, g["cols"]], np.abs(g["complex_cols_" + tag])).max() < TOL
+    np.testing.assert_allclose(a[0].max(axis=1), g["rowmax_" + tag], rtol=1e-5)
+
+
+@pytest.mark.parametrize("gamma,beta", GB_PAIRS)
+def test_other_morse_parameters_public_api(golden, gamma, beta):
+    """G11, driver D1: ContinuousWaveletTransform(wavelet=Morse(gamma=, beta=))
+    (ghost/wave/transforms.py:42-46)."""
+    from ghost_amd.wave import ContinuousWaveletTransform, Morse
+    g = golden("g11_gamma_beta.npz")
+    tag = "g%d_b%d" % (gamma, beta)
+    cwt = ContinuousWaveletTransform(wavelet=Morse(gamma=gamma, beta=beta))
+    cwt.transform(g["x"], fs=float(g["fs"]), freq_limits=[8, 300], voices_per_octave=4)
+    np.testing.assert_allclose(cwt.frequencies, g["d1_frequencies_" + tag], rtol=1e-14)
+    assert rel_err(cwt.amplitude[:, g["cols"]], g["d1_amplitude_cols_" + tag]).max() < TOL
+    np.testing.assert_allclose(cwt.amplitude.max(axis=1), g["d1_rowmax_" + tag], rtol=1e-5)
+
+
+def test_fullband_path_long_kernels_epochs_and_blocks():
+    """The full-band path on its own terms: kernels of thousands of taps (small beta, low
+    frequencies), two epochs, several channels, forced time blocks, execute_block."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd import _lib
+    fs, n = 1000.0, 50000
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((2, n)) + 0.3 * np.cumsum(rng.standard_normal((2, n)), axis=1) * 0.05).astype(np.float32)
+    f = np.array([120.0, 31.0, 7.0, 2.5, 1.2])
+    eb = np.array([[100, 30000], [30011, 50000]])
+    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, eb, gamma=3, beta=3) for c in range(2)])
+    p = CwtPlan(n, 2, fs, f, gamma=3, beta=3, epoch_bounds=eb, output="complex")
+    m = p.scale_info()["method"]
+    assert (m == _lib.SCALE_FULLBAND).sum() >= 3 and (m == _lib.SCALE_SPECTRAL).sum() == 0
+    got = p.execute(x)
+    assert rel_err(got, ref).max() < TOL
+    assert np.all(got[:, :, :100] == 0) and np.all(got[:, :, 30000:30011] == 0)
+    blk = p.execute_block(x, 29000, 3000)
+    np.testing.assert_array_equal(blk, got[:, :, 29000:32000])
+    # time blocks of 2^14 samples: seams exact
+    p2 = CwtPlan(n, 2, fs, f[:4], gamma=3, beta=3, epoch_bounds=eb, output="amplitude", max_fft_log2=14)
+    assert len(p2.segments()) > 4
+    got2 = p2.execute(x)
+    assert rel_err(got2, np.abs(ref[:, :4])).max() < TOL

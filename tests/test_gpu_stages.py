@@ -17,19 +17,27 @@ def _plan_and_run(x, fs, freqs, **kw):
     return plan, out
 
 
-def test_filter_bank_matches_closed_form():
+def test_filter_bank_is_the_response_of_the_reference_kernel():
+    """The device bank against the DTFT of the literal kernel (oracle), default and other
+    Morse parameters; and, for the default one, against the continuous spectrum it is
+    indistinguishable from."""
     from ghost_amd.engine import CwtPlan
     fs = 1000.0
     f = np.geomspace(200, 2, 100)
-    plan = CwtPlan(1 << 16, 1, fs, f)
-    bank = plan.filter_bank()
-    si = plan.scale_info()
-    om = orc.hz_to_rad(f, fs)
     k = np.arange(256)
-    for i in range(0, 100, 7):
-        theta = 2 * np.pi * k / (256 * si["decimation"][i])
-        ref = orc.spectral_filter(theta, om[i], si["length"][i])
-        assert np.abs(bank[i] - ref).max() < 3e-7 * 2.0
+    for gamma, beta in ((3, 20), (3, 8), (4, 30), (6, 100)):
+        plan = CwtPlan(1 << 16, 1, fs, f, gamma=gamma, beta=beta)
+        bank = plan.filter_bank()
+        si = plan.scale_info()
+        assert np.all(si["method"] == 0)
+        om = orc.hz_to_rad(f, fs)
+        for i in range(0, 100, 9):
+            theta = 2 * np.pi * k / (256 * si["decimation"][i])
+            ref = orc.kernel_response(theta, om[i], si["length"][i], gamma, beta)
+            assert np.abs(bank[i] - ref).max() < 2e-7 * 2.0, (gamma, beta, i)
+            if (gamma, beta) == (3, 20):
+                closed = orc.spectral_filter(theta, om[i], si["length"][i])
+                assert np.abs(bank[i] - closed).max() < 3e-7 * 2.0
 
 
 def test_direct_kernel_matches_reference_psi(golden):

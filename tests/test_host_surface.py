@@ -35,7 +35,7 @@ def test_abi_exports_every_declared_symbol():
     so = ctypes.CDLL(_lib.LIB_PATH)
     missing = [s for s in sorted(declared) if not hasattr(so, s)]
     assert not missing, missing
-    assert _lib.lib.gcwt_abi_version() == 1
+    assert _lib.lib.gcwt_abi_version() == 2
 
 
 def test_morse_scalars_and_lengths(golden):
@@ -214,11 +214,12 @@ def test_planner_through_the_abi():
     assert si["decimation"][0] == 2 and si["decimation"][-1] == 256
     assert np.all(np.diff(si["decimation"]) >= 0)
     assert np.all(si["hop"] >= 32) and np.all(si["hop"] + 2 * si["halo"] == 256)
-    # the filter's support fits the decimated band for every spectral scale
-    assert np.all(1.81 * f * si["decimation"] <= 1000.0)
-    # near-Nyquist scales go to the direct path (closed form invalid > 0.28 fs)
+    # the measured band of every spectral scale fits its decimated band
+    assert np.all(si["theta_hi"] * si["decimation"] <= 2 * np.pi)
+    assert np.all(si["theta_hi"] > 1.5 * 2 * np.pi * f / 1000.0)
+    # scales whose response reaches Nyquist go to the direct path
     p2 = CwtPlan(4096, 1, 1000.0, [391.0, 300.0, 280.0, 270.0, 200.0])
-    assert p2.scale_info()["method"].tolist() == [1, 1, 1, 0, 0]
+    assert p2.scale_info()["method"].tolist() == [1, 1, 0, 0, 0]
     try:
         p2.upload()                          # succeeds on a GPU box
     except GhostCwtError as e:               # fails loudly without one: there is no CPU path
@@ -271,15 +272,89 @@ def test_planner_rejects_bad_requests():
 
 
 def test_decimated_model_matches_oracle(golden):
-    """The algorithm the kernels implement, in float64 NumPy, against the goldens."""
+    """The algorithm the kernels implement, in float64 NumPy and with the planner's own
+    decisions, against the goldens."""
     from decimated_model import cwt_decimated
     from conftest import rel_err
     g = golden("g2_complex_small.npz")
     c = cwt_decimated(g["x"], float(g["fs"]), g["frequencies"])
-    assert rel_err(c, g["coeffs"]).max() < 5e-7      # block edges keep 0.82 of the kernel length
+    assert rel_err(c, g["coeffs"]).max() < 5e-7      # block edges cut 4.5e-6 of the kernel's energy
     g = golden("g5_two_epochs.npz")
     c = cwt_decimated(g["x"], float(g["fs"]), g["frequencies"][::6], g["epoch_bounds"])
     assert rel_err(c[:, g["cols"]], g["complex_cols"][::6]).max() < 5e-7
+
+
+GB_PAIRS = [(3, 8), (3, 4), (3, 2), (2, 8), (4, 30), (1, 5)]
+
+
+def test_exact_gain_is_the_response_of_the_reference_kernel():
+    """csrc/morse_exact.h (host evaluation through the debug hook) and its NumPy twin
+    against the DTFT of the literal kernel (oracle), for light and heavy tails, odd and
+    even L, on the bank's grid and on a full-band grid."""
+    from decimated_model import exact_gain, exact_response
+    from oracle import ghost_oracle as orc
+    fs = 1000.0
+    for gamma, beta in [(3, 20)] + GB_PAIRS:
+        f = np.array([390.0, 140.0, 40.0, 11.0])
+        plan = CwtPlan(20000, 1, fs, f, gamma=gamma, beta=beta)
+        si = plan.scale_info()
+        om = orc.hz_to_rad(f, fs)
+        np.testing.assert_array_equal(si["length"], orc.morse_lengths(om, gamma, beta))
+        for i in range(f.size):
+            L = int(si["length"][i])
+            for b in (256 * 8, 4096):
+                a = np.arange(0, b, 7)
+                theta = 2 * np.pi * a / b
+                ref = orc.kernel_response(theta, om[i], L, gamma, beta)
+                d = (L - 1) / 2 - (L - 1) // 2
+                ref_gain = (ref * np.exp(1j * theta * d))
+                assert np.abs(ref_gain.imag).max() < 1e-12          # G is real
+                twin = exact_gain(theta, om[i], L, gamma, beta)
+                host = plan.debug_exact_gain(i, a, b)
+                assert np.abs(twin - ref_gain.real).max() < 1e-12, (gamma, beta, f[i])
+                assert np.abs(host - ref_gain.real).max() < 1e-12, (gamma, beta, f[i])
+                assert np.abs(exact_response(theta, om[i], L, gamma, beta) - ref).max() < 1e-12
+
+
+def test_planner_measures_each_wavelet():
+    """What the planner decides from the measured support of the kernel's response:
+    the default wavelet keeps the fast path with hop >= 210; heavy-tailed wavelets
+    (side lobes of the L-tap truncation above band_eps everywhere) leave it entirely."""
+    fs, f = 1000.0, np.geomspace(200.0, 2.0, 100)
+    p = CwtPlan(1000000, 128, fs, f)
+    si, info = p.scale_info(), p.info
+    assert info["n_spectral"] == 100 and info["n_direct"] == 0 and info["n_fullband"] == 0
+    assert si["hop"].min() >= 210 and si["halo"].max() <= 32
+    assert np.all(si["theta_hi"] * si["decimation"] <= 2 * np.pi * (1 + 1e-12))
+    assert 0.80 < (si["support"] / (si["length"] / 2)).max() < 0.86
+    # default grid: the top scales reach Nyquist and are short -> time domain
+    g = CwtPlan(16384, 1, fs, np.geomspace(391.0, 4.4, 66)).scale_info()
+    assert list(g["method"][:4]) == [1, 1, 1, 1] and np.all(g["method"][6:] == 0)
+    f2 = np.geomspace(300.0, 3.0, 40)
+    for gamma, beta in GB_PAIRS:
+        q = CwtPlan(65536, 1, fs, f2, gamma=gamma, beta=beta)
+        m, ln = q.scale_info()["method"], q.scale_info()["length"]
+        if (gamma, beta) in ((3, 8), (4, 30)):
+            assert (m == _lib.SCALE_SPECTRAL).sum() >= 36, (gamma, beta)
+        else:
+            assert not (m == _lib.SCALE_SPECTRAL).any(), (gamma, beta)
+            assert np.all(m[ln <= 512] == _lib.SCALE_DIRECT)
+            assert np.all(m[ln > 512] == _lib.SCALE_FULLBAND) and (ln > 512).any()
+    # a looser tolerance is the caller's to ask for
+    q = CwtPlan(65536, 1, fs, f2, gamma=2, beta=8, band_eps=1e-5)
+    assert (q.scale_info()["method"] == _lib.SCALE_SPECTRAL).sum() >= 30
+
+
+def test_decimated_model_for_other_wavelets(golden):
+    """Planner decisions + exact bank, float64, against the reference-made G11."""
+    from decimated_model import cwt_decimated
+    from conftest import rel_err
+    g = golden("g11_gamma_beta.npz")
+    fs, x, cols = float(g["fs"]), g["x"], g["cols"]
+    for gamma, beta in GB_PAIRS:
+        tag = "g%d_b%d" % (gamma, beta)
+        c = cwt_decimated(x, fs, g["frequencies"], gamma=gamma, beta=beta)
+        assert rel_err(c[:, cols], g["complex_cols_" + tag]).max() < 1e-6, tag
 
 
 def test_time_blocks_tile_the_epochs():

@@ -129,3 +129,49 @@ def test_spectral_form_matches_literal(golden):
     g6 = golden("g6_near_nyquist.npz")
     spe6 = orc.cwt_complex_spectral(g6["x"].astype(np.float64), fs, g6["frequencies"][:2])
     assert rel_err(spe6, g6["coeffs"][:2]).min() > 1e-4
+
+
+PAIRS = [(3, 8), (3, 4), (3, 2), (2, 8), (4, 30), (1, 5)]
+
+
+def test_other_morse_parameters(golden):
+    """G11: the reference run with Morse(gamma=, beta=) other than (3, 20), inner loop and
+    public API (ghost/wave/morse.py:14-51, ghost/wave/transforms.py:42-46)."""
+    g = golden("g11_gamma_beta.npz")
+    fs, x, cols = float(g["fs"]), g["x"].astype(np.float64), g["cols"]
+    np.testing.assert_array_equal(g["pairs"], PAIRS)
+    for gamma, beta in PAIRS:
+        tag = "g%d_b%d" % (gamma, beta)
+        f = g["frequencies"]
+        np.testing.assert_array_equal(orc.morse_lengths(orc.hz_to_rad(f, fs), gamma, beta),
+                                      g["lengths_" + tag])
+        c = orc.cwt_complex(x, fs, f, gamma=gamma, beta=beta)
+        assert rel_err(c[:, cols], g["complex_cols_" + tag]).max() < 1e-12, tag
+        np.testing.assert_allclose(np.abs(c).max(axis=1), g["rowmax_" + tag], rtol=1e-12)
+        f1 = orc.frequency_grid(fs, x.size, freq_limits=[8, 300], voices_per_octave=4,
+                                gamma=gamma, beta=beta)
+        np.testing.assert_allclose(f1, g["d1_frequencies_" + tag], rtol=1e-14)
+        a1 = orc.cwt_amplitude(x, fs, f1[::5], gamma=gamma, beta=beta)
+        assert rel_err(a1[:, cols], g["d1_amplitude_cols_" + tag][::5]).max() < 1e-12, tag
+
+
+def test_closed_form_fails_for_heavy_tails_and_kernel_response_does_not(golden):
+    """Why the engine's bank is the response of the truncated kernel: the continuous Morse
+    spectrum stops matching the reference once the wavelet's tails are cut by
+    the L-tap truncation (small beta); the kernel's own response always does."""
+    from scipy.fft import fft, ifft
+    g = golden("g11_gamma_beta.npz")
+    fs, x = float(g["fs"]), g["x"].astype(np.float64)
+    f = g["frequencies"][3:6]
+    for (gamma, beta), floor in (((3, 2), 1e-3), ((1, 5), 1e-3), ((3, 4), 5e-5)):
+        lit = orc.cwt_complex(x, fs, f, gamma=gamma, beta=beta)
+        spe = orc.cwt_complex_spectral(x, fs, f, gamma=gamma, beta=beta)
+        assert rel_err(spe, lit).max() > floor
+        om = orc.hz_to_rad(f, fs)
+        ls = orc.morse_lengths(om, gamma, beta)
+        p = 16384
+        X = fft(x - x.mean(), n=p)
+        for i in range(len(f)):
+            H = orc.kernel_response(2 * np.pi * np.arange(p) / p, om[i], ls[i], gamma, beta)
+            y = ifft(X * H)[:x.size]
+            assert rel_err(y, lit[i]) < 1e-12

@@ -30,6 +30,11 @@ for case in range(n_cases):
     f = np.sort(np.exp(rng.uniform(np.log(lo), np.log(hi), ns)))[::-1] if lo < hi else np.array([0.4 * fs])
     output = ["complex", "amplitude", "power"][int(rng.integers(0, 3))]
     kw = dict(epoch_bounds=eb, output=output)
+    gamma, beta = 3.0, 20.0
+    if rng.random() < 0.5:       # other Morse wavelets: light tails (fast path) and heavy ones
+        gamma = float(rng.choice([1.0, 2.0, 3.0, 4.0, 6.0]))
+        beta = float(np.round(np.exp(rng.uniform(np.log(1.5), np.log(80.0))), 1))
+        kw.update(gamma=gamma, beta=beta)
     if rng.random() < 0.35:
         kw["max_fft_log2"] = int(rng.choice([12, 13, 14, 16]))
     try:
@@ -37,7 +42,8 @@ for case in range(n_cases):
     except Exception as e:
         print("case %2d: plan refused: %s" % (case, str(e)[:90]), flush=True)
         continue
-    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, np.array(eb)) for c in range(n_ch)])
+    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, np.array(eb), gamma=gamma, beta=beta)
+                    for c in range(n_ch)])
     if output == "amplitude":
         ref = np.abs(ref)
     elif output == "power":
@@ -51,9 +57,9 @@ for case in range(n_cases):
     same = np.array_equal(blk, got[:, :, a:a + ln])
     si = p.scale_info()
     tol = 2 * TOL if output == "power" else TOL
-    print("case %2d: fs %7.0f ch %d n %6d ep %d scales %d R<=%5d direct %d segs %3d %-9s err %.2e block %s" %
-          (case, fs, n_ch, n, len(eb), f.size, si["decimation"].max(), int((si["method"] == 1).sum()),
-           len(p.segments()), output, err, "ok" if same else "DIFFERS"), flush=True)
+    print("case %2d: fs %7.0f ch %d n %6d ep %d g,b %g,%4g scales %d R<=%5d direct %d full %d segs %3d %-9s err %.2e block %s" %
+          (case, fs, n_ch, n, len(eb), gamma, beta, f.size, si["decimation"].max(), int((si["method"] == 1).sum()),
+           int((si["method"] == 2).sum()), len(p.segments()), output, err, "ok" if same else "DIFFERS"), flush=True)
     worst = max(worst, err / (tol / TOL))
     if err > tol or not same:
         print("FAILED", dict(fs=fs, n=n, eb=eb, f=f.tolist(), kw=kw))
