@@ -76,10 +76,11 @@ def test_two_epochs(golden):
 
 
 def test_near_nyquist_direct_path(golden):
-    """Scales whose filter is not negligible at Nyquist use the literal kernel."""
+    """Scales whose response reaches Nyquist use the literal kernel; 280 Hz,
+    whose exact response is below 2e-7 of its peak from 0.96 pi on, fits the R = 2 band."""
     g = golden("g6_near_nyquist.npz")
     p, c = _plan(g["x"], float(g["fs"]), g["frequencies"], output="complex")
-    assert p.scale_info()["method"].tolist() == [1, 1, 1, 1, 1]
+    assert p.scale_info()["method"].tolist() == [1, 1, 1, 1, 0]
     assert rel_err(c[0], g["coeffs"]).max() < TOL
 
 
@@ -249,7 +250,7 @@ def test_fallback_synthesis_kernel(monkeypatch):
     assert rel_err(p.execute(x), ref).max() < TOL
     # 300 scales inside one octave -> one level with more than 256 scales
     x1 = lfp(1, 6000, fs)
-    f2 = np.geomspace(68.0, 36.0, 300)
+    f2 = np.geomspace(68.0, 38.0, 300)
     p2 = CwtPlan(6000, 1, fs, f2, output="amplitude")
     assert len(set(p2.scale_info()["decimation"].tolist())) == 1
     ref2 = np.abs(orc.cwt_complex(x1[0].astype(np.float64), fs, f2))
