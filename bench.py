@@ -1,19 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Msamples/s of the continuous wavelet transform,
-BASELINE.json config 3 -- 128 channels x 1e6 samples @ 1 kHz x 100 Morse scales
-(log-spaced 200..2 Hz), amplitude output -- per GPU, device-resident.
+"""Headline benchmark: Msamples/s of the continuous wavelet transform.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 3|5]
 
-N > 1 is launched by ``python -m torch.distributed.run`` (one rank per GPU); each
-rank transforms its own 128-channel block (weak scaling, no data-path
-collective); rank 0's filter bank is broadcast once with RCCL.  Rank 0 prints one
-JSON line.  A "step" is one gcwt_execute over the rank's block with input and
-output resident in HBM.  No torch anywhere in this file.
+--config 3 (default; BASELINE.json configs[2], and configs[3] at N = 8): 128 channels per
+GPU x 1e6 samples @ 1 kHz x 100 Morse scales (log-spaced 200..2 Hz), amplitude output,
+input and output resident in HBM.  A "step" is one gcwt_execute over the rank's block.
+--config 5 (BASELINE.json configs[4]): 48 channels per GPU (384 over 8) x 18e6 samples
+@ 30 kHz (one 10-minute epoch) x 200 scales 500..1 Hz, streamed: the plan's overlapping
+time blocks are computed one after the other, 8 channels at a time, into a ring of two
+device buffers (the 691 GB of output per GPU never exist at once).  A step is one pass over
+the rank's channels and the whole epoch.
+
+N > 1: one process per GPU.  Under ``python -m torch.distributed.run`` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) this process is one rank; run bare with
+``--gpus N`` it starts the N ranks itself, as fresh child processes, before anything here
+touches HIP.  Each rank transforms its own channel block (weak scaling, no data-path
+collective); rank 0's filter bank is broadcast once with RCCL.  Rank 0 prints one JSON
+line on the real stdout; everything else any library prints goes to stderr.
+No torch anywhere in this file.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,15 +34,72 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); measured copy 6290
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E data sheet (guides/MI355X_MICROARCH.md)
+
+# The result line goes to the stdout this process was started with; fd 1 itself is pointed
+# at stderr for the whole run, so that nothing a library prints (RCCL's banner) can land
+# in front of the line -- and no call ever has to redirect around itself.
+_RESULT = os.fdopen(os.dup(1), "w")
+os.dup2(2, 1)
+sys.stdout = sys.stderr
 
 
+def emit(obj):
+    _RESULT.write(json.dumps(obj) + "\n")
+    _RESULT.flush()
+
+
+# ----------------------------------------------------------------------------
+# launcher: N fresh ranks, no HIP call in this process
+# ----------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr))
+    line = procs[0].stdout.read().decode()
+    codes = []
+    deadline = time.time() + 3600
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(-9)
+    if any(codes):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write("bench.py: ranks exited with %s\n" % codes)
+        return 1
+    _RESULT.write(line)
+    _RESULT.flush()
+    return 0
+
+
+# ----------------------------------------------------------------------------
+# checkers (rank 0, N = 1, outside the timed region): the oracle is test infrastructure
+# ----------------------------------------------------------------------------
 def cpu_baseline(fs, n_samples, freqs, budget_s=25.0):
     """The oracle's literal path (port of transforms.py:187-224 + convolution.py:16-87)
     on this box's cores: config 2 shape, ThreadPool over scales like parallel=True."""
     from oracle import ghost_oracle as orc
     from ghost_amd.synthetic import lfp_channel
-    cores = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share is 16 cores
+    affinity = len(os.sched_getaffinity(0))
+    cores = min(affinity, 16)                       # a 1-GPU box's CPU share is 16 cores
     x = lfp_channel(n_samples, fs, 0).astype(np.float64)
     best, reps = None, 0
     t_start = time.time()
@@ -44,10 +112,199 @@ def cpu_baseline(fs, n_samples, freqs, budget_s=25.0):
         if time.time() - t_start > budget_s:
             break
     return {"value": round(n_samples / best / 1e6, 4), "unit": "Msamples/s", "cores": cores,
-            "kind": "port",
-            "sample": "1 ch x %d samples x %d scales (config 2), float64, scipy.fft overlap-add, "
-                      "ThreadPool(%d) over scales, best of %d runs (%.2f s each)" %
-                      (n_samples, len(freqs), cores, reps, best)}
+            "os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "kind": "port",
+            "sample": "1 ch x %d samples x %d scales (config 2 of the same fs and scales), float64, "
+                      "scipy.fft overlap-add, ThreadPool(%d) over scales, best of %d runs "
+                      "(%.2f s each)" % (n_samples, len(freqs), cores, reps, best)}
+
+
+def spot_check(obuf, base, fs, freqs, C, N, distinct):
+    """Looks at what the timed steps wrote: rows (channel, scale) of the device result
+    against the oracle (transforms.py:187-204), and the tiled channels c and c + distinct
+    (same input) bit for bit.  Returns (ok, worst relative error)."""
+    from oracle import ghost_oracle as orc
+    S = len(freqs)
+    chans = sorted({0, min(7, C - 1), C - 1})
+    scales = sorted({0, (57 * S) // 100, S - 1})
+    worst, same = 0.0, True
+    for c in chans:
+        ref = orc.cwt_amplitude(base[c % distinct].astype(np.float64), fs, freqs[scales])
+        for i, s in enumerate(scales):
+            row = obuf.download((N,), np.float32, offset_bytes=4 * (c * S + s) * N)
+            worst = max(worst, float(np.abs(row - ref[i]).max() / np.abs(ref[i]).max()))
+            twin = c + distinct if c + distinct < C else c - distinct
+            if 0 <= twin < C and twin != c:
+                other = obuf.download((N,), np.float32, offset_bytes=4 * (twin * S + s) * N)
+                same = same and np.array_equal(row, other)
+    return bool(worst <= 1e-5 and same), worst
+
+
+# ----------------------------------------------------------------------------
+# one rank
+# ----------------------------------------------------------------------------
+def run_rank(args):
+    from ghost_amd.dist import Comm, env_rank, shard_channels
+    from ghost_amd.engine import CwtPlan, DeviceBuffer, device_count, device_name
+    from ghost_amd._lib import lib, check
+    from ghost_amd.synthetic import lfp
+    import ctypes
+
+    rank, world, local = env_rank()
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if args.dry_run:                                # launcher rehearsal: no HIP call at all
+        path = os.path.join(args.dry_run, "rank%d.json" % rank)
+        json.dump({"rank": rank, "local_rank": local, "world": world,
+                   "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))},
+                  open(path, "w"))
+        if rank == 0:
+            emit({"dry_run": True, "n_gpus": world})
+        return 0
+    ndev = device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs an AMD GPU: libghostcwt has no CPU path")
+    if ndev < world and not os.environ.get("GHOSTCWT_ALLOW_SHARED_GPU"):
+        raise SystemExit("bench.py --gpus %d: only %d device(s) visible; ranks never share a GPU "
+                         "(GHOSTCWT_ALLOW_SHARED_GPU=1 to rehearse on one)" % (world, ndev))
+    dev = local % ndev
+    check(lib.gcwt_set_device(dev))
+
+    cfg5 = args.config == 5
+    fs = 30000.0 if cfg5 else 1000.0
+    C = args.channels or (48 if cfg5 else 128)
+    N = args.samples or (18000000 if cfg5 else 1000000)
+    S = args.scales or (200 if cfg5 else 100)
+    freqs = np.geomspace(500.0, 1.0, S) if cfg5 else np.geomspace(200.0, 2.0, S)
+    group = min(C, 8) if cfg5 else C                 # channels per plan execution
+    if C % group:
+        raise SystemExit("--channels must be a multiple of 8 for --config 5")
+    total_channels = C * world                       # weak scaling: fixed channels per GPU
+    c0, c1 = shard_channels(total_channels, rank, world)
+    assert c1 - c0 == C
+
+    comm = Comm(rank, world, device=dev)
+    t_plan = time.perf_counter()
+    plan = CwtPlan(N, group, fs, freqs, output=args.output, device=dev)
+    plan.upload()                                    # workspace, filter bank, FFT tables
+    check(lib.gcwt_device_synchronize())
+    plan_ms = (time.perf_counter() - t_plan) * 1e3   # reported apart from the timed steps
+    bank_via = comm.broadcast_bank(plan, root=0)
+    plan.set_profiling(True)
+    info = plan.info
+
+    # what this box's HBM delivers (measured once, before anything is timed)
+    ceilings = {}
+    if rank == 0 and not args.no_ceilings:
+        for key, pat in (("peak_measured_copy", 1), ("peak_measured_fill", 0), ("store_pattern_ceiling", 2)):
+            g = ctypes.c_double(0)
+            check(lib.gcwt_debug_bandwidth(pat, 12 << 30 if pat == 1 else 48 << 30, ctypes.byref(g)))
+            ceilings[key] = round(g.value, 1)
+    comm.barrier()
+
+    # synthetic LFP: 8 distinct generated channels per rank, tiled over the block
+    distinct = min(C, 8 if not cfg5 else 2)
+    base = lfp(distinct, N, fs, seed=1234 + 1000 * rank)
+    xbuf = DeviceBuffer(4 * C * N)
+    for c in range(C):
+        xbuf.upload(base[c % distinct], offset_bytes=4 * c * N)
+    b_out = 8 if args.output == "complex" else 4
+    segs = plan.segments()
+    if cfg5:
+        core = max(b - a for a, b, _ in segs)
+        ring = [DeviceBuffer(b_out * group * S * core) for _ in range(2)]
+
+        def step(stats):
+            k = 0
+            for g in range(C // group):
+                xg = ctypes.c_void_p(xbuf.ptr.value + 4 * g * group * N)
+                for i, (a, b, _) in enumerate(segs):
+                    plan.execute_block_device(xg, ring[k & 1], a, b - a, reuse_means=i > 0)
+                    k += 1
+                    tm = plan.timings()
+                    for key, v in tm.items():
+                        stats[key] = stats.get(key, 0) + v
+    else:
+        obuf = DeviceBuffer(info["out_bytes"])
+
+        def step(stats):
+            plan.execute_device(xbuf, obuf)          # returns after the stream has drained
+            for key, v in plan.timings().items():
+                stats[key] = stats.get(key, 0) + v
+
+    for _ in range(args.warmup):
+        step({})
+    check(lib.gcwt_device_synchronize())
+    comm.barrier()
+    stats = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(stats)
+    check(lib.gcwt_device_synchronize())
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = comm.allreduce_max(elapsed)
+
+    if rank == 0:
+        units = world * C * N * args.steps
+        value = units / elapsed / 1e6
+        launches = max(1, stats["synth_launches"])
+        k_ms = stats["synth_ms"] / launches
+        alg_step = C * N * (4 + S * b_out)           # SURVEY.md 8d: per channel-sample 4 + S*b_out
+        alg_launch = alg_step * args.steps / launches
+        achieved = alg_launch / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and (C, N, S, args.output, args.config) == (128, 1000000, 100, "amplitude", 3):
+            tj = json.load(open(tpath))
+            traffic = tj.get("k_synth_hbm_bytes_per_launch")
+            traffic_src = "profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+                          "this command, not measured in this run" % tj.get("round", "r01")
+        if cfg5:
+            workload = ("config 5: %d ch/GPU x %d samples @ 30 kHz x %d Morse scales 500..1 Hz, %s f32 out, "
+                        "streamed in %d time blocks x %d channel groups into a ring of 2 device buffers"
+                        % (C, N, S, args.output, len(segs), C // group))
+        else:
+            workload = ("%d ch/GPU x %d samples @ 1 kHz x %d Morse scales 200..2 Hz, %s f32 out, "
+                        "device-resident" % (C, N, S, args.output))
+        line = {
+            "metric": "Msamples/s CWT (128ch x 1e6 samp x 100 scales); % HBM roofline; 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic %g kHz LFP (pink noise + 8 Hz rhythm + 40 Hz bursts), "
+                    "%d generated channels tiled over each GPU's block" % (fs / 1e3, distinct),
+            "config": {"workload": workload, "channels_total": total_channels,
+                       "parallelism": "channel-sharded x%d" % world,
+                       "bank": bank_via, "comm": comm.backend, "device": device_name(dev),
+                       "plan_create_ms": round(plan_ms, 2),
+                       "scales": {"spectral": info["n_spectral"], "direct": info["n_direct"],
+                                  "fullband": info["n_fullband"]}},
+            "roofline": {"bound": "hbm", "kernel": "k_synth7", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_ms": round(k_ms, 4), "launches_per_step": launches // args.steps,
+                         "algorithmic_bytes": int(alg_launch), **ceilings,
+                         "limited_by": "package power (sclk held below 2 GHz with the HBM writes on: "
+                                       "DESIGN.md 5)"},
+            "stages_ms": {k: round(float(v) / args.steps, 4) for k, v in stats.items() if k.endswith("_ms")},
+            "whole_job_frac_of_hbm_peak": round(alg_step * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+        }
+        if ceilings:
+            line["roofline"]["frac_of_store_pattern_ceiling"] = round(
+                achieved / ceilings["store_pattern_ceiling"], 4)
+        if comm.rccl_error:
+            line["config"]["rccl_error"] = comm.rccl_error[:200]
+        if not cfg5 and not args.no_check:
+            ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct)
+            line["checked"] = ok
+            line["check"] = {"rows": "channels {0,7,C-1} x scales {0,57%,S-1} vs the oracle, "
+                                     "tiled channels c / c+%d bit-equal" % distinct,
+                             "worst_rel_err": float("%.3g" % worst)}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(fs, 1000000, freqs)
+        emit(line)
+    comm.close()
+    return 0
 
 
 def main():
@@ -55,107 +312,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--channels", type=int, default=128, help="channels per GPU")
-    ap.add_argument("--samples", type=int, default=1000000)
-    ap.add_argument("--scales", type=int, default=100)
+    ap.add_argument("--config", type=int, default=3, choices=[3, 5])
+    ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default 128; 48 for config 5)")
+    ap.add_argument("--samples", type=int, default=0)
+    ap.add_argument("--scales", type=int, default=0)
     ap.add_argument("--output", default="amplitude", choices=["amplitude", "power", "complex"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-ceilings", action="store_true")
+    ap.add_argument("--dry-run", default="", metavar="DIR",
+                    help="launcher rehearsal: every rank writes DIR/rank<r>.json and exits (no GPU)")
     args = ap.parse_args()
-
-    from ghost_amd.dist import Comm, env_rank, shard_channels
-    from ghost_amd.engine import CwtPlan, DeviceBuffer, device_count, device_name
-    from ghost_amd._lib import lib, check
-    from ghost_amd.synthetic import lfp
-
-    rank, world, local = env_rank()
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
-    ndev = device_count()
-    if ndev == 0:
-        raise SystemExit("bench.py needs an AMD GPU: libghostcwt has no CPU path")
-    dev = local % ndev
-    check(lib.gcwt_set_device(dev))
-
-    fs = 1000.0
-    C, N, S = args.channels, args.samples, args.scales
-    freqs = np.geomspace(200.0, 2.0, S)
-    total_channels = C * world                       # weak scaling: 128 channels per GPU
-    c0, c1 = shard_channels(total_channels, rank, world)
-    assert c1 - c0 == C
-
-    comm = Comm(rank, world, device=dev)
-    t_plan = time.perf_counter()
-    plan = CwtPlan(N, C, fs, freqs, output=args.output, device=dev)
-    plan.upload()                                    # workspace, filter bank, FFT tables
-    check(lib.gcwt_device_synchronize())
-    plan_ms = (time.perf_counter() - t_plan) * 1e3   # reported apart from the timed steps
-    bank_via = comm.broadcast_bank(plan, root=0)
-    plan.set_profiling(True)
-
-    # synthetic 1 kHz LFP: 8 distinct generated channels per rank, tiled over the block
-    distinct = min(C, 8)
-    base = lfp(distinct, N, fs, seed=1234 + 1000 * rank)
-    xbuf = DeviceBuffer(4 * C * N)
-    for c in range(C):
-        xbuf.upload(base[c % distinct], offset_bytes=4 * c * N)
-    obuf = DeviceBuffer(plan.info["out_bytes"])
-
-    for _ in range(args.warmup):
-        plan.execute_device(xbuf, obuf)
-    check(lib.gcwt_device_synchronize())
-    comm.barrier()
-    synth_ms, stage_ms = [], None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        plan.execute_device(xbuf, obuf)              # returns after the stream has drained
-        tm = plan.timings()
-        synth_ms.append(tm["synth_ms"] / max(1, tm["synth_launches"]))
-        stage_ms = tm
-    check(lib.gcwt_device_synchronize())
-    comm.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = comm.allreduce_max(elapsed)
-
-    if rank == 0:
-        b_out = 8 if args.output == "complex" else 4
-        units = world * C * N * args.steps
-        value = units / elapsed / 1e6
-        k_ms = float(np.mean(synth_ms))
-        alg_bytes = C * N * (4 + S * b_out)          # per channel-sample 4 + S*b_out
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and (C, N, S, args.output) == (128, 1000000, 100, "amplitude"):
-            traffic = json.load(open(tpath)).get("k_synth_hbm_bytes_per_launch")
-        line = {
-            "metric": "Msamples/s CWT (128ch x 1e6 samp x 100 scales); % HBM roofline; 1/2/4/8 GPU",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic 1 kHz LFP (pink noise + 8 Hz rhythm + 40 Hz bursts), "
-                    "%d generated channels tiled over each GPU's block" % distinct,
-            "config": {"workload": "%d ch/GPU x %d samples @ 1 kHz x %d Morse scales 200..2 Hz, "
-                                   "%s f32 out, device-resident" % (C, N, S, args.output),
-                       "channels_total": total_channels, "parallelism": "channel-sharded x%d" % world,
-                       "bank": bank_via, "comm": comm.backend, "device": device_name(dev),
-                       "plan_create_ms": round(plan_ms, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_synth7", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel_ms": round(k_ms, 4),
-                         "algorithmic_bytes": alg_bytes,
-                         "limited_by": "package power (1.3 of 1.4 kW, sclk ~1.9 GHz with the HBM "
-                                       "writes on: DESIGN.md 5, profiles/r01_power.txt)"},
-            "stages_ms": {k: round(float(v), 4) for k, v in stage_ms.items() if k.endswith("_ms")},
-            "whole_job_frac_of_hbm_peak": round(world and alg_bytes * args.steps / elapsed / 1e9
-                                                / HBM_PEAK_GBS, 4),
-        }
-        if comm.rccl_error:
-            line["config"]["rccl_error"] = comm.rccl_error[:200]
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(fs, N, freqs)
-        print(json.dumps(line), flush=True)
-    comm.close()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -64,20 +64,10 @@ Rccl& rccl() {
   return r;
 }
 
-// RCCL prints a version banner on stdout when it initialises.  A benchmark's stdout is
-// its result line, so anything RCCL says during set-up is sent to stderr instead.
-struct StdoutToStderr {
-  int saved = -1;
-  StdoutToStderr() {
-    fflush(stdout);
-    saved = dup(STDOUT_FILENO);
-    if (saved >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
-  }
-  ~StdoutToStderr() {
-    fflush(stdout);
-    if (saved >= 0) { dup2(saved, STDOUT_FILENO); close(saved); }
-  }
-};
+// RCCL may print a banner on stdout when it initialises.  This library never touches the
+// process's file descriptors to hide it (a redirect around a call that can block would
+// leave fd 1 pointing elsewhere): a caller whose stdout is a protocol keeps a private
+// copy of it and points fd 1 at stderr for the whole run, as bench.py does.
 
 }  // namespace
 
@@ -109,10 +99,7 @@ int gcwt_comm_unique_id(void* id128) {
   if (!r.ok) return cerr_(GCWT_ERR_COMM, "librccl not found or incomplete");
   ncclUniqueId id;
   ncclResult_t rc;
-  {
-    StdoutToStderr quiet;
-    rc = r.GetUniqueId(&id);
-  }
+  rc = r.GetUniqueId(&id);
   if (rc != 0) return nccl_fail("ncclGetUniqueId", rc);
   static_assert(sizeof(ncclUniqueId) == GCWT_COMM_ID_BYTES, "unique id size");
   memcpy(id128, &id, sizeof(id));
@@ -132,14 +119,11 @@ int gcwt_comm_create(gcwt_comm** out, int rank, int n_ranks, const void* id128) 
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   ncclResult_t rc;
-  {
-    StdoutToStderr quiet;
-    rc = r.CommInitRank(&c->comm, n_ranks, id, rank);
-  }
+  rc = r.CommInitRank(&c->comm, n_ranks, id, rank);
   if (rc != 0) { delete c; return nccl_fail("ncclCommInitRank", rc); }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void**)&c->d_val, sizeof(double)) != hipSuccess) {
-    { StdoutToStderr quiet; r.CommDestroy(c->comm); }
+    r.CommDestroy(c->comm);
     delete c;
     return cerr_(GCWT_ERR_HIP, "communicator scratch allocation failed");
   }
@@ -151,7 +135,7 @@ void gcwt_comm_destroy(gcwt_comm* c) {
   if (!c) return;
   if (c->d_val) (void)hipFree(c->d_val);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->comm) { StdoutToStderr quiet; rccl().CommDestroy(c->comm); }
+  if (c->comm) rccl().CommDestroy(c->comm);
   delete c;
 }
 
@@ -160,10 +144,7 @@ int gcwt_comm_allreduce_max(gcwt_comm* c, double* value) {
   if (hipMemcpyAsync(c->d_val, value, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess)
     return cerr_(GCWT_ERR_HIP, "copy to device failed");
   ncclResult_t rc;
-  {
-    StdoutToStderr quiet;
-    rc = rccl().AllReduce(c->d_val, c->d_val, 1, kNcclFloat64, kNcclMax, c->comm, c->stream);
-  }
+  rc = rccl().AllReduce(c->d_val, c->d_val, 1, kNcclFloat64, kNcclMax, c->comm, c->stream);
   if (rc != 0) return nccl_fail("ncclAllReduce", rc);
   if (hipMemcpyAsync(value, c->d_val, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize(c->stream) != hipSuccess)
@@ -183,13 +164,9 @@ int gcwt_comm_broadcast_bank(gcwt_comm* c, gcwt_plan* plan, int root) {
   size_t bytes = 0;
   float2* bank = gcwt_internal_bank_ptr(plan, &bytes);
   hipStream_t st = gcwt_internal_stream(plan);
-  ncclResult_t nr;
-  {
-    StdoutToStderr quiet;
-    nr = rccl().Broadcast(bank, bank, bytes, kNcclUint8, root, c->comm, st);
-  }
+  const ncclResult_t nr = rccl().Broadcast(bank, bank, bytes, kNcclUint8, root, c->comm, st);
   if (nr != 0) return nccl_fail("ncclBroadcast", nr);
-  if ((rc = gcwt_internal_refresh_bank(plan))) return rc;   // |H| table follows the bank
+  if ((rc = gcwt_internal_refresh_bank(plan))) return rc;   // signed gain table follows the bank
   if (hipStreamSynchronize(st) != hipSuccess) return cerr_(GCWT_ERR_HIP, "broadcast did not complete");
   return GCWT_OK;
 }

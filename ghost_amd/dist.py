@@ -143,6 +143,8 @@ class Comm:
                                        C.create_string_buffer(ident, COMM_ID_BYTES)))
             if not self._rccl_abandoned:
                 self._handle = h
+            else:                         # finished after the run gave up on it: do not leak it
+                lib.gcwt_comm_destroy(h)
         except Exception as e:            # RCCL missing / init failed: fall back to files
             self.rccl_error = "%s: %s" % (type(e).__name__, e)
             self._handle = None

@@ -29,6 +29,11 @@ int gcwt_debug_fetch(gcwt_plan* plan, int what, int channel, int epoch, int leve
  * (csrc/morse_exact.h).  Needs no GPU. */
 int gcwt_debug_exact_gain(const gcwt_plan* plan, int scale, const int64_t* a, int64_t b, int64_t n,
                           double* gain);
+/* Measurement only: GB/s this device reaches on `bytes` (>= 64 MiB) of HBM with a plain
+ * 16-byte fill, a 16-byte copy (read + write counted), or the store pattern of the
+ * synthesis kernel (128-byte runs into 100 rows a megasample apart).  Best of three. */
+enum { GCWT_BW_FILL = 0, GCWT_BW_COPY = 1, GCWT_BW_SYNTH_STORES = 2 };
+int gcwt_debug_bandwidth(int pattern, size_t bytes, double* gb_per_s);
 
 #ifdef __cplusplus
 }

@@ -102,3 +102,29 @@ def test_single_rank_comm_is_a_noop():
     assert c.backend == "single"
     c.barrier()
     assert c.allreduce_max(2.5) == 2.5
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` run bare starts N fresh rank processes itself (before any
+    HIP call), each with its own RANK / LOCAL_RANK and a shared rendezvous address; rank 0's
+    line is the only thing on stdout.  --dry-run stops every rank before it touches a GPU."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3",
+                          "--dry-run", str(tmp_path)], env=env, capture_output=True, timeout=120)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 3}
+    ranks = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(3)]
+    assert [r["rank"] for r in ranks] == [0, 1, 2]
+    assert [r["local_rank"] for r in ranks] == [0, 1, 2]
+    assert all(r["world"] == 3 for r in ranks)
+    assert len({r["master"] for r in ranks}) == 1 and ranks[0]["master"].startswith("127.0.0.1:")
+    # a mismatch between the launcher's world and --gpus is refused, not folded
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4",
+                          "--dry-run", str(tmp_path)], env=env2, capture_output=True, timeout=120)
+    assert res.returncode != 0 and b"WORLD_SIZE=2 but --gpus 4" in res.stderr

@@ -579,3 +579,32 @@ def test_fullband_path_long_kernels_epochs_and_blocks():
     assert len(p2.segments()) > 4
     got2 = p2.execute(x)
     assert rel_err(got2, np.abs(ref[:, :4])).max() < TOL
+
+
+def test_headline_workload_is_checked():
+    """BASELINE config 3 exactly as bench.py times it -- 128 ch x 1e6 samples x 100 scales,
+    amplitude, input and the 51 GB result resident in HBM: rows of channels {0, 7, 127} x
+    scales {0, 57, 99} against the oracle (transforms.py:187-204), and the tiled channels
+    c / c + 8 (same input) bit for bit."""
+    from ghost_amd.engine import CwtPlan, DeviceBuffer
+    from ghost_amd.synthetic import lfp
+    fs, C, N, S = 1000.0, 128, 1000000, 100
+    f = np.geomspace(200.0, 2.0, S)
+    plan = CwtPlan(N, C, fs, f, output="amplitude")
+    base = lfp(8, N, fs, seed=1234)
+    xbuf = DeviceBuffer(4 * C * N)
+    for c in range(C):
+        xbuf.upload(base[c % 8], offset_bytes=4 * c * N)
+    obuf = DeviceBuffer(plan.info["out_bytes"])
+    plan.execute_device(xbuf, obuf)
+    scales = [0, 57, 99]
+    for c in (0, 7, 127):
+        ref = orc.cwt_amplitude(base[c % 8].astype(np.float64), fs, f[scales])
+        for i, s in enumerate(scales):
+            row = obuf.download((N,), np.float32, offset_bytes=4 * (c * S + s) * N)
+            assert rel_err(row, ref[i]) < TOL, (c, s)
+            twin = c + 8 if c + 8 < C else c - 8
+            other = obuf.download((N,), np.float32, offset_bytes=4 * (twin * S + s) * N)
+            assert np.array_equal(row, other), (c, twin, s)
+    obuf.free()
+    xbuf.free()
