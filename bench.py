@@ -297,7 +297,7 @@ def run_rank(args):
         if not cfg5 and not args.no_check:
             ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct)
             line["checked"] = ok
-            line["check"] = {"rows": "channels {0,7,C-1} x scales {0,57%,S-1} vs the oracle, "
+            line["check"] = {"rows": "channels {0,7,C-1} x scales {0,57%%,S-1} vs the oracle, "
                                      "tiled channels c / c+%d bit-equal" % distinct,
                              "worst_rel_err": float("%.3g" % worst)}
         if world == 1 and not args.no_cpu_baseline:

@@ -95,6 +95,7 @@ def _load():
         "gcwt_debug_batch_of": (C.c_int, [vp, C.c_int, i32p, i32p]),
         "gcwt_debug_level_info": (C.c_int, [vp, C.c_int, C.c_int, i32p, i32p, i32p, i32p, i64p]),
         "gcwt_debug_exact_gain": (C.c_int, [vp, C.c_int, i64p, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
+        "gcwt_debug_clock": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "gcwt_debug_bandwidth": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_double)]),
         "gcwt_debug_fetch": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int64]),
     }

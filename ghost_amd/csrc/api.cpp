@@ -72,6 +72,8 @@ struct gcwt_plan {
   bool uploaded = false;
   bool profiling = false;
   int synth_cols = 32;        // columns per workgroup of k_synth7 (GHOSTCWT_SYNTH_COLS=16|32)
+  int synth_kernel = 7;       // 7: k_synth7; 8: producer/consumer waves (synth8.hip, measured slower:
+                              // DESIGN.md 5) -- GHOSTCWT_SYNTH_KERNEL
   bool use_synth16 = false;   // GHOSTCWT_SYNTH16=1: 16-column kernel for every output mode (A/B tests)
   int device = -1;
   hipStream_t stream = nullptr;
@@ -83,6 +85,7 @@ struct gcwt_plan {
   float* d_gain = nullptr;    // [S][B] |H|
   float2* d_half_tw = nullptr; // [levels][256] exp(-i pi k/(256 R))
   float2* d_psi = nullptr;    // direct kernels
+  unsigned long long* d_probe = nullptr;   // GHOSTCWT_CLOCK_PROBE=1: [cycles, 100 MHz ticks] of the synthesis workgroups
   double* d_amps = nullptr;   // kept spectrum samples A_j of every scale (planner.h: amps)
   float2* d_z = nullptr;      // [C][max_p]   full-band scales: spectrum * response, then its IFFT
   float2* d_hfull = nullptr;  // [max_p]      full-band response of the scale in hand
@@ -131,7 +134,7 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
-  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
+  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
@@ -203,7 +206,9 @@ int gcwt_device_name(int device, char* buf, size_t buflen) {
   if (!buf || buflen == 0) return set_err(GCWT_ERR_INVALID, "buf is NULL");
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
-  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  // some driver stacks leave prop.name empty: say so rather than print a blank
+  snprintf(buf, buflen, "%s (%s, %d CUs, %.0f GiB)", prop.name[0] ? prop.name : "AMD GPU (unnamed by the driver)",
+           prop.gcnArchName, prop.multiProcessorCount, (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
   return GCWT_OK;
 }
 
@@ -242,6 +247,7 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->device = params->device;
   if (const char* e = getenv("GHOSTCWT_SYNTH16")) p->use_synth16 = e[0] == '1';
   if (const char* e = getenv("GHOSTCWT_SYNTH_COLS")) p->synth_cols = atoi(e) == 16 ? 16 : 32;
+  if (const char* e = getenv("GHOSTCWT_SYNTH_KERNEL")) p->synth_kernel = atoi(e) == 8 ? 8 : 7;
   for (const auto& s : p->hp.scales)
     if (s.method == GCWT_SCALE_DIRECT) p->max_direct_len = std::max(p->max_direct_len, s.length);
   *out = p;
@@ -343,6 +349,11 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     }
   }
   if ((rc = upload_vec(&p->d_amps, hp.amps, p->stream))) return bail(rc);
+  if (getenv("GHOSTCWT_CLOCK_PROBE")) {
+    if ((rc = dev_alloc(&p->d_probe, 2))) return bail(rc);
+    hipError_t he0 = hipMemsetAsync(p->d_probe, 0, 16, p->stream);
+    if (he0 != hipSuccess) return bail(hip_err(he0, "probe reset"));
+  }
   if ((rc = dev_alloc(&p->d_bank, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_gain, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_psi, (size_t)hp.direct_total))) return bail(rc);
@@ -589,9 +600,13 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       a7.xb_cstride = hp.max_xb;
       a7.row_len = row_len;
       a7.n_scales = S;
-      a7.drop_stores = getenv("GHOSTCWT_SYNTH_DROP_STORES") != nullptr;   // tools/stage_times.py ablation
+      if (const char* e = getenv("GHOSTCWT_SYNTH_DROP_STORES")) a7.drop_stores = std::max(1, atoi(e));   // tools/stage_times.py ablations
       a7.seg = sout;
-      RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, dev.n_items7, slots, st));
+      a7.clock_probe = p->d_probe;
+      if (p->synth_kernel == 8)
+        RUN(ST_SYNTH, launch_synth8(mode, p->synth_cols, a7, dev.n_items7, slots, st));
+      else
+        RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, dev.n_items7, slots, st));
     }
     if (p->profiling && !hp.levels.empty()) p->last.synth_launches++;
     // full-band scales: W = IFFT_P(X H_s), one scale at a time for every slot of the batch
@@ -692,15 +707,7 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
     const size_t k = hp.out_elem_bytes / sizeof(float);
     hipError_t he = p->host_out.drain(dout, k * (size_t)row_len, rows, k * (size_t)n_out, out,
                                       (flags & GCWT_OUT_F64) != 0, p->stream);
-    if (he == hipErrorInvalidValue && !(flags & GCWT_OUT_F64)) {   // rows beyond the staging size
-      (void)hipGetLastError();
-      HIP_TRY(hipMemcpy2DAsync(out, hp.out_elem_bytes * (size_t)n_out, dout,
-                               hp.out_elem_bytes * (size_t)row_len, hp.out_elem_bytes * (size_t)n_out,
-                               rows, hipMemcpyDeviceToHost, p->stream));
-    } else if (he == hipErrorInvalidValue) {
-      (void)hipStreamSynchronize(p->stream);
-      return set_err(GCWT_ERR_UNSUPPORTED, "GCWT_OUT_F64 needs rows of at most 8M samples: use gcwt_execute_block");
-    } else if (he != hipSuccess) {
+    if (he != hipSuccess) {
       return hip_err(he, "host_out.drain");
     }
   }
@@ -926,6 +933,17 @@ int gcwt_debug_exact_gain(const gcwt_plan* p, int scale, const int64_t* a, int64
   const ScalePlan& s = p->hp.scales[scale];
   for (int64_t i = 0; i < n; ++i)
     gain[i] = exact_gain(p->hp.amps.data() + s.amp_offset, s.bin_lo, s.n_bins, s.length, a[i], b);
+  return GCWT_OK;
+}
+
+int gcwt_debug_clock(gcwt_plan* p, double* ghz, double* workgroup_seconds) {
+  if (!p || !ghz) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  if (!p->d_probe) return set_err(GCWT_ERR_INVALID, "plan was not created with GHOSTCWT_CLOCK_PROBE=1");
+  unsigned long long v[2] = {0, 0};
+  HIP_TRY(hipMemcpy(v, p->d_probe, sizeof(v), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(p->d_probe, 0, sizeof(v)));
+  *ghz = v[1] ? (double)v[0] / (double)v[1] * 0.1 : 0.0;
+  if (workgroup_seconds) *workgroup_seconds = (double)v[1] * 1e-8;
   return GCWT_OK;
 }
 

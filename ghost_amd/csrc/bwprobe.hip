@@ -17,9 +17,14 @@ __global__ void bw_fill128(float4* p, size_t n, float v) {
   const float4 q = make_float4(v, v, v, v);
   for (; i < n; i += st) p[i] = q;
 }
+// four 16-byte loads in flight per thread before the first store
 __global__ void bw_copy128(const float4* a, float4* b, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t st = (size_t)gridDim.x * blockDim.x;
+  for (; i + 3 * st < n; i += 4 * st) {
+    const float4 q0 = a[i], q1 = a[i + st], q2 = a[i + 2 * st], q3 = a[i + 3 * st];
+    b[i] = q0; b[i + st] = q1; b[i + 2 * st] = q2; b[i + 3 * st] = q3;
+  }
   for (; i < n; i += st) b[i] = a[i];
 }
 // synthesis-like pattern: a workgroup of 512 threads writes 14 runs of 32 consecutive floats
@@ -53,7 +58,7 @@ extern "C" int gcwt_debug_bandwidth(int pattern, size_t bytes, double* gb_per_s)
       hipLaunchKernelGGL(bw_fill128, dim3(2048), dim3(256), 0, 0, (float4*)a, bytes / 16, 1.f);
       moved = (double)bytes;
     } else if (pattern == GCWT_BW_COPY) {
-      hipLaunchKernelGGL(bw_copy128, dim3(2048), dim3(256), 0, 0, (const float4*)a, (float4*)b, bytes / 16);
+      hipLaunchKernelGGL(bw_copy128, dim3(4096), dim3(256), 0, 0, (const float4*)a, (float4*)b, bytes / 16);
       moved = 2.0 * (double)bytes;
     } else {
       const size_t row_len = 1000000 / 32 * 32 + 32;

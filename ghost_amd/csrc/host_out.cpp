@@ -1,6 +1,7 @@
 #include "host_out.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -52,18 +53,29 @@ hipError_t HostOut::drain(const float* d_src, size_t src_pitch_floats, size_t n_
     if (!landed_[i] && (e = hipEventCreateWithFlags(&landed_[i], hipEventDisableTiming)) != hipSuccess)
       return e;
   }
-  const size_t row_bytes = row_floats * sizeof(float);
-  if (row_bytes > kChunkBytes) {
-    // rows longer than a staging buffer (> 8 M samples): plain strided copy, widen in place
-    // is not possible -- the caller falls back to float32 + its own conversion
-    return hipErrorInvalidValue;
-  }
-  const size_t rows_per = std::max<size_t>(1, kChunkBytes / row_bytes);
-  const size_t n_chunks = (n_rows + rows_per - 1) / rows_per;
+  // Tiles of the result: whole rows while they fit a staging buffer, else pieces of one
+  // row (recordings longer than 8 M samples), so any row length streams through the ring.
+  size_t chunk_floats = kChunkBytes / sizeof(float);
+  if (const char* env = getenv("GHOSTCWT_STAGE_FLOATS"))   // tests: force small tiles
+    chunk_floats = std::min(chunk_floats, std::max<size_t>(64, (size_t)atoll(env)));
+  const size_t cols_per = std::min(row_floats, chunk_floats);
+  const size_t rows_per = std::max<size_t>(1, chunk_floats / cols_per);
+  const size_t col_tiles = (row_floats + cols_per - 1) / cols_per;
+  const size_t row_tiles = (n_rows + rows_per - 1) / rows_per;
+  const size_t n_chunks = row_tiles * col_tiles;
+  struct Tile { size_t r0, nr, c0, nc; };
+  auto tile = [&](size_t c) {
+    const size_t rt = c / col_tiles, ct = c % col_tiles;
+    Tile t{rt * rows_per, 0, ct * cols_per, 0};
+    t.nr = std::min(rows_per, n_rows - t.r0);
+    t.nc = std::min(cols_per, row_floats - t.c0);
+    return t;
+  };
   auto issue = [&](size_t c) -> hipError_t {
-    const size_t r0 = c * rows_per, nr = std::min(rows_per, n_rows - r0);
-    hipError_t er = hipMemcpy2DAsync(ring_[c & 1], row_bytes, d_src + r0 * src_pitch_floats,
-                                     src_pitch_floats * sizeof(float), row_bytes, nr,
+    const Tile t = tile(c);
+    hipError_t er = hipMemcpy2DAsync(ring_[c & 1], t.nc * sizeof(float),
+                                     d_src + t.r0 * src_pitch_floats + t.c0,
+                                     src_pitch_floats * sizeof(float), t.nc * sizeof(float), t.nr,
                                      hipMemcpyDeviceToHost, stream);
     if (er != hipSuccess) return er;
     return hipEventRecord(landed_[c & 1], stream);
@@ -72,17 +84,18 @@ hipError_t HostOut::drain(const float* d_src, size_t src_pitch_floats, size_t n_
   for (size_t c = 0; c < n_chunks; ++c) {
     if (c + 1 < n_chunks && (e = issue(c + 1)) != hipSuccess) return e;   // other buffer: free
     if ((e = hipEventSynchronize(landed_[c & 1])) != hipSuccess) return e;
-    const size_t r0 = c * rows_per, nr = std::min(rows_per, n_rows - r0);
+    const Tile t = tile(c);
     const float* src = ring_[c & 1];
     if (widen) {
-      double* out = static_cast<double*>(dst) + r0 * row_floats;
-      parallel_rows(nr, nr * row_bytes, [=](size_t a, size_t b) {
-        widen_row(src + a * row_floats, out + a * row_floats, (b - a) * row_floats);
+      double* out = static_cast<double*>(dst) + t.r0 * row_floats + t.c0;
+      parallel_rows(t.nr, t.nr * t.nc * sizeof(float), [=](size_t a, size_t b) {
+        for (size_t r = a; r < b; ++r) widen_row(src + r * t.nc, out + r * row_floats, t.nc);
       });
     } else {
-      float* out = static_cast<float*>(dst) + r0 * row_floats;
-      parallel_rows(nr, nr * row_bytes, [=](size_t a, size_t b) {
-        std::memcpy(out + a * row_floats, src + a * row_floats, (b - a) * row_bytes);
+      float* out = static_cast<float*>(dst) + t.r0 * row_floats + t.c0;
+      parallel_rows(t.nr, t.nr * t.nc * sizeof(float), [=](size_t a, size_t b) {
+        for (size_t r = a; r < b; ++r)
+          std::memcpy(out + r * row_floats, src + r * t.nc, t.nc * sizeof(float));
       });
     }
   }

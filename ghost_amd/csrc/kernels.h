@@ -97,12 +97,18 @@ struct Synth7Args {
   float* out;
   int64_t xb_cstride;
   int64_t row_len;       // samples per (channel, scale) row of out
+  unsigned long long* clock_probe;   // measurement only (GHOSTCWT_CLOCK_PROBE=1): [0] += shader cycles,
+                                     // [1] += 100 MHz ticks each workgroup lived; NULL in normal runs
   int32_t n_scales;
-  int32_t drop_stores;   // measurement only: stores get an empty range (kernel time without HBM writes)
+  int32_t drop_stores;   // measurement only (GHOSTCWT_SYNTH_DROP_STORES=bits; results are WRONG): 1 stores get
+                         // an empty range (kernel time without HBM writes), 2 no workgroup barriers
   SegOut seg;
 };
 
 hipError_t launch_synth7(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
+                         hipStream_t st);
+// same work items and arguments as launch_synth7 (synth8.hip)
+hipError_t launch_synth8(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
                          hipStream_t st);
 
 hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,

@@ -29,6 +29,11 @@ int gcwt_debug_fetch(gcwt_plan* plan, int what, int channel, int epoch, int leve
  * (csrc/morse_exact.h).  Needs no GPU. */
 int gcwt_debug_exact_gain(const gcwt_plan* plan, int scale, const int64_t* a, int64_t b, int64_t n,
                           double* gain);
+/* Measurement only, plans uploaded with GHOSTCWT_CLOCK_PROBE=1 in the environment: the shader
+ * clock the synthesis workgroups ran at since the last call (sum of s_memtime deltas over
+ * sum of s_memrealtime deltas, one pair per workgroup: MI355X_MICROARCH.md "DVFS
+ * give-back" item 6) and the summed workgroup lifetimes. */
+int gcwt_debug_clock(gcwt_plan* plan, double* ghz, double* workgroup_seconds);
 /* Measurement only: GB/s this device reaches on `bytes` (>= 64 MiB) of HBM with a plain
  * 16-byte fill, a 16-byte copy (read + write counted), or the store pattern of the
  * synthesis kernel (128-byte runs into 100 rows a megasample apart).  Best of three. */

@@ -608,3 +608,29 @@ def test_headline_workload_is_checked():
             assert np.array_equal(row, other), (c, twin, s)
     obuf.free()
     xbuf.free()
+
+
+def test_host_results_of_any_row_length(monkeypatch):
+    """Host output streams through pinned staging tiles; rows longer than a tile (recordings
+    beyond 8 M samples with the real 32 MB tiles) are cut by columns.  Forced here with
+    small tiles: float64 (the reference's dtype, transform()'s default) and float32,
+    amplitude and complex, must equal the untiled result."""
+    from ghost_amd.synthetic import lfp
+    fs, n = 1000.0, 30011
+    x = lfp(2, n, fs)
+    f = [120.0, 30.0, 9.0]
+    for output in ("amplitude", "complex"):
+        p, ref = _plan(x, fs, f, output=output)
+        ref64 = p.execute(x, wide=True)
+        np.testing.assert_array_equal(ref64, ref.astype(ref64.dtype))
+        monkeypatch.setenv("GHOSTCWT_STAGE_FLOATS", "4099")
+        np.testing.assert_array_equal(p.execute(x), ref)
+        np.testing.assert_array_equal(p.execute(x, wide=True), ref64)
+        np.testing.assert_array_equal(p.execute_block(x, 1234, 20000, wide=True), ref64[:, :, 1234:21234])
+        monkeypatch.delenv("GHOSTCWT_STAGE_FLOATS")
+    cwt = _cwt(x[0], fs, freq_limits=[10, 100], voices_per_octave=4)
+    a = cwt.amplitude.copy()
+    monkeypatch.setenv("GHOSTCWT_STAGE_FLOATS", "1000")
+    cwt2 = _cwt(x[0], fs, freq_limits=[10, 100], voices_per_octave=4)
+    assert cwt2.amplitude.dtype == np.float64
+    np.testing.assert_array_equal(cwt2.amplitude, a)

@@ -14,5 +14,12 @@ for it in range(reps+2):
     plan.execute_device(xb,ob)
     tm=plan.timings()
     if it>=2: syn.append(tm['synth_ms']); tot.append(tm['total_ms'])
-print(os.environ.get("QB_TAG",""), "synth min %.3f med %.3f | total min %.3f med %.3f"%(min(syn), np.median(syn), min(tot), np.median(tot)),
+clk=""
+if os.environ.get("GHOSTCWT_CLOCK_PROBE"):
+    import ctypes
+    from ghost_amd._lib import lib, check
+    g=ctypes.c_double(); w=ctypes.c_double()
+    check(lib.gcwt_debug_clock(plan._handle, ctypes.byref(g), ctypes.byref(w)))
+    clk=" | synth clock %.3f GHz, workgroup-seconds/launch %.4f"%(g.value, w.value/(reps+2))
+print(os.environ.get("QB_TAG","")+clk, "synth min %.3f med %.3f | total min %.3f med %.3f"%(min(syn), np.median(syn), min(tot), np.median(tot)),
       {k:round(v,3) for k,v in tm.items() if k.endswith('_ms') and k not in ('synth_ms','total_ms')})
