@@ -634,3 +634,131 @@ def test_host_results_of_any_row_length(monkeypatch):
     cwt2 = _cwt(x[0], fs, freq_limits=[10, 100], voices_per_octave=4)
     assert cwt2.amplitude.dtype == np.float64
     np.testing.assert_array_equal(cwt2.amplitude, a)
+
+
+class _FakeASA:
+    """Duck-typed nelpy.RegularlySampledAnalogSignalArray (nelpy is not installable here):
+    the attributes ghost/formats/preprocessing.py:78-114 and postprocessing.py:55-59 read."""
+
+    def __init__(self, data_rowsig, fs, lengths, gap=5.0):
+        self._data_rowsig = np.asarray(data_rowsig)
+        self._data_colsig = self._data_rowsig.T
+        self.data = self._data_rowsig
+        self.n_signals = self._data_rowsig.shape[0]
+        self.fs = fs
+        self.lengths = np.asarray(lengths)
+        t = np.arange(self._data_rowsig.shape[1]) / fs
+        for e in np.cumsum(lengths)[:-1]:
+            t[e:] += gap
+        self.abscissa_vals = t
+        self.support = "support-of-the-input"
+
+
+def test_nelpy_round_trip_end_to_end(monkeypatch):
+    """a two-epoch, three-signal ASA in -> transform() on the GPU -> result
+    wrapped back into an AnalogSignalArray.  Input side: ghost/formats/preprocessing.py:78-114
+    (epochs from the ASA's lengths -- cumulative); output side:
+    ghost/formats/postprocessing.py:41-65 against a stub nelpy module."""
+    import sys
+    import types
+    from ghost_amd.wave import ContinuousWaveletTransform
+    from ghost_amd.formats import output_numpy_or_asa
+    from ghost_amd.synthetic import lfp
+    fs = 1000.0
+    lengths = [5200, 3300]
+    x = lfp(3, sum(lengths), fs, seed=77)
+    asa = _FakeASA(x, fs, lengths)
+    cwt = ContinuousWaveletTransform()
+    cwt.transform(asa, multichannel=True, freq_limits=[12, 300], voices_per_octave=4)
+    f = cwt.frequencies
+    assert cwt.fs == fs and cwt.amplitude.shape == (3, f.size, sum(lengths))
+    eb = np.array([[0, 5200], [5200, 8500]])
+    for c in range(3):          # the reference handles one signal per call (transforms.py:57-58)
+        ref = orc.cwt_amplitude(x[c].astype(np.float64), fs, f, eb)
+        assert rel_err(cwt.amplitude[c], ref).max() < TOL, c
+    # one-signal ASA through the reference's own signature (n_signals = 1, no flag)
+    one = _FakeASA(x[1:2], fs, lengths)
+    cwt1 = ContinuousWaveletTransform()
+    cwt1.transform(one, freq_limits=[12, 300], voices_per_octave=4)
+    np.testing.assert_array_equal(cwt1.amplitude, cwt.amplitude[1])
+    np.testing.assert_array_equal(cwt1.time, one.abscissa_vals)
+
+    # output adapter with a stub nelpy (postprocessing.py:55-59 builds the ASA around the input)
+    made = {}
+
+    class StubASA:
+        def __init__(self, data, *, abscissa_vals, fs, support, labels=None):
+            made.update(data=data, abscissa_vals=abscissa_vals, fs=fs, support=support, labels=labels)
+
+    stub = types.ModuleType("nelpy")
+    stub.AnalogSignalArray = StubASA
+    stub.RegularlySampledAnalogSignalArray = _FakeASA
+    monkeypatch.setitem(sys.modules, "nelpy", stub)
+    spectrogram = cwt1.amplitude.T                        # (n_samples, n_freqs): one signal per scale
+    out = output_numpy_or_asa(one, spectrogram, output_type="asa", labels=["%.1f Hz" % v for v in f])
+    assert isinstance(out, StubASA)
+    assert made["data"].shape == (f.size, sum(lengths))   # ASAs are (n_signals, n_samples)
+    np.testing.assert_array_equal(made["data"], cwt1.amplitude)
+    np.testing.assert_array_equal(made["abscissa_vals"], one.abscissa_vals)
+    assert made["fs"] == fs and made["support"] == "support-of-the-input" and len(made["labels"]) == f.size
+    assert output_numpy_or_asa(one, spectrogram) is spectrogram
+    with pytest.raises(TypeError):
+        output_numpy_or_asa(np.zeros(3), spectrogram, output_type="asa")
+
+
+def test_role_split_synthesis_kernel_matches(monkeypatch):
+    """k_synth8 (producer / consumer waves, kept selectable as a measured alternative) gives
+    the same numbers as the production kernel, every output mode, 16 and 32 columns."""
+    from ghost_amd.synthetic import lfp
+    fs = 1000.0
+    x = lfp(2, 40000, fs)
+    f = np.geomspace(180.0, 3.0, 37)
+    eb = [[0, 15000], [15003, 40000]]
+    for output in ("amplitude", "power", "complex"):
+        monkeypatch.delenv("GHOSTCWT_SYNTH_KERNEL", raising=False)
+        p7, ref = _plan(x, fs, f, output=output, epoch_bounds=eb)
+        for cols in ("32", "16"):
+            monkeypatch.setenv("GHOSTCWT_SYNTH_KERNEL", "8")
+            monkeypatch.setenv("GHOSTCWT_SYNTH_COLS", cols)
+            p8, got = _plan(x, fs, f, output=output, epoch_bounds=eb)
+            scale = np.abs(ref).max(axis=-1, keepdims=True)
+            assert (np.abs(got - ref) / scale).max() < 2e-6, (output, cols)
+        monkeypatch.delenv("GHOSTCWT_SYNTH_COLS")
+
+
+def test_config5_regime_streamed_multichannel():
+    """BASELINE config 5 at a size the oracle can follow: 3 channels @ 30 kHz, all 200 scales
+    1-500 Hz (418 430-tap kernel at 1 Hz), the recording cut into overlapping time blocks that
+    are streamed one by one into a device buffer (execute_block_device, as bench.py
+    --config 5 does) by two 'ranks' that share the blocks (shard_time_blocks): the assembled
+    result against the oracle on every 12th scale and the 1 Hz one, and against the
+    whole-array call bit for bit."""
+    from ghost_amd.dist import shard_time_blocks
+    from ghost_amd.engine import CwtPlan, DeviceBuffer
+    from ghost_amd.synthetic import lfp
+    fs, C, n, S = 30000.0, 3, 2600000, 200
+    f = np.geomspace(500.0, 1.0, S)
+    x = lfp(C, n, fs, seed=505)
+    plan = CwtPlan(n, C, fs, f, output="amplitude", max_fft_log2=21)
+    segs = plan.segments()
+    assert len(segs) >= 2 and all(s[2] == 1 << 21 for s in segs)
+    assert plan.info["n_spectral"] == S and plan.scale_info()["decimation"].max() >= 8192
+    xb = DeviceBuffer(x.nbytes)
+    xb.upload(x)
+    core = max(b - a for a, b, _ in segs)
+    ring = DeviceBuffer(4 * C * S * core)
+    out = np.empty((C, S, n), dtype=np.float32)
+    first = True
+    for rank in range(2):
+        lo, hi = shard_time_blocks(segs, rank, 2)
+        for a, b, _ in segs:
+            if lo <= a < hi:
+                plan.execute_block_device(xb, ring, a, b - a, reuse_means=not first)
+                first = False
+                out[:, :, a:b] = ring.download((C, S, b - a), np.float32)
+    picks = sorted(set(range(0, S, 12)) | {S - 1})
+    for c in range(C):
+        ref = orc.cwt_amplitude(x[c].astype(np.float64), fs, f[picks], n_threads=8)
+        assert rel_err(out[c][picks], ref).max() < TOL, c
+    whole = plan.execute(x)
+    np.testing.assert_array_equal(whole, out)
