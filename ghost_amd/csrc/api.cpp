@@ -357,6 +357,10 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   if ((rc = dev_alloc(&p->d_bank, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_gain, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_psi, (size_t)hp.direct_total))) return bail(rc);
+  {   // every kernel is followed by zero taps up to a multiple of 8 (+8): k_direct reads whole groups
+    hipError_t hz = hipMemsetAsync(p->d_psi, 0, sizeof(float2) * (size_t)std::max<int64_t>(1, hp.direct_total), p->stream);
+    if (hz != hipSuccess) return bail(hip_err(hz, "psi reset"));
+  }
   if ((rc = dev_alloc(&p->d_sums, (size_t)C))) return bail(rc);
 
   // tables, computed in double on the host
@@ -630,7 +634,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     auto flush = [&]() -> int {
       if (ne > 0)
         RUN(ST_DIRECT, launch_direct(mode, dx, dout, p->d_psi, p->d_direct_sc, hp.n_direct, p->d_sums,
-                                     inv_n, N, S, eps, ne, r0, row_len, st));
+                                     inv_n, N, S, eps, ne, r0, row_len, p->max_direct_len, st));
       ne = 0;
       return GCWT_OK;
     };

@@ -156,7 +156,7 @@ struct DirectEpochs {                // time-domain scales: epochs handled by on
 hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi,
                          const DirectScale* sc, int n_direct, const double* sums, double inv_n,
                          int64_t n_samples, int n_scales, const DirectEpochs& eps, int n_epochs,
-                         int64_t col0, int64_t row_len, hipStream_t st);
+                         int64_t col0, int64_t row_len, int64_t max_len, hipStream_t st);
 hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_t p1_stride,
                               int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,
                               int n_channels, hipStream_t st);

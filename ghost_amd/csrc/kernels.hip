@@ -775,41 +775,89 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
 
 // ---------------------------------------------------------------------------
 // Direct scales: W[n] = sum_j (x[n + (L-1)/2 - j] - mean) psi[j] inside the epoch
-// (convolution.py:68-87 'same' crop; transforms.py:202-204).
-// grid (ceil(longest range/256), n_direct, n_epochs * C): up to 16 epochs per launch
+// (convolution.py:68-87 'same' crop; transforms.py:202-204), for kernels of up to
+// kDirectTaps taps.
+//
+// One workgroup owns kDirectTile consecutive output samples of one (epoch, channel): it
+// parks the samples those outputs need (tile + half the longest kernel on either side,
+// mean removed, zero outside the epoch) in LDS once and walks over ALL direct scales.
+// A thread computes 8 consecutive outputs; taps go in groups of 8, so the 15 samples a
+// group needs sit in registers with static indices (64 complex-by-real FMAs per 8 LDS
+// reads), and the taps themselves are wave-uniform: scalar loads, SGPR operands.  LDS
+// element i lives at i + i/8, which spreads the lanes' stride-8 reads over all banks.
+// psi of a scale is padded with zeros to a multiple of 8 taps (+8).
+// grid (ceil(longest range / kDirectTile), 1, n_epochs * C): up to 16 epochs per launch
 // ---------------------------------------------------------------------------
+constexpr int kDirectTile = 2048;     // outputs per workgroup: 256 threads x 8
+
+__device__ __forceinline__ int direct_pad(int i) { return i + (i >> 3); }
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, float* __restrict__ out,
                                                 const cf* __restrict__ psi,
-                                                const DirectScale* __restrict__ sc,
+                                                const DirectScale* __restrict__ sc, int n_direct,
                                                 const double* __restrict__ sums, double inv_n,
                                                 int64_t n_samples, int n_scales,
                                                 const DirectEpochs eps, int64_t col0,
-                                                int64_t row_len) {
+                                                int64_t row_len, int halo) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const tile = reinterpret_cast<float*>(smem);
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
-  const DirectScale p = sc[blockIdx.y];
   const int e = blockIdx.z / eps.n_channels, c = blockIdx.z - e * eps.n_channels;
   const int64_t epoch_start = eps.epoch_start[e], epoch_len = eps.epoch_len[e];
-  const int64_t gn = eps.g_lo[e] + (int64_t)blockIdx.x * 256 + threadIdx.x;   // sample of the recording
-  if (gn >= eps.g_hi[e]) return;
-  const int64_t n = gn - epoch_start;                                  // index in the epoch
+  const int64_t g0 = eps.g_lo[e] + (int64_t)blockIdx.x * kDirectTile;   // first output, recording index
+  if (g0 >= eps.g_hi[e]) return;
+  const int64_t base = g0 - epoch_start;                               // epoch-local index of output 0
   const float mean = (float)(sums[c] * inv_n);
   const float* xe = x + (int64_t)c * n_samples + epoch_start;
-  const cf* k = psi + p.offset;
-  const int64_t top = n + (p.length - 1) / 2;
-  float re = 0.f, im = 0.f;
-  for (int64_t j = 0; j < p.length; ++j) {
-    const int64_t m = top - j;
-    if (m >= 0 && m < epoch_len) {
-      const float xv = xe[m] - mean;
-      re += xv * k[j].x;
-      im += xv * k[j].y;
+  // tile[i] = sample base - halo + i of the epoch
+  const int n_tile = kDirectTile + 2 * halo;
+  for (int i = threadIdx.x; i < n_tile; i += 256) {
+    const int64_t m = base - halo + i;
+    tile[direct_pad(i)] = m >= 0 && m < epoch_len ? xe[m] - mean : 0.f;
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  for (int d = 0; d < n_direct; ++d) {
+    const DirectScale p = sc[d];
+    const cf* const taps = psi + p.offset;
+    const int top = (int)((p.length - 1) / 2);
+    // output o of this thread reads tile[q0 + o - j] for tap j
+    const int q0 = 8 * tid + top + halo;
+    float ar[8], ai[8], w[15];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) ar[o] = ai[o] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) w[i + 8] = tile[direct_pad(q0 + 1 + i)];   // indices q0+1 .. q0+7
+    const int n_groups = (int)((p.length + 7) >> 3);
+    for (int g = 0; g < n_groups; ++g) {
+      const int jg = 8 * g;
+      // w[i] = tile[q0 - jg - 7 + i], i < 15: the upper 7 come from the previous group
+#pragma unroll
+      for (int i = 0; i < 7; ++i) w[i + 8] = g == 0 ? w[i + 8] : w[i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = tile[direct_pad(q0 - jg - 7 + i)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const cf k = taps[jg + u];                // wave-uniform: scalar load
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          ar[o] = fmaf(w[7 - u + o], k.x, ar[o]);
+          ai[o] = fmaf(w[7 - u + o], k.y, ai[o]);
+        }
+      }
+    }
+    float* o_row = out + (((int64_t)c * n_scales + p.scale) * row_len + (g0 - col0) + 8 * tid) * kElem;
+    const int64_t left = eps.g_hi[e] - g0 - 8 * tid;     // outputs of this thread inside the range
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      if (o < left) {
+        if (MODE == GCWT_OUT_AMPLITUDE_F32) o_row[o] = sqrtf(ar[o] * ar[o] + ai[o] * ai[o]);
+        else if (MODE == GCWT_OUT_POWER_F32) o_row[o] = ar[o] * ar[o] + ai[o] * ai[o];
+        else { o_row[2 * o] = ar[o]; o_row[2 * o + 1] = ai[o]; }
+      }
     }
   }
-  float* o = out + (((int64_t)c * n_scales + p.scale) * row_len + (gn - col0)) * kElem;
-  if (MODE == GCWT_OUT_AMPLITUDE_F32) o[0] = sqrtf(re * re + im * im);
-  else if (MODE == GCWT_OUT_POWER_F32) o[0] = re * re + im * im;
-  else { o[0] = re; o[1] = im; }
 }
 
 // ---------------------------------------------------------------------------
@@ -1120,14 +1168,18 @@ hipError_t launch_synth(int mode, const SynthArgs& a, int n_items, int n_channel
 hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, const DirectScale* sc,
                          int n_direct, const double* sums, double inv_n, int64_t n_samples,
                          int n_scales, const DirectEpochs& eps, int n_epochs, int64_t col0,
-                         int64_t row_len, hipStream_t st) {
+                         int64_t row_len, int64_t max_len, hipStream_t st) {
   int64_t longest = 0;
   for (int e = 0; e < n_epochs; ++e) longest = std::max(longest, eps.g_hi[e] - eps.g_lo[e]);
   if (n_direct == 0 || n_epochs == 0 || longest <= 0) return hipSuccess;
-  dim3 grid((unsigned)((longest + 255) / 256), n_direct, eps.n_channels * n_epochs), block(256);
+  // samples either side of a tile that its outputs reach: half the longest kernel, and the
+  // zero-padded tail of the last group of 8 taps
+  const int halo = (int)(((max_len / 2 + 1 + 8) + 7) & ~7);
+  const size_t lds = sizeof(float) * (size_t)((kDirectTile + 2 * halo) * 9 / 8 + 16);
+  dim3 grid((unsigned)((longest + kDirectTile - 1) / kDirectTile), 1, eps.n_channels * n_epochs), block(256);
 #define GCWT_DIRECT(M)                                                                       \
-  hipLaunchKernelGGL((k_direct<M>), grid, block, 0, st, x, out, psi, sc, sums, inv_n,        \
-                     n_samples, n_scales, eps, col0, row_len)
+  hipLaunchKernelGGL((k_direct<M>), grid, block, lds, st, x, out, psi, sc, n_direct, sums,   \
+                     inv_n, n_samples, n_scales, eps, col0, row_len, halo)
   if (mode == GCWT_OUT_AMPLITUDE_F32) GCWT_DIRECT(GCWT_OUT_AMPLITUDE_F32);
   else if (mode == GCWT_OUT_POWER_F32) GCWT_DIRECT(GCWT_OUT_POWER_F32);
   else GCWT_DIRECT(GCWT_OUT_COMPLEX_C64);

@@ -239,7 +239,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     if (sp.method == GCWT_SCALE_DIRECT) {
       sp.direct_index = hp->n_direct++;
       sp.direct_offset = hp->direct_total;
-      hp->direct_total += sp.length;
+      hp->direct_total += ((sp.length + 7) & ~(int64_t)7) + 8;   // zero-padded to whole groups of 8 taps
     } else if (sp.method == GCWT_SCALE_FULLBAND) {
       sp.fullband_index = hp->n_fullband++;
     }
