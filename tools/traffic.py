@@ -25,6 +25,7 @@ fetch, write = counter("fetch"), counter("write")
 key = [k for k in fetch if "k_synth7" in k][0]
 f_kb, w_kb = fetch[key]["avg_KB"], write[key]["avg_KB"]
 out = {
+    "round": rnd,
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py 128ch x "
             "1e6 x 100 scales amplitude; values are KB per launch. On gfx950 FETCH_SIZE counts 64 B "
             "per 128 B request for coalesced streams, so fetched bytes = 2 * FETCH_SIZE * 1024 "
@@ -33,6 +34,10 @@ out = {
             "stores: it reports 5.0e7 KB = 51.2 GB = the amplitude output.",
     "k_synth_hbm_bytes_per_launch": int(2 * f_kb * 1024 + w_kb * 1024),
     "k_synth7_fetch_KB": f_kb, "k_synth7_write_KB": w_kb,
+    "non_synth_hbm_bytes_per_step": int(sum(2 * fetch[k]["avg_KB"] * 1024 * fetch[k]["calls"] for k in fetch if k != key)
+                                        / max(1, fetch[key]["calls"])
+                                        + sum(write[k]["avg_KB"] * 1024 * write[k]["calls"] for k in write if k != key)
+                                        / max(1, write[key]["calls"])),
     "counters": {"FETCH_SIZE": fetch, "WRITE_SIZE": write},
 }
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
