@@ -767,89 +767,6 @@ int gcwt_plan_segment_info(const gcwt_plan* p, int segment, int64_t* core_start,
   return GCWT_OK;
 }
 
-static int gcwt_fastconv_impl(const float* signal, int64_t n, const float* kernel, int64_t m,
-                  int kernel_is_complex, int mode, float* out, int device) {
-  if (!signal || !kernel || !out || n <= 0 || m <= 0) return set_err(GCWT_ERR_INVALID, "bad argument");
-  if (mode < 0 || mode > 2) return set_err(GCWT_ERR_INVALID, "Mode must be 'full', 'same', or 'valid'");
-  if (mode == 2 && n < m)
-    return set_err(GCWT_ERR_INVALID, "Cannot do a 'valid' convolution because the input is shorter than the kernel");
-  const int64_t total = n + m - 1;
-  int64_t P = kRowLen;
-  while (P < total) P <<= 1;
-  if (P > (int64_t)kRowLen * kMaxP1)
-    return set_err(GCWT_ERR_UNSUPPORTED, "n + m - 1 exceeds 2^22: chunk the signal");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    return set_err(GCWT_ERR_NO_DEVICE, "no HIP device: libghostcwt has no CPU path");
-  if (device >= 0) HIP_TRY(hipSetDevice(device));
-  const int P1 = (int)(P / kRowLen);
-  const int64_t count = mode == 0 ? total : (mode == 1 ? n : n - m + 1);
-  const int64_t first = (total - count) / 2;                      // convolution.py:79-87
-
-  float* d_sig = nullptr; float2 *d_ker = nullptr, *d_xs = nullptr, *d_xk = nullptr, *d_out = nullptr;
-  float2 *d_tw4096 = nullptr, *d_tw256 = nullptr; double* d_zero = nullptr;
-  hipStream_t st = nullptr;
-  int rc = GCWT_OK;
-  auto cleanup = [&]() {
-    (void)hipFree(d_sig); (void)hipFree(d_ker); (void)hipFree(d_xs); (void)hipFree(d_xk);
-    (void)hipFree(d_out); (void)hipFree(d_tw4096); (void)hipFree(d_tw256); (void)hipFree(d_zero);
-    if (st) (void)hipStreamDestroy(st);
-  };
-#define FC_TRY(call)                                                        \
-  do {                                                                      \
-    hipError_t e_ = (call);                                                 \
-    if (e_ != hipSuccess) { rc = hip_err(e_, #call); cleanup(); return rc; }\
-  } while (0)
-  FC_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  FC_TRY(hipMalloc((void**)&d_sig, sizeof(float) * n));
-  FC_TRY(hipMalloc((void**)&d_ker, sizeof(float2) * P));
-  FC_TRY(hipMalloc((void**)&d_xs, sizeof(float2) * P));
-  FC_TRY(hipMalloc((void**)&d_xk, sizeof(float2) * P));
-  FC_TRY(hipMalloc((void**)&d_out, sizeof(float2) * count));
-  FC_TRY(hipMalloc((void**)&d_zero, sizeof(double)));
-  std::vector<float2> tw4096(kRowLen / 2), tw256(256), kz((size_t)m);
-  for (int j = 0; j < kRowLen / 2; ++j) {
-    double a = -2.0 * M_PI * j / kRowLen;
-    tw4096[j] = make_float2((float)std::cos(a), (float)std::sin(a));
-  }
-  for (int q = 0; q < 256; ++q) {
-    double a = 2.0 * M_PI * q / 256.0;
-    tw256[q] = make_float2((float)std::cos(a), (float)std::sin(a));
-  }
-  for (int64_t i = 0; i < m; ++i)
-    kz[i] = kernel_is_complex ? make_float2(kernel[2 * i], kernel[2 * i + 1]) : make_float2(kernel[i], 0.f);
-  FC_TRY(hipMalloc((void**)&d_tw4096, sizeof(float2) * tw4096.size()));
-  FC_TRY(hipMalloc((void**)&d_tw256, sizeof(float2) * 256));
-  FC_TRY(hipMemcpyAsync(d_tw4096, tw4096.data(), sizeof(float2) * tw4096.size(), hipMemcpyHostToDevice, st));
-  FC_TRY(hipMemcpyAsync(d_tw256, tw256.data(), sizeof(float2) * 256, hipMemcpyHostToDevice, st));
-  FC_TRY(hipMemsetAsync(d_zero, 0, sizeof(double), st));
-  FC_TRY(hipMemsetAsync(d_ker, 0, sizeof(float2) * P, st));
-  FC_TRY(hipMemcpyAsync(d_ker, kz.data(), sizeof(float2) * m, hipMemcpyHostToDevice, st));
-  FC_TRY(hipMemcpyAsync(d_sig, signal, sizeof(float) * n, hipMemcpyHostToDevice, st));
-  // forward FFTs (k1-major spectra, all P bins), product, inverse: rows over k2 with the
-  // W_P^(k1 n2) twiddle, then columns over k1 -> natural order
-  FC_TRY(launch_fft_cols(-1, true, d_sig, d_xs, P1, kRowLen, 0, 0, P1 > 1 ? P : 0, d_tw4096, d_tw256,
-                         d_zero, 0.0, n, 1, st));
-  FC_TRY(launch_fft_rows(-1, d_xs, d_xs, kRowLen, P1, kRowLen, kRowLen, 0, 0, 0, d_tw4096, d_tw256,
-                         1.0f, 1, st));
-  FC_TRY(launch_fft_cols(-1, false, d_ker, d_xk, P1, kRowLen, 0, 0, P1 > 1 ? P : 0, d_tw4096, d_tw256,
-                         d_zero, 0.0, 0, 1, st));
-  FC_TRY(launch_fft_rows(-1, d_xk, d_xk, kRowLen, P1, kRowLen, kRowLen, 0, 0, 0, d_tw4096, d_tw256,
-                         1.0f, 1, st));
-  FC_TRY(launch_cmul_inplace(d_xs, d_xk, P, st));
-  FC_TRY(launch_fft_rows(+1, d_xs, d_xs, kRowLen, P1, kRowLen, kRowLen, 0, 0, P1 > 1 ? P : 0, d_tw4096,
-                         d_tw256, 1.0f, 1, st));
-  if (P1 > 1)
-    FC_TRY(launch_fft_cols(+1, false, d_xs, d_xs, P1, kRowLen, 0, 0, 0, d_tw4096, d_tw256, d_zero, 0.0,
-                           0, 1, st));
-  FC_TRY(launch_crop_scale(d_xs, d_out, first, count, (float)(1.0 / (double)P), st));
-  FC_TRY(hipMemcpyAsync(out, d_out, sizeof(float2) * count, hipMemcpyDeviceToHost, st));
-  FC_TRY(hipStreamSynchronize(st));
-#undef FC_TRY
-  cleanup();
-  return GCWT_OK;
-}
-
 int gcwt_filter_bank(gcwt_plan* p, float* bank) {
   if (!p || !bank) return set_err(GCWT_ERR_INVALID, "NULL argument");
   int rc = gcwt_plan_upload(p);
@@ -896,10 +813,6 @@ int gcwt_execute_block(gcwt_plan* p, const void* x, void* out, int64_t start, in
   return guarded([&] { return gcwt_execute_block_impl(p, x, out, start, length, flags); });
 }
 
-int gcwt_fastconv(const float* signal, int64_t n, const float* kernel, int64_t m,
-                  int kernel_is_complex, int mode, float* out, int device) {
-  return guarded([&] { return gcwt_fastconv_impl(signal, n, kernel, m, kernel_is_complex, mode, out, device); });
-}
 
 // ---- debug hooks (include/ghostcwt_debug.h) --------------------------------
 int gcwt_debug_level_count(const gcwt_plan* p) { return p ? (int)p->hp.levels.size() : -1; }

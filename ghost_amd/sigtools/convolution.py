@@ -2,9 +2,11 @@
 
 ``fastconv_hip`` plays the role of ``fastconv_scipy`` / ``fastconv_fftw`` (:16-216),
 ``fastconv_freq_hip`` that of ``fastconv_freq_scipy`` / ``fastconv_freq_fftw`` (:218-402).
-Both run ``gcwt_fastconv``: one FFT of length 2^k >= N + M - 1 instead of chunked
-overlap-add (the results are the same linear convolution).  float32 arithmetic; the
-result is complex64 for a complex kernel and float32 for a real one.
+Both run on a ``ConvPlan`` -- the library's reusable convolution operator
+(``gcwt_conv_plan_*``): stream, FFT tables, kernel spectrum and workspace made once, batches
+of signals ``(C, N)``, device-resident input / output if wanted, signals of any length
+(overlap-save chunks of one power-of-two FFT, the reference's chunked overlap-add).
+float32 arithmetic; the result is complex64 for a complex kernel and float32 for a real one.
 """
 import ctypes as C
 
@@ -12,18 +14,134 @@ import numpy as np
 
 from .._lib import lib, check
 
-__all__ = ["fastconv_hip", "fastconv_freq_hip"]
+__all__ = ["fastconv_hip", "fastconv_freq_hip", "ConvPlan"]
 
 _MODES = {"full": 0, "same": 1, "valid": 2}
+_vp, _i64p = C.c_void_p, C.POINTER(C.c_int64)
+for _name, _args in (("gcwt_conv_plan_create", [C.POINTER(_vp), C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+                     ("gcwt_conv_plan_info", [_vp, _i64p, _i64p, _i64p]),
+                     ("gcwt_conv_plan_set_kernel", [_vp, _vp, C.c_int, C.c_int]),
+                     ("gcwt_conv_plan_set_kernel_fd", [_vp, _vp, C.c_int]),
+                     ("gcwt_conv_plan_execute", [_vp, _vp, C.c_int, _vp, C.c_int]),
+                     ("gcwt_fastconv", [_vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_int, _vp, C.c_int])):
+    getattr(lib, _name).restype = C.c_int
+    getattr(lib, _name).argtypes = _args
+lib.gcwt_conv_plan_destroy.restype = None
+lib.gcwt_conv_plan_destroy.argtypes = [_vp]
 
-lib.gcwt_fastconv.restype = C.c_int
-lib.gcwt_fastconv.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
-                              C.c_void_p, C.c_int]
+
+def _check_mode(mode, n, m):
+    if mode is None:
+        mode = "same"
+    if mode not in _MODES:
+        raise ValueError("Mode must be 'full', 'same', or 'valid'")
+    if mode == "valid" and n < m:
+        raise ValueError("Cannot do a 'valid' convolution because "
+                         "the input is shorter than the kernel")
+    return mode
 
 
-def fastconv_hip(signal, kernel, *, mode=None, device=-1):
+class ConvPlan:
+    """Convolution of ``n_channels`` real signals of ``n_samples`` with one kernel of
+    ``kernel_len`` taps.  ``fft_length``: None (the smallest power of two that holds the
+    whole convolution, at most 2^22; longer signals are chunked) or a power of two
+    4096 .. 2^22, the reference's ``fft_length`` (chunks of ``fft_length - kernel_len + 1``)."""
+
+    def __init__(self, n_samples, kernel_len, n_channels=1, *, fft_length=None, device=-1):
+        self._handle = _vp()
+        log2 = 0
+        if fft_length is not None:
+            log2 = int(fft_length).bit_length() - 1
+            if (1 << log2) != int(fft_length) or not 12 <= log2 <= 22:
+                raise ValueError("fft_length must be a power of two between 4096 and 2**22")
+        check(lib.gcwt_conv_plan_create(C.byref(self._handle), int(n_samples), int(kernel_len),
+                                        int(n_channels), log2, int(device)))
+        self.n_samples, self.kernel_len, self.n_channels = int(n_samples), int(kernel_len), int(n_channels)
+        f, c, k = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.gcwt_conv_plan_info(self._handle, C.byref(f), C.byref(c), C.byref(k)))
+        self.fft_length, self.chunk, self.n_chunks = f.value, c.value, k.value
+        self.kernel_is_complex = True
+
+    def set_kernel(self, kernel):
+        """Kernel taps (time domain), real or complex, ``kernel_len`` of them."""
+        kernel = np.asarray(kernel)
+        if kernel.ndim != 1 or kernel.shape[0] != self.kernel_len:
+            raise ValueError("Kernel must be 1D with %d taps" % self.kernel_len)
+        self.kernel_is_complex = bool(np.iscomplexobj(kernel))
+        k = np.ascontiguousarray(kernel, dtype=np.complex64 if self.kernel_is_complex else np.float32)
+        check(lib.gcwt_conv_plan_set_kernel(self._handle, k.ctypes.data_as(_vp),
+                                            1 if self.kernel_is_complex else 0, 0))
+        return self
+
+    def set_kernel_fd(self, kernel_fd, *, real_kernel=False):
+        """The kernel by its DFT on the plan's own ``fft_length``-point grid
+        (``fastconv_freq_*``'s ``kernel_fd``; ``real_kernel``: its taps are real)."""
+        kernel_fd = np.asarray(kernel_fd)
+        if kernel_fd.ndim != 1 or kernel_fd.shape[0] != self.fft_length:
+            raise ValueError("kernel_fd must have the plan's fft_length (%d) bins" % self.fft_length)
+        self.kernel_is_complex = not real_kernel
+        k = np.ascontiguousarray(kernel_fd, dtype=np.complex64)
+        check(lib.gcwt_conv_plan_set_kernel_fd(self._handle, k.ctypes.data_as(_vp), 0))
+        return self
+
+    def count(self, mode):
+        n, m = self.n_samples, self.kernel_len
+        return {"full": n + m - 1, "same": n, "valid": n - m + 1}[mode]
+
+    def execute(self, signals, *, mode=None):
+        """signals (C, N) or (N,) real -> (C, count) or (count,); complex64, or float32 when
+        the kernel is real."""
+        mode = _check_mode(mode, self.n_samples, self.kernel_len)
+        x = np.asarray(signals)
+        if np.iscomplexobj(x):
+            raise TypeError("signal must be real")
+        one = x.ndim == 1
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.n_channels, self.n_samples)
+        out = np.empty((self.n_channels, self.count(mode)), dtype=np.complex64)
+        check(lib.gcwt_conv_plan_execute(self._handle, x.ctypes.data_as(_vp), _MODES[mode],
+                                         out.ctypes.data_as(_vp), 0))
+        res = out if self.kernel_is_complex else np.ascontiguousarray(out.real)
+        return res[0] if one else res
+
+    def execute_device(self, x_buf, out_buf, *, mode=None):
+        """Device-resident form: float32 [C][N] in, (re, im) float32 pairs [C][count] out
+        (``ghost_amd.engine.DeviceBuffer`` or raw pointers)."""
+        from .._lib import X_ON_DEVICE, OUT_ON_DEVICE
+        mode = _check_mode(mode, self.n_samples, self.kernel_len)
+        xp = getattr(x_buf, "ptr", x_buf)
+        op = getattr(out_buf, "ptr", out_buf)
+        check(lib.gcwt_conv_plan_execute(self._handle, xp, _MODES[mode], op, X_ON_DEVICE | OUT_ON_DEVICE))
+
+    def close(self):
+        if self._handle:
+            lib.gcwt_conv_plan_destroy(self._handle)
+            self._handle = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_cache = {}          # the last few plans by layout: repeated calls reuse tables and workspace
+
+
+def _plan_for(n, m, fft_length, device):
+    key = (n, m, fft_length, device)
+    plan = _cache.pop(key, None)
+    if plan is None:
+        plan = ConvPlan(n, m, 1, fft_length=fft_length, device=device)
+    _cache[key] = plan                  # most recently used last
+    while len(_cache) > 4:
+        _cache.pop(next(iter(_cache))).close()
+    return plan
+
+
+def fastconv_hip(signal, kernel, *, mode=None, fft_length=None, device=-1):
     """Linear convolution of a real 1-D ``signal`` with a real or complex 1-D ``kernel``.
-    ``mode``: 'full', 'same' (default, centred as convolution.py:85) or 'valid'."""
+    ``mode``: 'full', 'same' (default, centred as convolution.py:85) or 'valid';
+    ``fft_length`` as in the reference (a power of two here)."""
     signal = np.asarray(signal)
     kernel = np.asarray(kernel)
     if signal.ndim != 1:
@@ -32,34 +150,35 @@ def fastconv_hip(signal, kernel, *, mode=None, device=-1):
         raise ValueError("Kernel must be 1D")
     if np.iscomplexobj(signal):
         raise TypeError("signal must be real")
-    if mode is None:
-        mode = "same"
-    if mode not in _MODES:
-        raise ValueError("Mode must be 'full', 'same', or 'valid'")
     n, m = signal.shape[0], kernel.shape[0]
-    if mode == "valid" and n < m:
-        raise ValueError("Cannot do a 'valid' convolution because "
-                         "the input is shorter than the kernel")
-    cplx = np.iscomplexobj(kernel)
-    x = np.ascontiguousarray(signal, dtype=np.float32)
-    k = np.ascontiguousarray(kernel, dtype=np.complex64 if cplx else np.float32)
-    count = {"full": n + m - 1, "same": n, "valid": n - m + 1}[mode]
-    out = np.empty(count, dtype=np.complex64)
-    check(lib.gcwt_fastconv(x.ctypes.data_as(C.c_void_p), n, k.ctypes.data_as(C.c_void_p), m,
-                            1 if cplx else 0, _MODES[mode], out.ctypes.data_as(C.c_void_p),
-                            int(device)))
-    return out if cplx else np.ascontiguousarray(out.real)
+    mode = _check_mode(mode, n, m)
+    if fft_length is not None and fft_length < m:
+        raise ValueError("FFT length must be at least the kernel size")
+    plan = _plan_for(n, m, fft_length, int(device))
+    return plan.set_kernel(kernel).execute(signal, mode=mode)
 
 
 def fastconv_freq_hip(signal_td, kernel_fd, kernel_len, *, mode=None, device=-1):
     """Convolution with a kernel given by its DFT (any length >= ``kernel_len``), as
-    ``fastconv_freq_scipy(signal_td, kernel_fd, kernel_len, mode=...)``.  The kernel is
-    taken back to the time domain on the host (it is short) and ``fastconv_hip`` does the
-    rest."""
+    ``fastconv_freq_scipy(signal_td, kernel_fd, kernel_len, mode=...)``.  When the DFT is
+    on a power-of-two grid the plan can take (4096 .. 2^22 bins) it is used as it is and the
+    signal is chunked exactly as the reference does (``len(kernel_fd) - kernel_len + 1``
+    samples per chunk, convolution.py:262); any other grid goes back to the time domain on
+    the host first (the kernel is short)."""
+    signal_td = np.asarray(signal_td)
     kernel_fd = np.asarray(kernel_fd)
+    if signal_td.ndim != 1:
+        raise ValueError("Signal must be 1D")
     if kernel_fd.ndim != 1:
         raise ValueError("Kernel must be 1D")
-    kernel_td = np.fft.ifft(kernel_fd)[:int(kernel_len)]
+    n, m, f = signal_td.shape[0], int(kernel_len), kernel_fd.shape[0]
+    mode = _check_mode(mode, n, m)
+    if f >= 4096 and f <= (1 << 22) and (f & (f - 1)) == 0 and f >= m:
+        # real taps <=> Hermitian spectrum: hand back float32 like fastconv_hip does
+        herm = np.abs(kernel_fd[1:] - np.conj(kernel_fd[:0:-1])).max() <= 1e-6 * np.abs(kernel_fd).max()
+        plan = _plan_for(n, m, f, int(device))
+        return plan.set_kernel_fd(kernel_fd, real_kernel=bool(herm)).execute(signal_td, mode=mode)
+    kernel_td = np.fft.ifft(kernel_fd)[:m]
     if np.abs(kernel_td.imag).max() <= 1e-12 * max(np.abs(kernel_td).max(), 1e-300):
         kernel_td = kernel_td.real
     return fastconv_hip(signal_td, kernel_td, mode=mode, device=device)

@@ -191,13 +191,34 @@ int gcwt_direct_kernel(gcwt_plan* plan, int scale, float* psi);
 
 int gcwt_get_timings(const gcwt_plan* plan, gcwt_timings* t);
 
-/* FFT convolution of one real signal with one kernel, the operator layer under the
- * transform: ghost/sigtools/convolution.py:16-87 (fastconv_scipy) / :89-216
- * (fastconv_fftw).  signal: float32 [n] (host).  kernel: float32 [m] real, or (re,im)
- * pairs [m] when kernel_is_complex.  mode: 0 'full' (n+m-1 samples), 1 'same' (n, centred
- * as convolution.py:85), 2 'valid' (n-m+1).  out: float32 (re,im) pairs (host).  One FFT
- * of length 2^k >= n+m-1 <= 2^22 instead of the reference's chunked overlap-add: same
- * numbers. */
+/* The operator layer under the transform: FFT convolution of real signals with one kernel,
+ * ghost/sigtools/convolution.py:16-87 (fastconv_scipy) / :89-216 (fastconv_fftw) for a
+ * kernel in the time domain, :218-402 (fastconv_freq_scipy / _fftw) for a kernel given by
+ * its DFT.  A plan is made once per (signal length n, kernel length m, channel count) and
+ * reused: it owns its stream, FFT tables, the kernel's spectrum and the workspace.  Signals
+ * longer than one FFT run as overlap-save chunks (the reference's chunked overlap-add,
+ * convolution.py:68-77); chunks and channels are batched.  fft_log2: 0 = the smallest
+ * 2^k >= n + m - 1, at most 2^22; or 12..22 to fix the FFT length F = 2^fft_log2 (the
+ * reference's fft_length: chunks of F - m + 1 samples, convolution.py:70). */
+typedef struct gcwt_conv_plan gcwt_conv_plan;
+int gcwt_conv_plan_create(gcwt_conv_plan** out, int64_t n, int64_t m, int32_t n_channels,
+                          int32_t fft_log2, int32_t device);
+void gcwt_conv_plan_destroy(gcwt_conv_plan* plan);
+int gcwt_conv_plan_info(const gcwt_conv_plan* plan, int64_t* fft_length, int64_t* chunk,
+                        int64_t* n_chunks);
+/* kernel: float32 [m] real, or (re,im) pairs [m] when is_complex; host or device memory. */
+int gcwt_conv_plan_set_kernel(gcwt_conv_plan* plan, const float* kernel, int is_complex,
+                              int on_device);
+/* kernel_fd: (re,im) pairs, the DFT of the (zero-padded) kernel on the plan's own
+ * fft_length-point grid, natural bin order (the kernel_fd argument of
+ * convolution.py:218-219 when its length is a power of two the plan can take). */
+int gcwt_conv_plan_set_kernel_fd(gcwt_conv_plan* plan, const float* kernel_fd, int on_device);
+/* signal: float32 [C][n]; out: (re,im) pairs [C][count], count = n+m-1 ('full', mode 0),
+ * n ('same', mode 1, centred as convolution.py:85) or n-m+1 ('valid', mode 2).
+ * flags: GCWT_X_ON_DEVICE, GCWT_OUT_ON_DEVICE. */
+int gcwt_conv_plan_execute(gcwt_conv_plan* plan, const float* signal, int mode, float* out,
+                           int flags);
+/* One-shot form: one signal, one kernel, host memory (a plan made and destroyed inside). */
 int gcwt_fastconv(const float* signal, int64_t n, const float* kernel, int64_t m,
                   int kernel_is_complex, int mode, float* out, int device);
 

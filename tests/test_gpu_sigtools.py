@@ -47,6 +47,61 @@ def test_fastconv_freq_domain():
         assert _close(fastconv_freq_hip(x, Y, len(y), mode=mode), convolve(x, y, mode=mode)), mode
 
 
+def test_conv_plan_is_a_reusable_batched_operator():
+    """gcwt_conv_plan_*: one plan, many executions; (C, N) batches; kernel_fd used as it is
+    when it sits on the plan's FFT grid (convolution.py:218-402 with a power-of-two
+    kernel_fd, chunked exactly as the reference chunks); device-resident in / out; signals
+    beyond one 2^22-point FFT (overlap-save chunks); the reference's fft_length argument."""
+    from ghost_amd.engine import DeviceBuffer
+    from ghost_amd.sigtools import ConvPlan, fastconv_hip, fastconv_freq_hip
+    rng = np.random.default_rng(4)
+    C, n, m = 3, 50000, 777
+    x = rng.standard_normal((C, n))
+    k = rng.standard_normal(m) + 1j * rng.standard_normal(m)
+    plan = ConvPlan(n, m, C)
+    assert plan.fft_length == 65536 and plan.n_chunks == 1
+    plan.set_kernel(k)
+    for mode in ("full", "same", "valid"):
+        got = plan.execute(x, mode=mode)
+        for c in range(C):
+            assert _close(got[c], convolve(x[c], k, mode=mode)), (mode, c)
+    # a second kernel on the same plan, real this time -> float32 result
+    kr = rng.random(m)
+    got = plan.set_kernel(kr).execute(x)
+    assert got.dtype == np.float32 and _close(got[1], convolve(x[1], kr, mode="same"))
+    # the reference's chunking: fft_length 4096 -> chunks of 4096 - m + 1 samples
+    small = ConvPlan(n, m, C, fft_length=4096).set_kernel(k)
+    assert small.chunk == 4096 - m + 1 and small.n_chunks == -(-(n + m - 1) // small.chunk)
+    got = small.execute(x, mode="full")
+    assert _close(got[2], convolve(x[2], k, mode="full"))
+    # kernel given by its DFT on a power-of-two grid: consumed directly
+    Y = fft(kr, n=8192)
+    for mode in ("full", "same", "valid"):
+        assert _close(fastconv_freq_hip(x[0], Y, m, mode=mode), convolve(x[0], kr, mode=mode)), mode
+    Yc = fft(k, n=4096)
+    got = fastconv_freq_hip(x[0], Yc, m)
+    assert got.dtype == np.complex64 and _close(got, convolve(x[0], k, mode="same"))
+    # device-resident execution
+    xb = DeviceBuffer(4 * C * n)
+    xb.upload(x.astype(np.float32))
+    ob = DeviceBuffer(8 * C * n)
+    plan.set_kernel(k).execute_device(xb, ob, mode="same")
+    dev = ob.download((C, n), np.complex64)
+    np.testing.assert_array_equal(dev, plan.execute(x, mode="same"))
+    # longer than one 2^22-point FFT: overlap-save chunks, kernel of 30 001 taps
+    n2, m2 = 9000000, 30001
+    x2 = rng.standard_normal(n2)
+    k2 = rng.standard_normal(m2) * np.hanning(m2)
+    got = fastconv_hip(x2, k2, mode="same")
+    from oracle import ghost_oracle as orc
+    ref = orc.overlap_add_convolve(x2, k2, mode="same").real
+    assert got.shape == (n2,) and np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max()
+    with pytest.raises(ValueError):
+        ConvPlan(100, 10, fft_length=3000)
+    with pytest.raises(ValueError):
+        fastconv_hip(x[0], k, fft_length=512)
+
+
 def test_chirpz_dft():
     """tests/test_fourier.py:4-18 of the reference: even and odd (prime) lengths vs np.fft."""
     from ghost_amd.sigtools import chirpz_dft_hip, chirpz_idft_hip
