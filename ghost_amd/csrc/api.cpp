@@ -72,6 +72,7 @@ struct gcwt_plan {
   bool uploaded = false;
   bool profiling = false;
   int synth_cols = 32;        // columns per workgroup of k_synth7 (GHOSTCWT_SYNTH_COLS=16|32)
+  bool fuse_blocks = true;    // k_synth7 makes its own block spectra from x_R (GHOSTCWT_FUSE_BLOCKS=0: separate pass)
   int synth_kernel = 7;       // 7: k_synth7; 8: producer/consumer waves (synth8.hip, measured slower:
                               // DESIGN.md 5) -- GHOSTCWT_SYNTH_KERNEL
   bool use_synth16 = false;   // GHOSTCWT_SYNTH16=1: 16-column kernel for every output mode (A/B tests)
@@ -247,6 +248,7 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->device = params->device;
   if (const char* e = getenv("GHOSTCWT_SYNTH16")) p->use_synth16 = e[0] == '1';
   if (const char* e = getenv("GHOSTCWT_SYNTH_COLS")) p->synth_cols = atoi(e) == 16 ? 16 : 32;
+  if (const char* e = getenv("GHOSTCWT_FUSE_BLOCKS")) p->fuse_blocks = e[0] != '0';
   if (const char* e = getenv("GHOSTCWT_SYNTH_KERNEL")) p->synth_kernel = atoi(e) == 8 ? 8 : 7;
   for (const auto& s : p->hp.scales)
     if (s.method == GCWT_SCALE_DIRECT) p->max_direct_len = std::max(p->max_direct_len, s.length);
@@ -436,7 +438,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       while ((1 << lg) < lp.decimation) ++lg;
       lv7[l] = {lp.decimation, lg, lp.hop, lp.halo, ep.lv[l].nblk, (int32_t)lp.scales.size(),
                 scale_off[l], ep.lv[l].blk_lo, n_plain[l], (int32_t)(l * 256), ep.lv[l].xb_offset,
-                lp.twiddle_offset};
+                lp.twiddle_offset, ep.lv[l].xr_offset, ep.lv[l].m - 1};
       const int bpb = std::max(1, p->synth_cols / lp.decimation);
       const int n_rtiles = std::max(1, lp.decimation / p->synth_cols);
       for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
@@ -548,6 +550,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, rows_a, kRowLen, kRowLen, P, P, 0,
                                 p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, st,
                                 hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0));
+    // the production synthesis kernel computes its blocks' spectra itself (no XB pass)
+    const bool fused_blocks = p->fuse_blocks && p->synth_kernel == 7 && !p->use_synth16 && hp.halo_static;
     for (size_t l = 0; l < hp.levels.size(); ++l) {
       const LevelPlan& lp = hp.levels[l];
       const EpochLevel& el = ep.lv[l];
@@ -569,8 +573,9 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, slots, st));
       }
       const float scale = (float)(1.0 / ((double)hp.block * (double)P));
-      RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.blk_lo,
-                                     el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, slots, st));
+      if (!fused_blocks)
+        RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.blk_lo,
+                                       el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, slots, st));
     }
     const EpochDev& dev = p->ep_dev[ep.batch_first];
     if (hp.levels.empty()) {
@@ -607,6 +612,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       if (const char* e = getenv("GHOSTCWT_SYNTH_DROP_STORES")) a7.drop_stores = std::max(1, atoi(e));   // tools/stage_times.py ablations
       a7.seg = sout;
       a7.clock_probe = p->d_probe;
+      if (fused_blocks) {
+        a7.xr = p->d_xr;
+        a7.xr_cstride = hp.max_xr;
+        a7.xb_scale = (float)(1.0 / ((double)hp.block * (double)P));
+      }
       if (p->synth_kernel == 8)
         RUN(ST_SYNTH, launch_synth8(mode, p->synth_cols, a7, dev.n_items7, slots, st));
       else

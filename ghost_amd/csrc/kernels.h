@@ -82,6 +82,8 @@ struct Synth7Level {
   int32_t half_offset; // the rest carry the half-sample phase level_half_tw[half_offset + k]
   int64_t xb_offset;   // per-channel offset of this level's block spectra (complex elems)
   int64_t tw_offset;   // into level_tw
+  int64_t xr_offset;   // per-channel offset of this level's decimated signal x_R (complex elems)
+  int64_t m_mask;      // M - 1, M = P / R samples of x_R (circular index)
 };
 
 struct Synth7Args {
@@ -97,6 +99,10 @@ struct Synth7Args {
   float* out;
   int64_t xb_cstride;
   int64_t row_len;       // samples per (channel, scale) row of out
+  const float2* xr;      // non-NULL: the workgroup computes its blocks' spectra itself from x_R
+  int64_t xr_cstride;    //   (k_synth7 only; the block-spectra pass and the XB array are skipped)
+  float xb_scale;        //   1 / (256 P)
+  int32_t pad0;
   unsigned long long* clock_probe;   // measurement only (GHOSTCWT_CLOCK_PROBE=1): [0] += shader cycles,
                                      // [1] += 100 MHz ticks each workgroup lived; NULL in normal runs
   int32_t n_scales;

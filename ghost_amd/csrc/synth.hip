@@ -83,7 +83,58 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   };
   fill_stage(0);
   v2f pw[16];
-  {
+  if (a.xr) {
+    // Block spectra made here: XB_b = FFT_256(x_R[(b hop - halo + n) mod M]) / (256 P) for the
+    // workgroup's 32/R blocks (one for R > 32), 16 threads per block, forward transform as
+    // conj(IFFT(conj .)) on the packed inverse DFT16; the result goes through LDS to every
+    // column (phase) of its block.  Saves the XB array's round trip through HBM and a launch
+    // per level.  `ex` is free until the scale loop starts: [NCOL/2][16][16] exchange (element
+    // (t, m2) at t*16 + (m2 ^ t): conflict-free without padding) + [NCOL/2][256] spectra
+    // (at most NCOL/2 blocks per workgroup: R = 2).
+    const int nblk_wg = wide ? 1 : (NCOL >> lg);
+    v2f* const fx = ex;
+    v2f* const xbs = ex + (NCOL / 2) * 256;
+    static_assert(NCOL * 256 <= 16 * (16 * NCOL + 1), "prologue buffers must fit the exchange planes");
+    v2f v[16];
+    if (colw < nblk_wg) {
+      const int blkx = min(it.blk0 + colw, lv.nblk - 1);
+      const int64_t base = (int64_t)(lv.blk_base + blkx) * hop - halo + t;
+      const float2* xr = a.xr + (int64_t)c * a.xr_cstride + lv.xr_offset;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float2 q = xr[(base + 16 * j) & lv.m_mask];
+        v[j] = (v2f){q.x, -q.y};
+      }
+      idft16v(v);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float2 w = a.tw256[(t * m) & 255];            // exp(+2 pi i t m / 256)
+        fx[colw * 256 + t * 16 + (m ^ t)] = cmulv(v[dft16_pos(m)], (v2f){w.x, w.y});
+      }
+    }
+    __syncthreads();
+    if (colw < nblk_wg) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) v[k1] = fx[colw * 256 + k1 * 16 + (t ^ k1)];
+      idft16v(v);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const v2f z = v[dft16_pos(j)];
+        xbs[colw * 256 + t + 16 * j] = (v2f){z.x * a.xb_scale, -z.y * a.xb_scale};
+      }
+    }
+    __syncthreads();
+    const float2* ltw = a.level_tw + lv.tw_offset;
+    const float2 b0 = ltw[t * r], st = ltw[16 * r];
+    v2f wcur = (v2f){b0.x, b0.y};
+    const v2f wstep = (v2f){st.x, st.y};
+    const v2f* const mine = xbs + blk_l * 256 + t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      pw[j] = cmulv(mine[16 * j], wcur);
+      wcur = cmulv(wcur, wstep);
+    }
+  } else {
     // it.blk0 counts from the level's first computed block (lv.blk_base); columns past
     // the last block reuse it and are never stored
     const int blk = min(it.blk0 + blk_l, lv.nblk - 1);
