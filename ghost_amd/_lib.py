@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("GHOSTCWT_LIB") or os.path.join(
 OUT_AMPLITUDE, OUT_POWER, OUT_COMPLEX = 0, 1, 2
 X_ON_DEVICE, OUT_ON_DEVICE, REUSE_MEANS, OUT_F64 = 1, 2, 4, 8
 SCALE_SPECTRAL, SCALE_DIRECT, SCALE_FULLBAND = 0, 1, 2
+WAVELET_ENERGY = 0x100
 ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_COMM = -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
 
@@ -33,7 +34,7 @@ class Params(C.Structure):
                 ("freqs_hz", C.POINTER(C.c_double)), ("n_epochs", C.c_int32),
                 ("out_mode", C.c_int32), ("epoch_bounds", C.POINTER(C.c_int64)),
                 ("device", C.c_int32), ("block", C.c_int32), ("band_eps", C.c_double),
-                ("max_fft_log2", C.c_int32), ("reserved", C.c_int32)]
+                ("max_fft_log2", C.c_int32), ("wavelet_flags", C.c_int32)]
 
 
 class PlanInfo(C.Structure):

@@ -180,11 +180,6 @@ struct SpanGuard {
   }
 };
 
-int banker_round_half(int64_t L) {  // Python round(L/2): half to even (morseutils.py:178)
-  if (L % 2 == 0) return (int)(L / 2);
-  int64_t lo = L / 2;               // L/2 = lo + 0.5
-  return (int)((lo % 2 == 0) ? lo : lo + 1);
-}
 
 }  // namespace
 
@@ -393,7 +388,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     bsc[i] = {s.omega, s.half_delay, s.length, s.amp_offset, s.bin_lo, s.n_bins, s.decimation,
               s.method == GCWT_SCALE_SPECTRAL ? 1 : 0};
     if (s.method == GCWT_SCALE_DIRECT)
-      dsc[s.direct_index] = {s.omega, s.length, banker_round_half(s.length), s.direct_offset, i, 0};
+      dsc[s.direct_index] = {s.omega, s.length, s.amp_offset, s.direct_offset, i, s.bin_lo, s.n_bins, 0};
   }
   if ((rc = upload_vec(&p->d_bank_sc, bsc, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_direct_sc, dsc, p->stream))) return bail(rc);
@@ -451,8 +446,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
 
   hipError_t he = launch_build_bank(p->d_bank, p->d_gain, p->d_bank_sc, p->d_amps, S, B, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_bank"));
-  he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, hp.prm.gamma,
-                           hp.prm.beta, hp.w0, p->stream);
+  he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, p->d_amps, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_direct"));
   he = hipStreamSynchronize(p->stream);  // host vectors above go out of scope
   if (he != hipSuccess) return bail(hip_err(he, "plan upload"));

@@ -24,10 +24,10 @@ struct BankScale {
 struct DirectScale {
   double omega;
   int64_t length;
-  int64_t n_bins;   // round-half-even(L/2): bins kept by the reference (morseutils.py:178)
-  int64_t offset;   // into the psi buffer
-  int32_t scale;    // output row
-  int32_t pad;
+  int64_t amp_offset;   // kept spectrum samples A_j: amps[amp_offset .. + n_bins), bins bin_lo ..
+  int64_t offset;       // into the psi buffer
+  int32_t scale;        // output row
+  int32_t bin_lo, n_bins, pad;
 };
 
 // Segments launched together (planner.h: batches).  blockIdx.y = segment * n_channels +
@@ -133,7 +133,7 @@ hipError_t launch_fullband_store(int mode, const float2* y, float* out, int64_t 
                                  int n_scales, int64_t row_len, const SegOut& seg, int n_segments,
                                  hipStream_t st);
 hipError_t launch_build_direct(float2* psi, const DirectScale* sc, int n_direct, int64_t max_len,
-                               double gamma, double beta, double w0, hipStream_t st);
+                               const double* amps, hipStream_t st);
 hipError_t launch_fft_cols(int sign, bool real_in, const void* in, float2* out, int len, int ld,
                            int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
                            const float2* tw4096, const float2* tw256, const double* sums, double inv_n, int64_t n_valid,

@@ -192,27 +192,26 @@ __global__ void k_bank_gain(const cf* __restrict__ bank, float* __restrict__ gai
 }
 
 // ---------------------------------------------------------------------------
-// literal kernels for direct scales: psi[n] = (1/L) sum_{k<K} A(k) e^{i pi k (L+1)/L}
-//   e^{2 pi i k n / L},  K = round-half-even(L/2)            (morseutils.py:117-149)
+// literal kernels for direct scales: psi[n] = (1/L) sum_j A_j e^{i pi j (L+1)/L} e^{2 pi i j n / L}
+// over the scale's kept spectrum samples A_j (planner.h: amps)    (morseutils.py:147-149)
 // grid (n_direct, ceil(Lmax/256))
 // ---------------------------------------------------------------------------
 __global__ void k_build_direct(cf* __restrict__ psi, const DirectScale* __restrict__ sc,
-                               double gamma, double beta, double w0) {
+                               const double* __restrict__ amps) {
   const DirectScale p = sc[blockIdx.x];
   const int64_t n = (int64_t)blockIdx.y * 256 + threadIdx.x;
   if (n >= p.length) return;
   const int64_t L = p.length;
-  const double fact = p.omega / w0;
   double re = 0.0, im = 0.0;
-  for (int64_t k = 1; k < p.n_bins; ++k) {
-    const double w = 2.0 * M_PI * ((double)k / (double)L) / fact;
-    const double amp = 2.0 * exp(-beta * log(w0) + pow(w0, gamma) + beta * log(w) - pow(w, gamma));
+  for (int32_t i = 0; i < p.n_bins; ++i) {
+    const int64_t k = p.bin_lo + i;
     // phase = pi k (L+1)/L + 2 pi k n / L, reduced exactly: (k (L+1 + 2n)) mod 2L over L
     const int64_t q = (k * ((L + 1 + 2 * n) % (2 * L))) % (2 * L);
     double sn, cs;
     sincospi((double)q / (double)L, &sn, &cs);
-    re += amp * cs;
-    im += amp * sn;
+    const double a = amps[p.amp_offset + i];
+    re += a * cs;
+    im += a * sn;
   }
   psi[p.offset + n] = make_float2((float)(re / (double)L), (float)(im / (double)L));
 }
@@ -1026,10 +1025,10 @@ hipError_t launch_bank_gain(const cf* bank, float* gain, const BankScale* sc, in
 }
 
 hipError_t launch_build_direct(cf* psi, const DirectScale* sc, int n_direct, int64_t max_len,
-                               double gamma, double beta, double w0, hipStream_t st) {
+                               const double* amps, hipStream_t st) {
   if (n_direct == 0) return hipSuccess;
   hipLaunchKernelGGL(k_build_direct, dim3(n_direct, (unsigned)((max_len + 255) / 256)), dim3(256),
-                     0, st, psi, sc, gamma, beta, w0);
+                     0, st, psi, sc, amps);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

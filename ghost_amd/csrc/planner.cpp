@@ -38,12 +38,71 @@ static int64_t round_half_even_half(int64_t L) {   // round(L / 2)
   return (lo % 2 == 0) ? lo : lo + 1;
 }
 
+// Spectrum sample j of the L-point grid for any member of the family (morseutils.py:115-133,
+// :175-196): psizero(w) * coeff * Laguerre_k^{(c)}(2 w^gamma), w = theta_j w0 / omega.
+//   'bandpass': psizero = 2 exp(-b ln w0 + w0^g + b ln w - w^g), coeff = sqrt(exp(lgamma(r) +
+//               lgamma(k+1) - lgamma(k+r))) (1 for beta = 0)
+//   'energy':   psizero = exp(b ** ln(w) - w^g) -- the reference's expression as written
+//               (:124), its numbers are the contract -- coeff = sqrt(omega... 1/fact) * A_k
+// psizero(0) is halved (:133).
+static double family_sample(int64_t j, int64_t L, double omega, double g, double b, double w0,
+                            int order, bool energy) {
+  const double fact = omega / w0;
+  const double w = 2.0 * M_PI * ((double)j / (double)L) / fact;
+  double psizero;
+  if (energy) {
+    psizero = b == 0.0 ? std::exp(-std::pow(w, g)) : std::exp(std::pow(b, std::log(w)) - std::pow(w, g));
+  } else {
+    psizero = b == 0.0 ? 2.0 * std::exp(-std::pow(w, g))
+                       : 2.0 * std::exp(-b * std::log(w0) + std::pow(w0, g) + b * std::log(w) - std::pow(w, g));
+  }
+  if (j == 0) psizero *= 0.5;
+  if (!std::isfinite(psizero)) psizero = 0.0;                 // morseutils.py:142
+  const double r = (2.0 * b + 1.0) / g, c = r - 1.0;
+  double coeff = 1.0;
+  if (energy) {
+    const double a = std::sqrt(2.0 * M_PI * g * std::pow(2.0, r) *
+                               std::exp(std::lgamma((double)order + 1.0) - std::lgamma((double)order + r)));
+    coeff = std::sqrt(1.0 / fact) * a;                        // morseutils.py:186-189, :249-251
+  } else if (b != 0.0) {
+    coeff = std::sqrt(std::exp(std::lgamma(r) + std::lgamma((double)order + 1.0) - std::lgamma((double)order + r)));
+  }
+  const double x = 2.0 * std::pow(w, g);
+  double lag = 0.0, xm = 1.0;                                 // generalized Laguerre (morseutils.py:256-273)
+  for (int m = 0; m <= order; ++m) {
+    const double f = std::exp(std::lgamma(order + c + 1.0) - std::lgamma(c + m + 1.0) - std::lgamma(order - m + 1.0));
+    lag += ((m & 1) ? -1.0 : 1.0) * f * xm / std::tgamma(m + 1.0);
+    xm *= x;
+  }
+  const double v = coeff * psizero * lag;
+  return std::isfinite(v) ? v : 0.0;
+}
+
 static void scale_bins(const HostPlan& hp, ScalePlan* sp, std::vector<double>* amp) {
   const int64_t L = sp->length, K = round_half_even_half(L);
+  amp->clear();
+  const int flags = hp.prm.wavelet_flags;
+  if (flags != 0) {
+    // other family members: every kept bin, then the negligible ends trimmed
+    const int order = flags & 0xff;
+    const bool energy = (flags & GCWT_WAVELET_ENERGY) != 0;
+    std::vector<double> all((size_t)std::max<int64_t>(K, 0));
+    double top = 0.0;
+    for (int64_t j = 0; j < K; ++j) {
+      all[(size_t)j] = family_sample(j, L, sp->omega, hp.prm.gamma, hp.prm.beta, hp.w0, order, energy);
+      top = std::max(top, std::fabs(all[(size_t)j]));
+    }
+    int64_t lo = 0, hi = K - 1;
+    while (lo <= hi && std::fabs(all[(size_t)lo]) <= 1e-18 * top) ++lo;
+    while (hi >= lo && std::fabs(all[(size_t)hi]) <= 1e-18 * top) --hi;
+    sp->bin_lo = (int32_t)lo;
+    if (hi >= lo) amp->assign(all.begin() + lo, all.begin() + hi + 1);
+    sp->n_bins = (int32_t)amp->size();
+    return;
+  }
   const double per_u = sp->omega * (double)L / (2.0 * M_PI);   // bins per unit of u = theta/omega
   int64_t lo = std::max<int64_t>(1, (int64_t)std::floor(hp.u_lo * per_u));
   int64_t hi = std::min<int64_t>(K - 1, (int64_t)std::ceil(hp.u_hi * per_u));
-  amp->clear();
   sp->bin_lo = (int32_t)lo;
   for (int64_t j = lo; j <= hi; ++j)
     amp->push_back(morse_amplitude(2.0 * M_PI * (double)j / (double)L, sp->omega, hp.prm.gamma,
@@ -70,7 +129,7 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
   double pk = 0.0, energy = 0.0;
   int32_t i_pk = 0;
   for (int32_t i = 0; i < nb; ++i) {
-    if (amp[i] > pk) { pk = amp[i]; i_pk = i; }
+    if (std::fabs(amp[i]) > pk) { pk = std::fabs(amp[i]); i_pk = i; }
     energy += amp[i] * amp[i];
   }
   const double lim = hp.band_tol * pk;
@@ -135,6 +194,8 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   if (!(prm.fs > 0)) return fail(GCWT_ERR_INVALID, "Sampling rate must be positive");
   if (!(prm.gamma > 0)) return fail(GCWT_ERR_INVALID, "gamma must be positive");
   if (!(prm.beta > 0)) return fail(GCWT_ERR_INVALID, "beta must be positive");
+  if (prm.wavelet_flags < 0 || (prm.wavelet_flags & ~(0xff | GCWT_WAVELET_ENERGY)) || (prm.wavelet_flags & 0xff) > 32)
+    return fail(GCWT_ERR_INVALID, "bad wavelet_flags (order 0..32, GCWT_WAVELET_ENERGY)");
   if (prm.out_mode < 0 || prm.out_mode > 2) return fail(GCWT_ERR_INVALID, "bad out_mode");
   if (prm.block != 0 && prm.block != 256)
     return fail(GCWT_ERR_UNSUPPORTED, "only block = 256 is built");

@@ -83,7 +83,7 @@ class CwtPlan:
 
     def __init__(self, n_samples, n_channels, fs, freqs_hz, *, gamma=3.0, beta=20.0,
                  epoch_bounds=None, output="amplitude", device=-1, band_eps=0.0, block=0,
-                 max_fft_log2=0):
+                 max_fft_log2=0, normalization=None, order=0):
         self._handle = C.c_void_p()
         self.freqs = np.ascontiguousarray(freqs_hz, dtype=np.float64)
         if epoch_bounds is None:
@@ -105,6 +105,13 @@ class CwtPlan:
         p.block = int(block)
         p.band_eps = float(band_eps)
         p.max_fft_log2 = int(max_fft_log2)
+        # other members of the Morse family (morseutils.py:119-124, :181-196); transform()
+        # itself always uses the first 'bandpass' wavelet (morse.py:84-91)
+        if normalization not in (None, "bandpass", "energy"):
+            raise ValueError("Normalization must be 'bandpass', or 'energy'")
+        if not 0 <= int(order) <= 32:
+            raise ValueError("order must be between 0 and 32")
+        p.wavelet_flags = int(order) | (_lib.WAVELET_ENERGY if normalization == "energy" else 0)
         check(lib.gcwt_plan_create(C.byref(self._handle), C.byref(p)))
         self.n_samples, self.n_channels = int(n_samples), int(n_channels)
         self.n_freqs = int(self.freqs.size)

@@ -86,8 +86,13 @@ typedef struct {
                                   band, relative to the peak; 0 = 2e-7             */
   int32_t max_fft_log2;        /* longest FFT the plan may use, 12..22; 0 = 22.  Epochs
                                   that need more are cut into overlapping time blocks  */
-  int32_t reserved;
+  int32_t wavelet_flags;       /* 0 = what transform() uses: first wavelet, 'bandpass'
+                                  (morse.py:84-91).  Bits 0-7: order k of the orthogonal
+                                  family (0 = first; morseutils.py:181-196); bit 8: 'energy'
+                                  normalisation (morseutils.py:119-124, 186-189)         */
 } gcwt_params;
+
+#define GCWT_WAVELET_ENERGY 0x100
 
 typedef struct {
   int32_t abi_version;

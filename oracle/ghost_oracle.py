@@ -97,30 +97,56 @@ def morse_lengths(norm_radian_freqs, gamma=3.0, beta=20.0):
 # Morse time-domain kernel (literal)
 # --------------------------------------------------------------------------
 
-def morse_kernel(length, omega, gamma=3.0, beta=20.0):
-    """``Morse.__call__(length)`` with 'bandpass' normalisation, one wavelet.
+def morse_kernel(length, omega, gamma=3.0, beta=20.0, normalization="bandpass", order=0):
+    """``Morse.__call__(length)``: one wavelet of the family, time domain and spectrum.
 
     Returns ``(psi, psif)``: complex128 (L,) time-domain kernel and float64 (L,)
-    one-sided spectrum sampled on the L-point grid.
+    one-sided spectrum sampled on the L-point grid.  The defaults are what
+    ``transform()`` uses ('bandpass', first wavelet: morse.py:84-91).
 
     Follows ghost/wave/morse.py:84-91 -> ghost/wave/morseutils.py:93-151
-    (``_morsewave``) and :153-198 (``_morsewave_first_family``).  For a single
-    first-family wavelet the Laguerre factor and ``coeff`` are exactly 1
-    (:188-196, :266-271), the spectrum is kept on bins 0..round(L/2)-1 only
+    (``_morsewave``) and :153-198 (``_morsewave_first_family``).  For the first wavelet
+    with 'bandpass' normalisation the Laguerre factor and ``coeff`` are exactly 1
+    (:188-196, :266-271); the spectrum is kept on bins 0..round(L/2)-1 only
     (:178, Python banker's ``round``) and is zero elsewhere (:177, :196).
+    ``order`` k >= 1 multiplies by ``coeff * L_k^(c)(2 w^gamma)`` (:181-196, :256-273);
+    'energy' uses ``exp(beta ** log(w) - w ** gamma)`` exactly as the reference writes it
+    (:124) and ``coeff = sqrt(1/fact) * morseafunc(order=k+1)`` (:186-189, :249-251).
     """
+    from scipy.special import gammaln, gamma as gammafunc
     L = int(length)
     w0 = morse_peak_freq(gamma, beta)
     fact = omega / w0                                        # :116
     w = 2 * np.pi * np.linspace(0, 1 - 1 / L, L) / fact      # :117
-    with np.errstate(divide="ignore", invalid="ignore"):
-        psizero = 2 * np.exp(-beta * np.log(w0) + w0 ** gamma
-                             + beta * np.log(w) - w ** gamma)  # :130-131
-    psizero[0] /= 2                                          # :133 (already 0)
-    keep = np.zeros(L)
-    keep[:round(L / 2)] = 1.0                                # :178, :194
-    psif = psizero * keep                                    # :196
-    psif[np.isinf(psif)] = 0                                 # :142 (never hit)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        if normalization == "energy":
+            psizero = np.exp(-w ** gamma) if beta == 0 else np.exp(beta ** np.log(w) - w ** gamma)  # :121-124
+        elif beta == 0:
+            psizero = 2 * np.exp(-w ** gamma)
+        else:
+            psizero = 2 * np.exp(-beta * np.log(w0) + w0 ** gamma
+                                 + beta * np.log(w) - w ** gamma)  # :130-131
+    psizero[0] /= 2                                          # :133
+    r = (2 * beta + 1) / gamma                               # :173-174
+    c = r - 1
+    index = np.arange(round(L / 2))                          # :178
+    if normalization == "energy":
+        a = np.sqrt(2 * np.pi * gamma * (2 ** r) * np.exp(gammaln(order + 1) - gammaln(order + r)))  # :249-251
+        coeff = np.sqrt(1 / fact) * a                        # :186-189
+    elif beta != 0:
+        coeff = np.sqrt(np.exp(gammaln(r) + gammaln(order + 1) - gammaln(order + r)))  # :190-193
+    else:
+        coeff = 1
+    x = 2 * w[index] ** gamma
+    lag = np.zeros(index.size)
+    for m in range(order + 1):                               # :266-271
+        f = np.exp(gammaln(order + c + 1) - gammaln(c + m + 1) - gammaln(order - m + 1))
+        lag += (-1) ** m * f * x ** m / gammafunc(m + 1)
+    poly = np.zeros(L)
+    poly[index] = lag                                        # :194
+    with np.errstate(invalid="ignore"):
+        psif = coeff * psizero * poly                        # :196
+    psif[np.isinf(psif)] = 0                                 # :142
     centred = psif * np.exp(1j * w * (L + 1) / 2 * fact)     # :147
     psi = np.fft.ifft(centred)                               # :149
     return psi, psif
@@ -209,7 +235,7 @@ def frequency_grid(fs, shortest_epoch, freq_limits=None, voices_per_octave=10,
 
 
 def cwt_complex(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0,
-                n_threads=1, keep="complex"):
+                n_threads=1, keep="complex", normalization="bandpass", order=0):
     """Complex wavelet coefficients, literal path, one channel.
 
     Mirror of the closure ``wavelet_conv`` (ghost/wave/transforms.py:187-204) and
@@ -232,7 +258,7 @@ def cwt_complex(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0,
                    dtype=np.complex128 if keep == "complex" else np.float64)
 
     def one(idx):
-        kernel, _ = morse_kernel(lengths[idx], omegas[idx], gamma, beta)
+        kernel, _ = morse_kernel(lengths[idx], omegas[idx], gamma, beta, normalization, order)
         for start, stop in epoch_bounds:
             res = overlap_add_convolve(x[start:stop], kernel)
             out[idx, start:stop] = res if keep == "complex" else np.abs(res)
@@ -280,7 +306,7 @@ def spectral_filter(theta, omega, length, gamma=3.0, beta=20.0):
     return amp * np.exp(-1j * theta * d)
 
 
-def kernel_response(theta, omega, length, gamma=3.0, beta=20.0):
+def kernel_response(theta, omega, length, gamma=3.0, beta=20.0, normalization="bandpass", order=0):
     """Frequency response of the L-tap kernel the reference convolves with, as the
     'same' crop positions it: H(theta) = sum_n psi[n] exp(-i theta (n - (L-1)//2)), psi from
     ``morse_kernel`` (morseutils.py:149) and the offset from convolution.py:85.  Direct
@@ -288,7 +314,7 @@ def kernel_response(theta, omega, length, gamma=3.0, beta=20.0):
     ~6e-9 of the peak; for heavier-tailed wavelets only this one is what the reference
     applies."""
     theta = np.atleast_1d(np.asarray(theta, dtype=np.float64))
-    psi, _ = morse_kernel(length, omega, gamma, beta)
+    psi, _ = morse_kernel(length, omega, gamma, beta, normalization, order)
     n = np.arange(int(length)) - (int(length) - 1) // 2
     return np.exp(-1j * np.outer(theta, n)) @ psi
 

@@ -23,23 +23,22 @@ from scipy.fft import fft, ifft
 from oracle import ghost_oracle as orc
 
 
-def kept_bins(omega, length, gamma, beta):
+def kept_bins(omega, length, gamma, beta, normalization="bandpass", order=0):
     """(j, A_j): the spectrum samples the reference kernel is built from
-    (morseutils.py:117, :130-131, :178), without the ones below 1e-18 of the peak."""
-    L = int(length)
-    w0 = orc.morse_peak_freq(gamma, beta)
-    j = np.arange(1, round(L / 2))
-    w = 2 * np.pi * j / L * w0 / omega
-    amp = 2 * np.exp(-beta * np.log(w0) + w0 ** gamma + beta * np.log(w) - w ** gamma)
-    keep = amp > amp.max() * 1e-18 if amp.size else np.zeros(0, bool)
-    return j[keep], amp[keep]
+    (morseutils.py:117, :130-131, :178, :181-196), without the ones below 1e-18 of the
+    largest."""
+    _, psif = orc.morse_kernel(int(length), omega, gamma, beta, normalization, order)
+    amp = psif[:round(int(length) / 2)]
+    keep = np.abs(amp) > np.abs(amp).max() * 1e-18 if amp.size else np.zeros(0, bool)
+    j = np.flatnonzero(keep)
+    return j, amp[j]
 
 
-def exact_gain(theta, omega, length, gamma=3.0, beta=20.0):
+def exact_gain(theta, omega, length, gamma=3.0, beta=20.0, normalization="bandpass", order=0):
     """G(theta), real: H = exp(-i theta d) G is the response of the reference's kernel;
     G(theta) = (1/L) sum_j A_j sin(L (theta_j - theta)/2) / sin((theta_j - theta)/2)."""
     L = int(length)
-    j, amp = kept_bins(omega, L, gamma, beta)
+    j, amp = kept_bins(omega, L, gamma, beta, normalization, order)
     theta = np.atleast_1d(np.asarray(theta, dtype=np.float64))
     d = 2 * np.pi * j[None, :] / L - theta[:, None]
     num, den = np.sin(L * d / 2), np.sin(d / 2)
@@ -48,13 +47,14 @@ def exact_gain(theta, omega, length, gamma=3.0, beta=20.0):
     return (ratio * amp[None, :]).sum(axis=1) / L
 
 
-def exact_response(theta, omega, length, gamma=3.0, beta=20.0):
+def exact_response(theta, omega, length, gamma=3.0, beta=20.0, normalization="bandpass", order=0):
     theta = np.atleast_1d(np.asarray(theta, dtype=np.float64))
     d = (length - 1) / 2 - (length - 1) // 2
-    return exact_gain(theta, omega, length, gamma, beta) * np.exp(-1j * theta * d)
+    return exact_gain(theta, omega, length, gamma, beta, normalization, order) * np.exp(-1j * theta * d)
 
 
-def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=256, plan=None):
+def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=256, plan=None,
+                  normalization="bandpass", order=0):
     """Model output, complex128 (S, N).  ``plan``: a CwtPlan for the same layout (made
     here when omitted; planning needs no GPU)."""
     from ghost_amd.engine import CwtPlan
@@ -65,7 +65,8 @@ def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=25
         epoch_bounds = np.array([[0, n]])
     freqs_hz = np.atleast_1d(np.asarray(freqs_hz, dtype=np.float64))
     if plan is None:
-        plan = CwtPlan(n, 1, fs, freqs_hz, gamma=gamma, beta=beta, epoch_bounds=epoch_bounds)
+        plan = CwtPlan(n, 1, fs, freqs_hz, gamma=gamma, beta=beta, epoch_bounds=epoch_bounds,
+                       normalization=normalization, order=order)
     si = plan.scale_info()
     omegas = orc.hz_to_rad(freqs_hz, fs)
     lengths = orc.morse_lengths(omegas, gamma, beta)
@@ -81,11 +82,12 @@ def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=25
         for i, (om, L) in enumerate(zip(omegas, lengths)):
             method = si["method"][i]
             if method == 1:
-                psi, _ = orc.morse_kernel(L, om, gamma, beta)
+                psi, _ = orc.morse_kernel(L, om, gamma, beta, normalization, order)
                 out[i, start:stop] = orc.overlap_add_convolve(x[start:stop], psi)
                 continue
             if method == 2:
-                H = exact_response(2 * np.pi * np.arange(p_big) / p_big, om, L, gamma, beta)
+                H = exact_response(2 * np.pi * np.arange(p_big) / p_big, om, L, gamma, beta,
+                                   normalization, order)
                 out[i, start:stop] = ifft(X * H)[lead:lead + ne]
                 continue
             R, lh, hop = int(si["decimation"][i]), int(si["halo"][i]), int(si["hop"][i])
@@ -94,7 +96,7 @@ def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=25
                 xr_cache[R] = ifft(X[:M]) / R
             xr = xr_cache[R]
             k = np.arange(B)
-            H = exact_response(2 * np.pi * k / (B * R), om, L, gamma, beta)
+            H = exact_response(2 * np.pi * k / (B * R), om, L, gamma, beta, normalization, order)
             tw = np.exp(2j * np.pi * np.outer(k, np.arange(R)) / (B * R))
             nblk = int(math.ceil(math.ceil((lead + ne) / R) / hop))
             y = np.zeros(R * nblk * hop, dtype=np.complex128)

@@ -762,3 +762,22 @@ def test_config5_regime_streamed_multichannel():
         assert rel_err(out[c][picks], ref).max() < TOL, c
     whole = plan.execute(x)
     np.testing.assert_array_equal(whole, out)
+
+
+def test_other_family_members_on_the_device(golden):
+    """higher-order wavelets and the 'energy' normalisation on the device --
+    G12, made by the reference's ``morsewave(..., n_wavelets=, normalization=)``
+    (ghost/wave/morseutils.py:22-91) and ``fastconv_scipy``.  The bank / kernels are built
+    from whatever spectrum samples the family member has; band and support are measured, so
+    'energy' members (a spectrum that does not vanish at zero frequency) take the exact
+    time-domain and full-band paths."""
+    g = golden("g12_family.npz")
+    fs, x, cols, f = float(g["fs"]), g["x"], g["cols"], g["frequencies"]
+    for gamma, beta, energy, n_w in g["cases"]:
+        norm = "energy" if energy else "bandpass"
+        tag = "g%d_b%d_%s" % (gamma, beta, norm)
+        for k in range(int(n_w)):
+            p, c = _plan(x, fs, f, output="complex", gamma=gamma, beta=beta, normalization=norm, order=k)
+            err = rel_err(c[0][:, cols], g["complex_cols_" + tag][k])
+            print(tag, "order", k, "methods", p.scale_info()["method"].tolist(), "err", err.max())
+            assert err.max() < TOL, (tag, k)

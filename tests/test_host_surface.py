@@ -316,6 +316,41 @@ def test_exact_gain_is_the_response_of_the_reference_kernel():
                 assert np.abs(exact_response(theta, om[i], L, gamma, beta) - ref).max() < 1e-12
 
 
+def test_other_family_members_on_the_host(golden):
+    """Higher orders and 'energy' normalisation (morseutils.py:119-124, :181-196): the
+    planner's spectrum samples, evaluated by the library's host code, give the response of
+    the reference's kernel; the planner-driven float64 model reproduces G12."""
+    from decimated_model import cwt_decimated, exact_gain
+    from conftest import rel_err
+    from oracle import ghost_oracle as orc
+    g = golden("g12_family.npz")
+    fs, x, cols, f = float(g["fs"]), g["x"], g["cols"], g["frequencies"]
+    om = orc.hz_to_rad(f, fs)
+    for gamma, beta, energy, n_w in g["cases"]:
+        norm = "energy" if energy else "bandpass"
+        tag = "g%d_b%d_%s" % (gamma, beta, norm)
+        for k in range(int(n_w)):
+            plan = CwtPlan(x.size, 1, fs, f, gamma=gamma, beta=beta, normalization=norm, order=k)
+            si = plan.scale_info()
+            for i in (1, 3):
+                L = int(si["length"][i])
+                a, b = np.arange(0, 4096, 11), 4096
+                theta = 2 * np.pi * a / b
+                ref = orc.kernel_response(theta, om[i], L, gamma, beta, norm, k)
+                d = (L - 1) / 2 - (L - 1) // 2
+                ref_gain = (ref * np.exp(1j * theta * d)).real
+                scale = np.abs(ref_gain).max()
+                assert np.abs(plan.debug_exact_gain(i, a, b) - ref_gain).max() < 1e-12 * scale, (tag, k, i)
+                assert np.abs(exact_gain(theta, om[i], L, gamma, beta, norm, k) - ref_gain).max() < 1e-12 * scale
+            if k == int(n_w) - 1:
+                c = cwt_decimated(x, fs, f, gamma=gamma, beta=beta, plan=plan, normalization=norm, order=k)
+                assert rel_err(c[:, cols], g["complex_cols_" + tag][k]).max() < 2e-6, (tag, k)
+    with pytest.raises(ValueError):
+        CwtPlan(1000, 1, fs, [10.0], normalization="peak")
+    with pytest.raises(ValueError):
+        CwtPlan(1000, 1, fs, [10.0], order=99)
+
+
 def test_planner_measures_each_wavelet():
     """What the planner decides from the measured support of the kernel's response:
     the default wavelet keeps the fast path with hop >= 210; heavy-tailed wavelets

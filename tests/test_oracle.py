@@ -175,3 +175,23 @@ def test_closed_form_fails_for_heavy_tails_and_kernel_response_does_not(golden):
             H = orc.kernel_response(2 * np.pi * np.arange(p) / p, om[i], ls[i], gamma, beta)
             y = ifft(X * H)[:x.size]
             assert rel_err(y, lit[i]) < 1e-12
+
+
+def test_other_family_members(golden):
+    """G12: higher-order wavelets and the 'energy' normalisation of the reference's
+    ``morsewave`` (ghost/wave/morseutils.py:22-91, :119-124, :181-196), kernels and the
+    convolution they give."""
+    g = golden("g12_family.npz")
+    fs, x, cols, f = float(g["fs"]), g["x"].astype(np.float64), g["cols"], g["frequencies"]
+    for gamma, beta, energy, n_w in g["cases"]:
+        norm = "energy" if energy else "bandpass"
+        tag = "g%d_b%d_%s" % (gamma, beta, norm)
+        lengths = orc.morse_lengths(orc.hz_to_rad(f, fs), gamma, beta)
+        np.testing.assert_array_equal(lengths, g["lengths_" + tag])
+        for k in range(int(n_w)):
+            psi, psif = orc.morse_kernel(lengths[2], orc.hz_to_rad(f[2], fs), gamma, beta, norm, k)
+            ref_psi, ref_psif = g["psi_" + tag][:, k], g["psif_" + tag][:, k]
+            assert np.abs(psif - ref_psif).max() <= 1e-13 * np.abs(ref_psif).max()
+            assert np.abs(psi - ref_psi).max() <= 1e-13 * np.abs(ref_psi).max()
+            c = orc.cwt_complex(x, fs, f, gamma=gamma, beta=beta, normalization=norm, order=k)
+            assert rel_err(c[:, cols], g["complex_cols_" + tag][k]).max() < 1e-12, (tag, k)
