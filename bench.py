@@ -175,16 +175,16 @@ def run_rank(args):
     N = args.samples or (18000000 if cfg5 else 1000000)
     S = args.scales or (200 if cfg5 else 100)
     freqs = np.geomspace(500.0, 1.0, S) if cfg5 else np.geomspace(200.0, 2.0, S)
-    group = min(C, 8) if cfg5 else C                 # channels per plan execution
+    group = min(C, args.group or 8) if cfg5 else C   # channels per plan execution
     if C % group:
-        raise SystemExit("--channels must be a multiple of 8 for --config 5")
+        raise SystemExit("--channels must be a multiple of the group size for --config 5")
     total_channels = C * world                       # weak scaling: fixed channels per GPU
     c0, c1 = shard_channels(total_channels, rank, world)
     assert c1 - c0 == C
 
     comm = Comm(rank, world, device=dev)
     t_plan = time.perf_counter()
-    plan = CwtPlan(N, group, fs, freqs, output=args.output, device=dev)
+    plan = CwtPlan(N, group, fs, freqs, output=args.output, device=dev, max_fft_log2=args.max_fft_log2)
     plan.upload()                                    # workspace, filter bank, FFT tables
     check(lib.gcwt_device_synchronize())
     plan_ms = (time.perf_counter() - t_plan) * 1e3   # reported apart from the timed steps
@@ -317,6 +317,8 @@ def main():
     ap.add_argument("--samples", type=int, default=0)
     ap.add_argument("--scales", type=int, default=0)
     ap.add_argument("--output", default="amplitude", choices=["amplitude", "power", "complex"])
+    ap.add_argument("--group", type=int, default=0, help="config 5: channels per plan execution (default 8)")
+    ap.add_argument("--max-fft-log2", type=int, default=0, help="longest FFT of the plan (time-block size), 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true")

@@ -56,7 +56,8 @@ int guarded(F&& body) {
   } while (0)
 
 struct EpochDev {
-  SynthItemDev* items = nullptr;     // 16-column kernel (complex output, odd layouts)
+  SynthItemDev* items = nullptr;     // 16-column kernel: levels the production kernel does not take
+  int n_items = 0;
   SynthLevelDev* levels = nullptr;
   Synth7Item* items7 = nullptr;      // production kernel
   Synth7Level* levels7 = nullptr;
@@ -416,9 +417,13 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   for (size_t e = 0; e < hp.epochs.size(); ++e) {
     const EpochPlan& ep = hp.epochs[e];
     if (ep.batch_count == 0) continue;     // shares the tables of its batch's first segment
-    std::vector<SynthItemDev> items(ep.items.size());
-    for (size_t i = 0; i < items.size(); ++i)
-      items[i] = {ep.items[i].level, ep.items[i].scale, ep.items[i].blk0, ep.items[i].nblk};
+    // each level goes to the production kernel when its layout allows (16 <= halo <= 32, at
+    // most 256 scales), else to the 16-column kernel; GHOSTCWT_SYNTH16=1 sends everything there
+    std::vector<SynthItemDev> items;
+    for (size_t i = 0; i < ep.items.size(); ++i)
+      if (p->use_synth16 || !hp.levels[ep.items[i].level].fast)
+        items.push_back({ep.items[i].level, ep.items[i].scale, ep.items[i].blk0, ep.items[i].nblk});
+    p->ep_dev[e].n_items = (int)items.size();
     std::vector<SynthLevelDev> lv(hp.levels.size());
     for (size_t l = 0; l < lv.size(); ++l)
       lv[l] = {hp.levels[l].decimation, hp.levels[l].hop, hp.levels[l].halo, ep.lv[l].blk_lo,
@@ -436,6 +441,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
                 lp.twiddle_offset, ep.lv[l].xr_offset, ep.lv[l].m - 1};
       const int bpb = std::max(1, p->synth_cols / lp.decimation);
       const int n_rtiles = std::max(1, lp.decimation / p->synth_cols);
+      if (p->use_synth16 || !lp.fast) continue;
       for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
         for (int rt = 0; rt < n_rtiles; ++rt) items7.push_back({(int32_t)l, b0, rt, 0});
     }
@@ -545,7 +551,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
                                 p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, st,
                                 hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0));
     // the production synthesis kernel computes its blocks' spectra itself (no XB pass)
-    const bool fused_blocks = p->fuse_blocks && p->synth_kernel == 7 && !p->use_synth16 && hp.halo_static;
+    const bool fused_blocks = p->fuse_blocks && p->synth_kernel == 7 && !p->use_synth16;
     for (size_t l = 0; l < hp.levels.size(); ++l) {
       const LevelPlan& lp = hp.levels[l];
       const EpochLevel& el = ep.lv[l];
@@ -567,14 +573,12 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, slots, st));
       }
       const float scale = (float)(1.0 / ((double)hp.block * (double)P));
-      if (!fused_blocks)
+      if (!fused_blocks || !lp.fast)     // levels of the 16-column kernel read XB
         RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.blk_lo,
                                        el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, slots, st));
     }
     const EpochDev& dev = p->ep_dev[ep.batch_first];
-    if (hp.levels.empty()) {
-      // full-band scales only: no decimated levels to synthesise
-    } else if (p->use_synth16 || !hp.halo_static) {
+    if (dev.n_items > 0) {
       SynthArgs a{};
       a.xb = p->d_xb;
       a.bank = p->d_bank;
@@ -587,8 +591,9 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       a.row_len = row_len;
       a.n_scales = S;
       a.seg = sout;
-      RUN(ST_SYNTH, launch_synth(mode, a, (int)ep.items.size(), slots, st));
-    } else {
+      RUN(ST_SYNTH, launch_synth(mode, a, dev.n_items, slots, st));
+    }
+    if (dev.n_items7 > 0) {
       Synth7Args a7{};
       a7.xb = p->d_xb;
       a7.bank = p->d_bank;

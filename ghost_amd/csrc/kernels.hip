@@ -127,12 +127,14 @@ __global__ void __launch_bounds__(256) k_channel_sum(const float* __restrict__ x
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + stride < nv; i += 2 * stride) {
-    const float4 u = xv[i], v = xv[i + stride];
-    a0 += (double)u.x + (double)v.x; a1 += (double)u.y + (double)v.y;
-    a2 += (double)u.z + (double)v.z; a3 += (double)u.w + (double)v.w;
+  for (; i + 3 * stride < nv; i += 4 * stride) {      // four 16-byte loads in flight per thread
+    const float4 u = xv[i], v = xv[i + stride], w = xv[i + 2 * stride], z = xv[i + 3 * stride];
+    a0 += ((double)u.x + (double)v.x) + ((double)w.x + (double)z.x);
+    a1 += ((double)u.y + (double)v.y) + ((double)w.y + (double)z.y);
+    a2 += ((double)u.z + (double)v.z) + ((double)w.z + (double)z.z);
+    a3 += ((double)u.w + (double)v.w) + ((double)w.w + (double)z.w);
   }
-  if (i < nv) {
+  for (; i < nv; i += stride) {
     const float4 u = xv[i];
     a0 += (double)u.x; a1 += (double)u.y; a2 += (double)u.z; a3 += (double)u.w;
   }
@@ -275,11 +277,11 @@ __global__ void __launch_bounds__(256) k_fft_cols(const void* __restrict__ in_, 
     const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
     const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
     const float* x = reinterpret_cast<const float*>(in_) + (int64_t)ch * in_cstride + segs.x_off[g];
-    const float mean = (float)(sums[ch] * inv_n);
+    const double mean = sums[ch] * inv_n;   // subtracted in fp64: a mean 1e3 x the signal's spread must not cost its low bits
     for (int e = threadIdx.x; e < total; e += 256) {
       const int i = e >> 4, cc = e & 15;
       const int64_t n = (int64_t)i * ld + col0 + cc;
-      buf[e] = make_float2(n >= n_lead && n < n_valid ? x[n] - mean : 0.f, 0.f);
+      buf[e] = make_float2(n >= n_lead && n < n_valid ? (float)((double)x[n] - mean) : 0.f, 0.f);
     }
   } else {
     const cf* x = reinterpret_cast<const cf*>(in_) + (int64_t)c * in_cstride;
@@ -540,12 +542,12 @@ __global__ void __launch_bounds__(256, 4) k_fft_cols256(const void* __restrict__
     const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
     const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
     const float* x = reinterpret_cast<const float*>(in_) + (int64_t)ch * in_cstride + segs.x_off[g];
-    const float mean = (float)(sums[ch] * inv_n);
+    const double mean = sums[ch] * inv_n;   // subtracted in fp64: a mean 1e3 x the signal's spread must not cost its low bits
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int64_t n = (int64_t)(t + 16 * j) * ld + col0 + s;
       const float a = x[min(max(n, n_lead), n_valid - 1)];   // clamped: no branch around the load
-      v[j] = make_float2(n >= n_lead && n < n_valid ? a - mean : 0.f, 0.f);
+      v[j] = make_float2(n >= n_lead && n < n_valid ? (float)((double)a - mean) : 0.f, 0.f);
     }
   } else {
     const cf* x = reinterpret_cast<const cf*>(in_) + (int64_t)c * in_cstride + col0 + s;
@@ -586,7 +588,7 @@ __global__ void __launch_bounds__(256) k_fft_cols256_real2(const float* __restri
   const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
   const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
-  const float mean = (float)(sums[ch] * inv_n);
+  const double mean = sums[ch] * inv_n;     // subtracted in fp64 (transforms.py:142-143 works in float64)
   const int s = tid & 15, t = tid >> 4;
   cf tw[16], v[16];
 #pragma unroll
@@ -599,8 +601,8 @@ __global__ void __launch_bounds__(256) k_fft_cols256_real2(const float* __restri
     const int64_t n = (int64_t)(t + 16 * j) * ld + col0 + 2 * s;
     const int64_t na = min(max(n, n_lead), n_valid - 1), nb = min(max(n + 1, n_lead), n_valid - 1);
     const float a = x[na], b = x[nb];               // clamped: no branch around the loads
-    v[j] = make_float2(n >= n_lead && n < n_valid ? a - mean : 0.f,
-                       n + 1 >= n_lead && n + 1 < n_valid ? b - mean : 0.f);
+    v[j] = make_float2(n >= n_lead && n < n_valid ? (float)((double)a - mean) : 0.f,
+                       n + 1 >= n_lead && n + 1 < n_valid ? (float)((double)b - mean) : 0.f);
   }
   fft256_16t<-1>(v, tw, ex_re + s * kExColD, ex_im + s * kExColD, t);
   __syncthreads();   // the tile aliases the planes
@@ -807,13 +809,13 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
   const int64_t g0 = eps.g_lo[e] + (int64_t)blockIdx.x * kDirectTile;   // first output, recording index
   if (g0 >= eps.g_hi[e]) return;
   const int64_t base = g0 - epoch_start;                               // epoch-local index of output 0
-  const float mean = (float)(sums[c] * inv_n);
+  const double mean = sums[c] * inv_n;      // subtracted in fp64
   const float* xe = x + (int64_t)c * n_samples + epoch_start;
   // tile[i] = sample base - halo + i of the epoch
   const int n_tile = kDirectTile + 2 * halo;
   for (int i = threadIdx.x; i < n_tile; i += 256) {
     const int64_t m = base - halo + i;
-    tile[direct_pad(i)] = m >= 0 && m < epoch_len ? xe[m] - mean : 0.f;
+    tile[direct_pad(i)] = m >= 0 && m < epoch_len ? (float)((double)xe[m] - mean) : 0.f;
   }
   __syncthreads();
   const int tid = threadIdx.x;
@@ -1003,7 +1005,7 @@ hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double*
                               hipStream_t st) {
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * n_channels, st);
   if (e != hipSuccess) return e;
-  int parts = (int)std::min<int64_t>(32, (n + 256 * 32 - 1) / (256 * 32));
+  int parts = (int)std::min<int64_t>(64, (n + 256 * 32 - 1) / (256 * 32));
   if (parts < 1) parts = 1;
   hipLaunchKernelGGL(k_channel_sum, dim3(parts, n_channels), dim3(256), 0, st, x, n, sums);
   GCWT_LAUNCH_CHECK();

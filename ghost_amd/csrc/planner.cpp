@@ -373,7 +373,8 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     if (lp.hop < 32)
       return fail(GCWT_ERR_UNSUPPORTED,
                   "internal: a spectral scale does not fit its 256-sample decimated block");
-    if (lp.halo > 32 || lp.scales.size() > 256) hp->halo_static = false;   // fast kernel's limits
+    lp.fast = lp.halo <= 48 && lp.scales.size() <= 256;                     // fast kernel's limits
+    if (!lp.fast) hp->halo_static = false;
     lp.twiddle_offset = hp->level_twiddle_total;
     hp->level_twiddle_total += (int64_t)kSynthCols * lp.decimation;
   }

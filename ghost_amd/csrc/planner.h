@@ -52,6 +52,7 @@ struct LevelPlan {
   int halo = 0;                    // Lh, decimated samples discarded at each block edge
   int hop = 0;                     // B - 2*Lh valid decimated samples per block
   std::vector<int> scales;         // scale indices evaluated on this level
+  bool fast = true;                // 16 <= halo <= 48 and at most 256 scales: the production kernel
   int64_t twiddle_offset = 0;      // offset into the level twiddle table (complex elems)
 };
 
@@ -101,7 +102,7 @@ struct HostPlan {
   std::vector<ScalePlan> scales;
   std::vector<LevelPlan> levels;
   std::vector<EpochPlan> epochs;   // segments, in time order
-  bool halo_static = true;         // every level has 16 <= halo <= 32 (fast synthesis kernel)
+  bool halo_static = true;         // every level is `fast`
   int n_direct = 0;
   int n_fullband = 0;
   int max_bins = 0;                // largest n_bins

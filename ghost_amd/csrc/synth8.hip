@@ -150,7 +150,12 @@ __global__ void __launch_bounds__(32 * NCOL) k_synth8(const Synth7Args a) {
     const int r2 = wide ? it.rtile * kCols + (tid & (kCols - 1)) : (rem & (R - 1));
     const v2f* const exr = ex + tid;
     const int off0 = (blk_l2 * hop + m2 - halo) * R + r2;   // sample offset of row m1 = 0
-    const bool keep1 = m2 >= halo - 16, keep14 = m2 < 32 - halo;
+    // which of a thread's 16 output rows (m = 16 m1 + m2) lie in the kept part [halo, 256 - halo):
+    // 16 <= halo <= 32: rows 2..13 always, 1 and 14 lane-wise; 32 < halo <= 48: rows 3..12
+    // always, 2 and 13 lane-wise
+    const bool deep = halo > 32;
+    const bool keep1 = !deep && m2 >= halo - 16, keep14 = !deep && m2 < 32 - halo;
+    const bool keep2 = !deep || m2 >= halo - 32, keep13 = !deep || m2 < 48 - halo;
     // Stores go through a buffer descriptor that covers exactly the samples this launch may
     // write, [w_lo, w_hi) of the segment: halo rows (negative offsets wrap), the end of the
     // epoch, blocks past the last one, neighbouring time blocks are dropped by the hardware
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(32 * NCOL) k_synth8(const Synth7Args a) {
 #pragma unroll
       for (int m1 = 1; m1 < 15; ++m1) {
         const v2f z = v[dft16_pos(m1)];
-        const bool keep = m1 == 1 ? keep1 : (m1 == 14 ? keep14 : true);
+        const bool keep = m1 == 1 ? keep1 : m1 == 2 ? keep2 : m1 == 13 ? keep13 : m1 == 14 ? keep14 : true;
         const unsigned vo = voff0 + (unsigned)m1 * vstep;
         if (MODE == GCWT_OUT_COMPLEX_C64) {
           typedef unsigned v2u __attribute__((ext_vector_type(2)));

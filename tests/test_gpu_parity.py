@@ -236,18 +236,21 @@ def test_integration_stub_from_the_docs_runs():
 
 
 def test_fallback_synthesis_kernel(monkeypatch):
-    """k_synth (16 columns, staged tile) serves the layouts the production kernel does not:
-    block halos above 32 (a long kernel on a short epoch caps the decimation) and levels
-    with more than 256 scales; GHOSTCWT_SYNTH16=1 forces it everywhere."""
+    """k_synth (16 columns, staged tile) serves, level by level, the layouts the production
+    kernel does not take: block halos above 48 (a long kernel on a short epoch caps the
+    decimation) and levels with more than 256 scales; halos of 33..48 run the production
+    kernel's deep-halo rows; GHOSTCWT_SYNTH16=1 forces the 16-column kernel everywhere."""
     from ghost_amd.engine import CwtPlan
     from ghost_amd.synthetic import lfp
     fs = 1000.0
     x = lfp(2, 1500, fs)
-    f = [100.0, 10.0]                                   # L = 1395 on P = 4096: R capped at 16
-    p = CwtPlan(1500, 2, fs, f, output="complex")
-    assert p.scale_info()["halo"].max() > 32
-    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f) for c in range(2)])
-    assert rel_err(p.execute(x), ref).max() < TOL
+    for f, lo, hi in (([100.0, 10.0], 33, 48), ([100.0, 6.0], 49, 112)):   # L = 1395 / 2325 on P = 4096: R capped at 16
+        p = CwtPlan(1500, 2, fs, f, output="complex")
+        assert lo <= p.scale_info()["halo"][1] <= hi and np.all(p.scale_info()["method"] == 0)
+        ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f) for c in range(2)])
+        assert rel_err(p.execute(x), ref).max() < TOL
+        pa = CwtPlan(1500, 2, fs, f, output="amplitude")
+        assert rel_err(pa.execute(x), np.abs(ref)).max() < TOL
     # 300 scales inside one octave -> one level with more than 256 scales
     x1 = lfp(1, 6000, fs)
     f2 = np.geomspace(68.0, 38.0, 300)
@@ -781,3 +784,21 @@ def test_other_family_members_on_the_device(golden):
             err = rel_err(c[0][:, cols], g["complex_cols_" + tag][k])
             print(tag, "order", k, "methods", p.scale_info()["method"].tolist(), "err", err.max())
             assert err.max() < TOL, (tag, k)
+
+
+def test_large_offset_small_signal():
+    """A channel whose mean is 1 000 x its spread (a DC-coupled amplifier): the reference
+    removes the mean in float64 (transforms.py:142-143); here it is subtracted in fp64 before
+    the samples become fp32 FFT input, so the signal keeps its low bits -- epoch edges, where
+    a residual offset would show as a step, included."""
+    from ghost_amd.synthetic import lfp
+    fs, n = 1000.0, 10000
+    rng = np.random.default_rng(131)
+    x = (0.1 * rng.standard_normal((2, n)) + np.array([[97.3], [-81.9]])).astype(np.float32)
+    f = np.array([390.0, 110.6, 67.3, 11.6, 5.5, 2.8])
+    eb = [[0, 6100], [6103, n]]
+    for gamma, beta in ((3, 20), (4, 7.4)):
+        ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, np.array(eb), gamma=gamma, beta=beta)
+                        for c in range(2)])
+        p, got = _plan(x, fs, f, output="complex", epoch_bounds=eb, gamma=gamma, beta=beta)
+        assert rel_err(got, ref).max() < 3e-6, (gamma, beta)
