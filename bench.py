@@ -8,8 +8,8 @@ GPU x 1e6 samples @ 1 kHz x 100 Morse scales (log-spaced 200..2 Hz), amplitude o
 input and output resident in HBM.  A "step" is one gcwt_execute over the rank's block.
 --config 5 (BASELINE.json configs[4]): 48 channels per GPU (384 over 8) x 18e6 samples
 @ 30 kHz (one 10-minute epoch) x 200 scales 500..1 Hz, streamed: the plan's overlapping
-time blocks are computed one after the other, 8 channels at a time, into a ring of two
-device buffers (the 691 GB of output per GPU never exist at once).  A step is one pass over
+time blocks are computed one after the other, 24 channels at a time, into a ring of two
+72 GB device buffers (the 691 GB of output per GPU never exist at once).  A step is one pass over
 the rank's channels and the whole epoch.
 
 N > 1: one process per GPU.  Under ``python -m torch.distributed.run`` (RANK / LOCAL_RANK /
@@ -175,7 +175,7 @@ def run_rank(args):
     N = args.samples or (18000000 if cfg5 else 1000000)
     S = args.scales or (200 if cfg5 else 100)
     freqs = np.geomspace(500.0, 1.0, S) if cfg5 else np.geomspace(200.0, 2.0, S)
-    group = min(C, args.group or 8) if cfg5 else C   # channels per plan execution
+    group = min(C, args.group or 24) if cfg5 else C  # channels per plan execution
     if C % group:
         raise SystemExit("--channels must be a multiple of the group size for --config 5")
     total_channels = C * world                       # weak scaling: fixed channels per GPU
@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--samples", type=int, default=0)
     ap.add_argument("--scales", type=int, default=0)
     ap.add_argument("--output", default="amplitude", choices=["amplitude", "power", "complex"])
-    ap.add_argument("--group", type=int, default=0, help="config 5: channels per plan execution (default 8)")
+    ap.add_argument("--group", type=int, default=0, help="config 5: channels per plan execution (default 24)")
     ap.add_argument("--max-fft-log2", type=int, default=0, help="longest FFT of the plan (time-block size), 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")

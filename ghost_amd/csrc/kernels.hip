@@ -570,6 +570,81 @@ __global__ void __launch_bounds__(256, 4) k_fft_cols256(const void* __restrict__
   }
 }
 
+// Column pass for len = 256 q, q = 2 or 4 (FFT lengths 2^21 and 2^22: long recordings, time
+// blocks): the same 16-column tile and lanes-over-columns loads as k_fft_cols256; the rows
+// are taken as q interleaved subsequences, each through the register FFT256, times
+// W_len^(a kb); a thread ends up with all q values of its own 16 (kb, column) pairs -- the
+// first q-1 parked in LDS words nobody else touches, the last in registers -- and finishes
+// them with a DFT_q.  (The generic radix-2 LDS pass these lengths used before took 4 x as
+// long per point.)  grid (ld/16, slots), dynamic LDS 37 KB + (q-1) x 32 KB
+template <int SIGN, bool REAL_IN, int LQ>
+__global__ void __launch_bounds__(256) k_fft_colsq(const void* __restrict__ in_, cf* __restrict__ out,
+                                                   int ld, int64_t in_cstride, int64_t out_cstride,
+                                                   int64_t tw_n, const cf* __restrict__ tw4096,
+                                                   const cf* __restrict__ tw256,
+                                                   const double* __restrict__ sums, double inv_n,
+                                                   const SegIn segs, int rows_out) {
+  constexpr int q = 1 << LQ, len = 256 * q;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const ex_re = reinterpret_cast<float*>(smem);
+  float* const ex_im = ex_re + 16 * kExColD;
+  cf* const park = reinterpret_cast<cf*>(ex_im + 16 * kExColD);   // [(q-1) * 16][256]
+  const int c = blockIdx.y, col0 = blockIdx.x * 16, tid = threadIdx.x;   // c: workspace slot
+  const int s = tid & 15, t = tid >> 4;
+  cf tw[16], v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    cf w = tw256[(t * j) & 255];
+    if (SIGN < 0) w.y = -w.y;
+    tw[j] = w;
+  }
+  for (int a = 0; a < q; ++a) {
+    if (REAL_IN) {
+      const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
+      const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+      const float* x = reinterpret_cast<const float*>(in_) + (int64_t)ch * in_cstride + segs.x_off[g];
+      const double mean = sums[ch] * inv_n;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int64_t n = (int64_t)(q * (t + 16 * j) + a) * ld + col0 + s;
+        const float xv = x[min(max(n, n_lead), n_valid - 1)];   // clamped: no branch around the load
+        v[j] = make_float2(n >= n_lead && n < n_valid ? (float)((double)xv - mean) : 0.f, 0.f);
+      }
+    } else {
+      const cf* x = reinterpret_cast<const cf*>(in_) + (int64_t)c * in_cstride + col0 + s;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = x[(int64_t)(q * (t + 16 * j) + a) * ld];
+    }
+    fft256_16t_aliased<SIGN>(v, tw, ex_re + s * kExColD, ex_im + s * kExColD, t);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int kb = t + 16 * j;
+      const cf val = cmul(v[j], tw4096_at<SIGN>(tw4096, a * kb * (kRowLenDev / len)));
+      if (a < q - 1) park[(a * 16 + j) * 256 + tid] = val;    // this thread's own words
+      else v[j] = val;
+    }
+  }
+  cf* o = out + (int64_t)c * out_cstride + col0 + s;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int kb = t + 16 * j;
+    cf u[q];
+#pragma unroll
+    for (int a = 0; a < q - 1; ++a) u[a] = park[(a * 16 + j) * 256 + tid];
+    u[q - 1] = v[j];
+    dft_small<SIGN, q>(u);
+#pragma unroll
+    for (int ka = 0; ka < q; ++ka) {
+      const int k = kb + 256 * ka;
+      if (k < rows_out) {
+        cf val = u[ka];
+        if (tw_n > 0) val = cmul(val, unit_phase((int64_t)(col0 + s) * k, tw_n, SIGN));
+        o[(int64_t)k * ld] = val;
+      }
+    }
+  }
+}
+
 // Forward column pass for REAL input, two columns per FFT: z = x[.., 2m] + i x[.., 2m+1]
 // goes through one FFT256 and is split again with Z[k] +- conj(Z[256-k]); only rows
 // k = 0 .. 128 exist afterwards (the mirrored rows are reflected by the row pass).
@@ -1041,6 +1116,25 @@ static hipError_t launch_fft_cols_segs(int sign, bool real_in, const void* in, c
                                        double inv_n, const SegIn& segs, int n_segments, hipStream_t st,
                                        int rows_out);
 
+template <int SIGN, bool REAL_IN, int LQ>
+static hipError_t launch_colsq(const void* in, cf* out, int ld, int64_t in_cstride, int64_t out_cstride,
+                               int64_t tw_n, const cf* tw4096, const cf* tw256, const double* sums,
+                               double inv_n, const SegIn& segs, int n_slots, int rows_out, hipStream_t st) {
+  const size_t lds = 2 * 16 * kExColD * sizeof(float) + (size_t)((1 << LQ) - 1) * 16 * 256 * sizeof(cf);
+  static bool attr_done[64] = {};            // per device and instantiation
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (!attr_done[dev_ & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_fft_colsq<SIGN, REAL_IN, LQ>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done[dev_ & 63] = true;
+  }
+  hipLaunchKernelGGL((k_fft_colsq<SIGN, REAL_IN, LQ>), dim3(ld / 16, n_slots), dim3(256), lds, st, in, out,
+                     ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, rows_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_fft_cols(int sign, bool real_in, const void* in, cf* out, int len, int ld,
                            int64_t in_cstride, int64_t out_cstride, int64_t tw_n, const cf* tw4096,
                            const cf* tw256,
@@ -1077,6 +1171,20 @@ static hipError_t launch_fft_cols_segs(int sign, bool real_in, const void* in, c
                        sums, inv_n, segs);
     GCWT_LAUNCH_CHECK();
     return hipSuccess;
+  }
+  if ((len == 512 || len == 1024) && tw256 && tw4096 && !(sign > 0 && real_in)) {
+    const bool big = len == 1024;
+    hipError_t e;
+    if (sign < 0 && real_in)
+      e = big ? launch_colsq<-1, true, 2>(in, out, ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, n_channels, rows_out, st)
+              : launch_colsq<-1, true, 1>(in, out, ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, n_channels, rows_out, st);
+    else if (sign < 0)
+      e = big ? launch_colsq<-1, false, 2>(in, out, ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, n_channels, rows_out, st)
+              : launch_colsq<-1, false, 1>(in, out, ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, n_channels, rows_out, st);
+    else
+      e = big ? launch_colsq<1, false, 2>(in, out, ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, n_channels, rows_out, st)
+              : launch_colsq<1, false, 1>(in, out, ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, n_channels, rows_out, st);
+    return e;
   }
   if (len == 256 && tw256) {
     dim3 grid(ld / 16, n_channels), block(256);
