@@ -373,8 +373,8 @@ def test_planner_measures_each_wavelet():
             assert (m == _lib.SCALE_SPECTRAL).sum() >= 36, (gamma, beta)
         else:
             assert not (m == _lib.SCALE_SPECTRAL).any(), (gamma, beta)
-            assert np.all(m[ln <= 512] == _lib.SCALE_DIRECT)
-            assert np.all(m[ln > 512] == _lib.SCALE_FULLBAND) and (ln > 512).any()
+            assert np.all(m[ln <= 256] == _lib.SCALE_DIRECT)
+            assert np.all(m[ln > 256] == _lib.SCALE_FULLBAND) and (ln > 256).any()
     # a looser tolerance is the caller's to ask for
     q = CwtPlan(65536, 1, fs, f2, gamma=2, beta=8, band_eps=1e-5)
     assert (q.scale_info()["method"] == _lib.SCALE_SPECTRAL).sum() >= 30
