@@ -175,9 +175,11 @@ def run_rank(args):
     N = args.samples or (18000000 if cfg5 else 1000000)
     S = args.scales or (200 if cfg5 else 100)
     freqs = np.geomspace(500.0, 1.0, S) if cfg5 else np.geomspace(200.0, 2.0, S)
-    group = min(C, args.group or 24) if cfg5 else C  # channels per plan execution
-    if C % group:
-        raise SystemExit("--channels must be a multiple of the group size for --config 5")
+    group = C                                        # channels per plan execution
+    if cfg5:
+        group = min(C, args.group or 24)
+        while C % group:                             # the largest divisor of C within the request
+            group -= 1
     total_channels = C * world                       # weak scaling: fixed channels per GPU
     c0, c1 = shard_channels(total_channels, rank, world)
     assert c1 - c0 == C

@@ -83,12 +83,23 @@ static void scale_bins(const HostPlan& hp, ScalePlan* sp, std::vector<double>* a
   amp->clear();
   const int flags = hp.prm.wavelet_flags;
   if (flags != 0) {
-    // other family members: every kept bin, then the negligible ends trimmed
+    // other family members: every kept bin, then the negligible ends trimmed.  A 'bandpass'
+    // member is the first wavelet times a degree-k polynomial in w^gamma, so it is negligible
+    // wherever the first wavelet is below 1e-40 of its peak; 'energy' members (a different
+    // envelope, non-zero at zero frequency) are evaluated on every kept bin.
     const int order = flags & 0xff;
     const bool energy = (flags & GCWT_WAVELET_ENERGY) != 0;
-    std::vector<double> all((size_t)std::max<int64_t>(K, 0));
+    int64_t j_first = 0, j_last = K - 1;
+    if (!energy) {
+      double ulo, uhi;
+      band_edges(hp.prm.gamma, hp.prm.beta, 1e-40, &ulo, &uhi);
+      const double per_u = sp->omega * (double)L / (2.0 * M_PI);
+      j_first = std::max<int64_t>(0, (int64_t)std::floor(ulo * per_u) - 1);
+      j_last = std::min<int64_t>(K - 1, (int64_t)std::ceil(uhi * per_u) + 1);
+    }
+    std::vector<double> all((size_t)std::max<int64_t>(K, 0), 0.0);
     double top = 0.0;
-    for (int64_t j = 0; j < K; ++j) {
+    for (int64_t j = j_first; j <= j_last; ++j) {
       all[(size_t)j] = family_sample(j, L, sp->omega, hp.prm.gamma, hp.prm.beta, hp.w0, order, energy);
       top = std::max(top, std::fabs(all[(size_t)j]));
     }
