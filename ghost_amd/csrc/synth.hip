@@ -199,6 +199,10 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     v2f v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = pw[j] * hs[16 * j];
+#ifdef GCWT_PRUNE_TEST   // measurement build only (wrong results): upper bound of input pruning
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (j < GCWT_PRUNE_LO || j >= GCWT_PRUNE_HI) v[j] = (v2f){0.f, 0.f};
+#endif
     idft16v(v);
 #pragma unroll
     for (int j = 0; j < 16; ++j) exw[j * sstride] = cmulv(v[dft16_pos(j)], twl[16 * j + t]);
