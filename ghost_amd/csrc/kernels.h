@@ -167,8 +167,6 @@ hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_
                               int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,
                               int n_channels, hipStream_t st);
 hipError_t launch_cmul_inplace(float2* a, const float2* b, int64_t n, hipStream_t st);
-hipError_t launch_crop_scale(const float2* in, float2* out, int64_t first, int64_t count, float scale,
-                             hipStream_t st);
 // Bluestein pieces (arbitrary-length DFT, analytic signal)
 hipError_t launch_chirp_kernel(float2* b, int64_t N, int64_t P, hipStream_t st);
 hipError_t launch_chirp_load(const float* v, int is_complex, int conj_in, int64_t n_valid, int64_t N,

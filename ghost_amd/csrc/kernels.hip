@@ -1048,16 +1048,6 @@ __global__ void k_cmul_inplace(cf* __restrict__ a, const cf* __restrict__ b, int
   if (i < n) a[i] = cmul(a[i], b[i]);
 }
 
-// out[i] = scale * in[first + i], i < count (complex).  grid (ceil(count/256))
-__global__ void k_crop_scale(const cf* __restrict__ in, cf* __restrict__ out, int64_t first,
-                             int64_t count, float scale) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < count) {
-    const cf v = in[first + i];
-    out[i] = make_float2(v.x * scale, v.y * scale);
-  }
-}
-
 // zero [start, stop) of every (channel, scale) row.  grid (ceil(len/256), C*S)
 __global__ void k_zero_range(float* __restrict__ out, int64_t row_len_floats, int64_t start,
                              int64_t len) {
@@ -1319,15 +1309,6 @@ hipError_t launch_level_small(const cf* x, cf* xr, int n1, int q, int64_t row_st
 
 hipError_t launch_cmul_inplace(cf* a, const cf* b, int64_t n, hipStream_t st) {
   hipLaunchKernelGGL(k_cmul_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, n);
-  GCWT_LAUNCH_CHECK();
-  return hipSuccess;
-}
-
-hipError_t launch_crop_scale(const cf* in, cf* out, int64_t first, int64_t count, float scale,
-                             hipStream_t st) {
-  if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_crop_scale, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, in, out,
-                     first, count, scale);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }
