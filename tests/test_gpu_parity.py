@@ -802,3 +802,35 @@ def test_large_offset_small_signal():
                         for c in range(2)])
         p, got = _plan(x, fs, f, output="complex", epoch_bounds=eb, gamma=gamma, beta=beta)
         assert rel_err(got, ref).max() < 3e-6, (gamma, beta)
+
+
+def test_bench_runs_two_ranks_end_to_end(tmp_path):
+    """`python bench.py --gpus 2` run bare: the launcher starts two fresh rank processes, each
+    plans, uploads, times and (rank 0) checks its block against the oracle; one JSON line comes
+    back.  The box has one GPU, so the ranks are allowed to share it for this rehearsal and
+    the control plane is the file backend (RCCL refuses two ranks on one device); on a
+    multi-GPU node the same command puts one rank on each GPU with RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(GHOSTCWT_ALLOW_SHARED_GPU="1", GHOSTCWT_COMM="file", GHOSTCWT_RDZV_DIR=str(tmp_path))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--channels", "8", "--samples", "150000", "--no-cpu-baseline",
+                          "--no-ceilings"], env=env, capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["checked"] is True
+    assert line["config"]["channels_total"] == 16 and line["config"]["comm"] == "file"
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    # without the rehearsal switch two ranks on one GPU are refused, loudly
+    env.pop("GHOSTCWT_ALLOW_SHARED_GPU")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                          "--warmup", "0", "--channels", "8", "--samples", "150000", "--no-cpu-baseline",
+                          "--no-ceilings"], env=env, capture_output=True, timeout=600)
+    assert res.returncode != 0 and b"ranks never share a GPU" in res.stderr
