@@ -29,11 +29,14 @@ __global__ void bw_copy128(const float4* a, float4* b, size_t n) {
 }
 // synthesis-like pattern: a workgroup of 512 threads writes 14 runs of 32 consecutive floats
 // (128 B) per 16-lane-group in each of `rows` rows that are row_len floats apart
+// blockIdx.y = channel: one launch fills the chip like the synthesis does (round 1's probe
+// launched 139 workgroups per channel, one channel after the other, and read 5.1 TB/s)
 __global__ void bw_fill_rows(float* p, size_t row_len, int rows, float v) {
   const int lane = threadIdx.x & 31, m2 = threadIdx.x >> 5;
   const size_t col0 = (size_t)blockIdx.x * 32 * 16 * 14;
+  float* const base = p + (size_t)blockIdx.y * rows * row_len + col0;
   for (int r = 0; r < rows; ++r) {
-    float* q = p + (size_t)r * row_len + col0;
+    float* q = base + (size_t)r * row_len;
     for (int m1 = 0; m1 < 14; ++m1) q[(size_t)(m2 + 16 * m1) * 32 + lane] = v;
   }
 }
@@ -70,9 +73,7 @@ extern "C" int gcwt_debug_bandwidth(int pattern, size_t bytes, double* gb_per_s)
         const unsigned wgs = (unsigned)(row_len / (32 * 16 * 14));
         const size_t per_ch = (size_t)rows * row_len * 4;
         const int n_ch = (int)std::min<size_t>(120, bytes / per_ch);
-        for (int c = 0; c < n_ch; ++c)
-          hipLaunchKernelGGL(bw_fill_rows, dim3(wgs), dim3(512), 0, 0, a + (size_t)c * rows * row_len,
-                             row_len, rows, 1.f);
+        hipLaunchKernelGGL(bw_fill_rows, dim3(wgs, n_ch), dim3(512), 0, 0, a, row_len, rows, 1.f);
         moved = (double)wgs * 512 * 14 * rows * 4 * n_ch;
       }
       (void)hipEventRecord(e1, 0);
