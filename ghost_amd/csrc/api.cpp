@@ -556,7 +556,9 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       const LevelPlan& lp = hp.levels[l];
       const EpochLevel& el = ep.lv[l];
       float2* xr = p->d_xr + el.xr_offset;
-      if (lp.decimation <= kMaxTwoPassDecimation) {
+      if (lp.xr_owner != (int)l) {
+        // x_R of this decimation was made for the level that owns it (an earlier one)
+      } else if (lp.decimation <= kMaxTwoPassDecimation) {
         const int Q = kRowLen / lp.decimation;
         // x_R[Q m1 + m2] = sum_{j1} e^{2 pi i j1 m1/P1} e^{2 pi i j1 m2/M} sum_{j2} X~[j1][j2] e^{2 pi i j2 m2/Q}
         RUN(ST_DECIM, launch_fft_rows(+1, p->d_x, xr, Q, P1, kRowLen, Q, P, hp.max_xr,

@@ -54,6 +54,8 @@ struct LevelPlan {
   int hop = 0;                     // B - 2*Lh valid decimated samples per block
   std::vector<int> scales;         // scale indices evaluated on this level
   bool fast = true;                // 16 <= halo <= 48 and at most 256 scales: the production kernel
+  int xr_owner = -1;               // first level with this decimation: its x_R is shared (a
+                                   // decimation's scales are split by halo into up to two levels)
   int64_t twiddle_offset = 0;      // offset into the level twiddle table (complex elems)
 };
 

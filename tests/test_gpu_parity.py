@@ -834,3 +834,21 @@ def test_bench_runs_two_ranks_end_to_end(tmp_path):
                           "--warmup", "0", "--channels", "8", "--samples", "150000", "--no-cpu-baseline",
                           "--no-ceilings"], env=env, capture_output=True, timeout=600)
     assert res.returncode != 0 and b"ranks never share a GPU" in res.stderr
+
+
+def test_split_levels_option(monkeypatch):
+    """GHOSTCWT_SPLIT_LEVELS=1 (two block grids per decimation, x_R shared; measured slower on
+    the headline workload, kept as an option) gives the same numbers to rounding."""
+    from ghost_amd.synthetic import lfp
+    fs = 1000.0
+    x = lfp(2, 30000, fs)
+    f = np.geomspace(190.0, 3.0, 41)
+    p0, ref = _plan(x, fs, f, output="complex")
+    monkeypatch.setenv("GHOSTCWT_SPLIT_LEVELS", "1")
+    p1, got = _plan(x, fs, f, output="complex")
+    assert p1.info["n_levels"] > p0.info["n_levels"]
+    assert set(p1.scale_info()["halo"].tolist()) >= {16} and p1.scale_info()["halo"].max() > 16
+    scale = np.abs(ref).max(axis=-1, keepdims=True)
+    assert (np.abs(got - ref) / scale).max() < 2e-6
+    oracle = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f) for c in range(2)])
+    assert rel_err(got, oracle).max() < TOL
