@@ -9,6 +9,11 @@
 #include "kernels.h"
 #include "synth_math.h"
 
+// cache policy bits of the output stores (measurement builds: profiles/r02_synth_study.md)
+#ifndef GCWT_STORE_AUX
+#define GCWT_STORE_AUX 2   // nt: the rows are written once and not read by this launch
+#endif
+
 namespace gcwt {
 
 // ---------------------------------------------------------------------------
@@ -26,18 +31,21 @@ namespace gcwt {
 //   DFT16, |.|, 14 stores of 4 B per lane: 256 contiguous bytes per wave store
 // With 16 <= halo <= 32 rows 0 and 15 of a thread's 16 outputs are always halo,
 // rows 2..13 are always kept and rows 1 / 14 are kept lane-wise.
-// LDS: 16 x 513 complex + 2 x 256 complex = 69.8 KB -> two workgroups per CU.
+// LDS: 16 x 513 complex + 256 complex + 8 x 320 gains + 256 indices = 71.9 KB -> two workgroups per CU.
 // ---------------------------------------------------------------------------
 template <int MODE, int NCOL>
 __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   constexpr int kThreads = 16 * NCOL;
   constexpr int kPlane = kThreads + 1;
   constexpr int kLgN = NCOL == 32 ? 5 : 4;
+  // gains of one scale in LDS: lane t's sixteen (bins t + 16 j) side by side, 20 floats per lane so
+  // that the four 16-byte reads of the 16 lanes of a column fall on distinct banks
+  constexpr int kGainRow = 16 * 20;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2f* const ex = reinterpret_cast<v2f*>(smem);
   v2f* const twl = ex + 16 * kPlane;
   float* const stage = reinterpret_cast<float*>(twl + 256);       // gains of kChunk scales
-  int* const sc_lds = reinterpret_cast<int*>(stage + 8 * 256);   // this level's scale indices
+  int* const sc_lds = reinterpret_cast<int*>(stage + 8 * kGainRow);   // this level's scale indices
 
   const Synth7Item it = a.items[blockIdx.x];
   const Synth7Level lv = a.levels[it.level];
@@ -71,14 +79,14 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   }
   // The filter enters as its real gain |H_s[k]|; the half-sample phase that even kernel
   // lengths carry is folded into P when the walk reaches those scales (they come last in
-  // the level's list).  Gains of kChunk scales at a time are parked in LDS (8 KB): a
+  // the level's list).  Gains of kChunk scales at a time are parked in LDS (10 KB): a
   // refill is one global load per thread per kChunk batches, so its vmcnt(0) drain of
   // the outstanding stores is paid once per kChunk batches, not per batch.
   constexpr int kChunk = 8;
   auto fill_stage = [&](int b0) {
     for (int i = tid; i < kChunk * 256; i += kThreads) {
       const int sb = min(b0 + (i >> 8), lv.n_scales - 1);
-      stage[i] = a.gain[(int64_t)scales[sb] * 256 + (i & 255)];
+      stage[(i >> 8) * kGainRow + (i & 15) * 20 + ((i >> 4) & 15)] = a.gain[(int64_t)scales[sb] * 256 + (i & 255)];
     }
   };
   fill_stage(0);
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   float* const out0 = a.out + ((int64_t)ch * a.n_scales * a.row_len + a.seg.seg_col[seg] + w_lo) * kElem;
   const unsigned voff0 = (unsigned)(((int)(n_b - w_lo) + off0) * (4 * kElem));
   const unsigned vstep = (unsigned)(m1step * (4 * kElem));
-  const float* const st_rd = stage + t;
+  const float* const st_rd = stage + t * 20;
   __syncthreads();
 
   for (int b = 0; b < lv.n_scales; ++b) {
@@ -195,10 +203,16 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
         pw[j] = cmulv(pw[j], (v2f){q.x, q.y});
       }
     }
-    const float* const hs = st_rd + (b & (kChunk - 1)) * 256;
+    const float4* const hs = reinterpret_cast<const float4*>(st_rd + (b & (kChunk - 1)) * kGainRow);
     v2f v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = pw[j] * hs[16 * j];
+    for (int q = 0; q < 4; ++q) {
+      const float4 g = hs[q];
+      v[4 * q] = pw[4 * q] * g.x;
+      v[4 * q + 1] = pw[4 * q + 1] * g.y;
+      v[4 * q + 2] = pw[4 * q + 2] * g.z;
+      v[4 * q + 3] = pw[4 * q + 3] * g.w;
+    }
 #ifdef GCWT_PRUNE_TEST   // measurement build only (wrong results): upper bound of input pruning
 #pragma unroll
     for (int j = 0; j < 16; ++j) if (j < GCWT_PRUNE_LO || j >= GCWT_PRUNE_HI) v[j] = (v2f){0.f, 0.f};
@@ -227,11 +241,11 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
       const unsigned vo = voff0 + (unsigned)m1 * vstep;
       if (MODE == GCWT_OUT_COMPLEX_C64) {
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        if (keep) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, z), rsrc, vo, 0, 0);
+        if (keep) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, z), rsrc, vo, 0, GCWT_STORE_AUX);
       } else {
         const float p2 = __builtin_fmaf(z.y, z.y, z.x * z.x);   // v_mul + v_fma: cheaper than packed
         const float val = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2) : p2;
-        if (keep) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc, vo, 0, 0);
+        if (keep) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsrc, vo, 0, GCWT_STORE_AUX);
       }
     }
   }
@@ -244,7 +258,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
 template <int NCOL>
 static hipError_t launch_synth7_n(int mode, const Synth7Args& a, int n_items, int n_channels,
                                   hipStream_t st) {
-  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 8 * 256 * 4 + 256 * 4;
+  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 8 * 320 * 4 + 256 * 4;
   static bool attr_done[64] = {};            // per device: one process may drive several
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
