@@ -112,6 +112,24 @@ __device__ __forceinline__ void fft256_16t_aliased(cf v[16], const cf tw[16], fl
   __syncthreads();
 }
 
+// Same FFT256 with its twiddles W256^(t m2) read from an LDS table (tw_t[16 m2]) instead of
+// 32 registers: for callers that need the registers (k_fft_colsq).
+template <int SIGN>
+__device__ __forceinline__ void fft256_16t_ldstw(cf v[16], const cf* tw_t, float* ex_re, float* ex_im, int t) {
+  dft16<SIGN>(v);
+#pragma unroll
+  for (int m2 = 0; m2 < 16; ++m2) {
+    cf u = cmul(v[m2], tw_t[16 * m2]);
+    ex_re[t * kExPitch + m2] = u.x;
+    ex_im[t * kExPitch + m2] = u.y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1)
+    v[k1] = make_float2(ex_re[k1 * kExPitch + t], ex_im[k1 * kExPitch + t]);
+  dft16<SIGN>(v);
+}
+
 // ---------------------------------------------------------------------------
 // per-channel sum (fp64 accumulate), partial sums combined with one atomic per
 // workgroup.  grid (parts, C)
@@ -389,7 +407,9 @@ __device__ __forceinline__ cf tw4096_at(const cf* __restrict__ tw4096, int idx) 
 
 __device__ __forceinline__ cf unit_phase(int64_t num, int64_t den, int sign) {
   float sn, cs;
-  sincospif(2.0f * (float)(num % den) / (float)den, &sn, &cs);
+  // every length here is a power of two: the remainder is a mask (the general form stays for safety)
+  const int64_t r = (den & (den - 1)) == 0 ? (num & (den - 1)) : num % den;
+  sincospif(2.0f * (float)r / (float)den, &sn, &cs);
   return make_float2(cs, sign > 0 ? sn : -sn);
 }
 
@@ -573,31 +593,37 @@ __global__ void __launch_bounds__(256, 4) k_fft_cols256(const void* __restrict__
 // Column pass for len = 256 q, q = 2 or 4 (FFT lengths 2^21 and 2^22: long recordings, time
 // blocks): the same 16-column tile and lanes-over-columns loads as k_fft_cols256; the rows
 // are taken as q interleaved subsequences, each through the register FFT256, times
-// W_len^(a kb); a thread ends up with all q values of its own 16 (kb, column) pairs -- the
-// first q-1 parked in LDS words nobody else touches, the last in registers -- and finishes
-// them with a DFT_q.  (The generic radix-2 LDS pass these lengths used before took 4 x as
-// long per point.)  grid (ld/16, slots), dynamic LDS 37 KB + (q-1) x 32 KB
+// W_len^(a kb); a thread ends up with all q values of its own 16 (kb, column) pairs -- kept
+// in registers, one set of four in LDS (parking the first q-1 in LDS took 98 KB for q = 4: one
+// workgroup, i.e. one wave per SIMD, per CU, and 1.26 ms per 24 x 2^22 launch) -- and
+// finishes them with a DFT_q.
+// grid (ld/16, slots), 39 KB (q = 2) or 71 KB (q = 4) of LDS, two workgroups per CU (256
+// VGPRs; q = 4 still spills about 30 of its parked values to scratch, each stored and read
+// once): 0.5 ms per 24 x 2^22 launch
 template <int SIGN, bool REAL_IN, int LQ>
-__global__ void __launch_bounds__(256) k_fft_colsq(const void* __restrict__ in_, cf* __restrict__ out,
+__global__ void __launch_bounds__(256, 2) k_fft_colsq(const void* __restrict__ in_, cf* __restrict__ out,
                                                    int ld, int64_t in_cstride, int64_t out_cstride,
                                                    int64_t tw_n, const cf* __restrict__ tw4096,
                                                    const cf* __restrict__ tw256,
                                                    const double* __restrict__ sums, double inv_n,
                                                    const SegIn segs, int rows_out) {
   constexpr int q = 1 << LQ, len = 256 * q;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* const ex_re = reinterpret_cast<float*>(smem);
-  float* const ex_im = ex_re + 16 * kExColD;
-  cf* const park = reinterpret_cast<cf*>(ex_im + 16 * kExColD);   // [(q-1) * 16][256]
+  __shared__ float ex_re[16 * kExColD];
+  __shared__ float ex_im[16 * kExColD];
   const int c = blockIdx.y, col0 = blockIdx.x * 16, tid = threadIdx.x;   // c: workspace slot
   const int s = tid & 15, t = tid >> 4;
-  cf tw[16], v[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    cf w = tw256[(t * j) & 255];
+  __shared__ cf twl[256];                 // W256^(+-t j) at [j][t]: the FFT256's twiddles, read as broadcasts
+  {
+    cf w = tw256[((tid & 15) * (tid >> 4)) & 255];
     if (SIGN < 0) w.y = -w.y;
-    tw[j] = w;
+    twl[tid] = w;
   }
+  // q = 4: the first subsequence's values wait in LDS (32 KB of this thread's own words: no
+  // barrier), the next two in registers; q = 2: the one in registers
+  constexpr int kInLds = q == 4 ? 1 : 0, kInReg = q - 1 - kInLds;
+  __shared__ cf park[kInLds ? 16 * 256 : 1];
+  cf v[16], u[kInReg * 16];
+#pragma unroll
   for (int a = 0; a < q; ++a) {
     if (REAL_IN) {
       const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
@@ -615,33 +641,46 @@ __global__ void __launch_bounds__(256) k_fft_colsq(const void* __restrict__ in_,
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = x[(int64_t)(q * (t + 16 * j) + a) * ld];
     }
-    fft256_16t_aliased<SIGN>(v, tw, ex_re + s * kExColD, ex_im + s * kExColD, t);
+    __syncthreads();                      // twiddle table written / previous exchange read
+    fft256_16t_ldstw<SIGN>(v, twl + t, ex_re + s * kExColD, ex_im + s * kExColD, t);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int kb = t + 16 * j;
       const cf val = cmul(v[j], tw4096_at<SIGN>(tw4096, a * kb * (kRowLenDev / len)));
-      if (a < q - 1) park[(a * 16 + j) * 256 + tid] = val;    // this thread's own words
+      if (a < kInLds) park[j * 256 + tid] = val;
+      else if (a < q - 1) u[(a < q - 1 ? a - kInLds : 0) * 16 + j] = val;
       else v[j] = val;
     }
   }
   cf* o = out + (int64_t)c * out_cstride + col0 + s;
+  // output twiddle W_P^(col k), k = t + 16 j + 256 ka: three sincos per thread and the same
+  // 16-step recurrence over j as k_fft_cols256, three more steps over ka
+  cf stq = make_float2(1.f, 0.f), st16 = stq, wj = stq;
+  if (tw_n > 0) {
+    stq = unit_phase((int64_t)(col0 + s) * 256, tw_n, SIGN);
+    st16 = unit_phase((int64_t)(col0 + s) * 16, tw_n, SIGN);
+    wj = unit_phase((int64_t)(col0 + s) * t, tw_n, SIGN);
+  }
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int kb = t + 16 * j;
-    cf u[q];
+    cf w[q];
 #pragma unroll
-    for (int a = 0; a < q - 1; ++a) u[a] = park[(a * 16 + j) * 256 + tid];
-    u[q - 1] = v[j];
-    dft_small<SIGN, q>(u);
+    for (int a = 0; a < q - 1; ++a) w[a] = a < kInLds ? park[j * 256 + tid] : u[(a < kInLds ? 0 : a - kInLds) * 16 + j];
+    w[q - 1] = v[j];
+    dft_small<SIGN, q>(w);
+    cf ph = wj;
 #pragma unroll
     for (int ka = 0; ka < q; ++ka) {
       const int k = kb + 256 * ka;
       if (k < rows_out) {
-        cf val = u[ka];
-        if (tw_n > 0) val = cmul(val, unit_phase((int64_t)(col0 + s) * k, tw_n, SIGN));
+        cf val = w[ka];
+        if (tw_n > 0) val = cmul(val, ph);
         o[(int64_t)k * ld] = val;
       }
+      if (tw_n > 0) ph = cmul(ph, stq);
     }
+    if (tw_n > 0) wj = cmul(wj, st16);
   }
 }
 
@@ -1110,17 +1149,7 @@ template <int SIGN, bool REAL_IN, int LQ>
 static hipError_t launch_colsq(const void* in, cf* out, int ld, int64_t in_cstride, int64_t out_cstride,
                                int64_t tw_n, const cf* tw4096, const cf* tw256, const double* sums,
                                double inv_n, const SegIn& segs, int n_slots, int rows_out, hipStream_t st) {
-  const size_t lds = 2 * 16 * kExColD * sizeof(float) + (size_t)((1 << LQ) - 1) * 16 * 256 * sizeof(cf);
-  static bool attr_done[64] = {};            // per device and instantiation
-  int dev_ = 0;
-  (void)hipGetDevice(&dev_);
-  if (!attr_done[dev_ & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_fft_colsq<SIGN, REAL_IN, LQ>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done[dev_ & 63] = true;
-  }
-  hipLaunchKernelGGL((k_fft_colsq<SIGN, REAL_IN, LQ>), dim3(ld / 16, n_slots), dim3(256), lds, st, in, out,
+  hipLaunchKernelGGL((k_fft_colsq<SIGN, REAL_IN, LQ>), dim3(ld / 16, n_slots), dim3(256), 0, st, in, out,
                      ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, rows_out);
   return hipGetLastError();
 }
