@@ -767,6 +767,28 @@ def test_config5_regime_streamed_multichannel():
     np.testing.assert_array_equal(whole, out)
 
 
+def test_fft_length_2_22_blocks():
+    """bench.py --config 5's own FFT length: time blocks of 2^22 points (a 1024-point column
+    pass: k_fft_colsq with four interleaved FFT256s per column, real input), two channels with
+    different offsets, scales from 500 Hz down to 1.5 Hz at 30 kHz, against the oracle; and the
+    2^21-point plan of the same recording must give the same numbers to within rounding."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp
+    fs, C, n = 30000.0, 2, 4300000
+    f = np.array([500.0, 170.0, 41.0, 9.5, 1.5])
+    x = lfp(C, n, fs, seed=2222) + np.array([[40.0], [-3.0]], dtype=np.float32)
+    plan = CwtPlan(n, C, fs, f, output="amplitude", max_fft_log2=22)
+    segs = plan.segments()
+    assert any(s[2] == 1 << 22 for s in segs), segs
+    got = plan.execute(x)
+    for c in range(C):
+        ref = orc.cwt_amplitude(x[c].astype(np.float64), fs, f, n_threads=8)
+        assert rel_err(got[c], ref).max() < TOL, c
+    other = CwtPlan(n, C, fs, f, output="amplitude", max_fft_log2=21).execute(x)
+    scale = got.max(axis=-1, keepdims=True)
+    assert (np.abs(other - got) / scale).max() < 2e-6
+
+
 def test_other_family_members_on_the_device(golden):
     """higher-order wavelets and the 'energy' normalisation on the device --
     G12, made by the reference's ``morsewave(..., n_wavelets=, normalization=)``
