@@ -305,6 +305,47 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     }
     if (!moved) break;
   }
+  // A decimation that only a few scales reach is folded into the next lower one: every
+  // workgroup of a level pays a prologue worth about three scales of its walk (7.8 us against
+  // 2.5 us per scale, profiles/r02_synth_study.md 6), so e.g. 3 scales at R = 256 cost as much as
+  // 6, while walked by the R = 128 workgroups (block halo 22 -> 25 for all 18 scales) they cost
+  // 3.6.  Cost model per level: (3 + scales) / hop.  Only merges that keep the plain block
+  // layout (halo <= 32) are taken.  GHOSTCWT_MERGE_LEVELS=0 keeps every scale at its largest R.
+  {
+    const char* e = getenv("GHOSTCWT_MERGE_LEVELS");
+    if (!e || atoi(e) != 0) {
+      std::map<int, std::vector<int>> by_r;
+      for (int i = 0; i < prm.n_freqs; ++i)
+        if (hp->scales[i].method == GCWT_SCALE_SPECTRAL) by_r[hp->scales[i].decimation].push_back(i);
+      auto halo_of = [&](int r, const std::vector<int>& idx) {
+        int h = 16;
+        for (int i : idx) {
+          int hs = std::max((int)std::ceil(hp->scales[i].support / (double)r) + 2, 16);
+          if (r == 2) hs += hs & 1;
+          h = std::max(h, hs);
+        }
+        return h;
+      };
+      const double kPrologue = 3.0;
+      auto cost = [&](int r, const std::vector<int>& idx) {
+        return (kPrologue + (double)idx.size()) / (double)(B - 2 * halo_of(r, idx));
+      };
+      std::vector<int> rs;
+      for (const auto& kv : by_r) rs.push_back(kv.first);
+      for (size_t k = rs.size(); k-- > 1;) {           // from the largest decimation down
+        const int r = rs[k], r_lo = r / 2;
+        if (r_lo < 2 || !by_r.count(r_lo) || by_r[r].empty() || by_r[r_lo].empty()) continue;
+        std::vector<int> merged = by_r[r_lo];
+        merged.insert(merged.end(), by_r[r].begin(), by_r[r].end());
+        if (merged.size() > 256 || halo_of(r_lo, merged) > 32) continue;
+        if (cost(r_lo, merged) < cost(r, by_r[r]) + cost(r_lo, by_r[r_lo])) {
+          for (int i : by_r[r]) hp->scales[i].decimation = r_lo;
+          by_r[r_lo] = merged;
+          by_r[r].clear();
+        }
+      }
+    }
+  }
   int64_t lmax_spec = longest_fft_kernel();
   for (int i = 0; i < prm.n_freqs; ++i) {
     ScalePlan& sp = hp->scales[i];

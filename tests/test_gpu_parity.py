@@ -115,9 +115,10 @@ def test_config2_reduced(golden):
     err = rel_err(c[0][:, g["cols"]], g["complex_cols"].astype(np.complex128))
     assert err.max() < TOL, err
     np.testing.assert_allclose(np.abs(c[0]).max(axis=1), g["amplitude_rowmax"], rtol=2e-5)
-    # amplitude / power go through the production kernel (k_synth7), all eight decimation levels
+    # amplitude / power go through the production kernel (k_synth7), all seven decimation levels
+    # (the scales that reach R = 256 are folded into the R = 128 level)
     p, a = _plan(g["x"], float(g["fs"]), g["frequencies"], output="amplitude")
-    assert sorted(set(p.scale_info()["decimation"])) == [2, 4, 8, 16, 32, 64, 128, 256]
+    assert sorted(set(p.scale_info()["decimation"])) == [2, 4, 8, 16, 32, 64, 128]
     ref = np.abs(g["complex_cols"].astype(np.complex128))
     assert rel_err(a[0][:, g["cols"]], ref).max() < TOL
     p, pw = _plan(g["x"], float(g["fs"]), g["frequencies"], output="power")
@@ -510,7 +511,8 @@ def test_low_frequencies_at_high_sampling_rate():
     x = lfp_channel(n, fs, 8)
     f = [500.0, 80.0, 12.0, 6.0]
     p, c = _plan(x, fs, f, output="complex")
-    assert p.scale_info()["decimation"].tolist() == [32, 128, 1024, 2048]
+    # 6 Hz could run at R = 2048; alone there, it is walked by the R = 1024 workgroups instead
+    assert p.scale_info()["decimation"].tolist() == [32, 128, 1024, 1024]
     ref = orc.cwt_complex(x.astype(np.float64), fs, f)
     assert rel_err(c[0], ref).max() < TOL
     # 1 Hz at 30 kHz: 418 430-tap kernel, decimation 8192, in time blocks of 2^21

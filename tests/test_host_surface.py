@@ -211,7 +211,8 @@ def test_planner_through_the_abi():
     assert info["out_bytes"] == 128 * 100 * 1000000 * 4
     si = p.scale_info()
     assert si["length"][0] == 70 and si["length"][-1] == 6974
-    assert si["decimation"][0] == 2 and si["decimation"][-1] == 256
+    # the three scales that could run at R = 256 are walked by the R = 128 workgroups (planner.cpp)
+    assert si["decimation"][0] == 2 and si["decimation"][-1] == 128
     assert np.all(np.diff(si["decimation"]) >= 0)
     assert np.all(si["hop"] >= 32) and np.all(si["hop"] + 2 * si["halo"] == 256)
     # the measured band of every spectral scale fits its decimated band
@@ -353,13 +354,14 @@ def test_other_family_members_on_the_host(golden):
 
 def test_planner_measures_each_wavelet():
     """What the planner decides from the measured support of the kernel's response:
-    the default wavelet keeps the fast path with hop >= 210; heavy-tailed wavelets
+    the default wavelet keeps the fast path with hop >= 206 (212, and 206 for the level
+    that takes in the three scales of the thin top decimation); heavy-tailed wavelets
     (side lobes of the L-tap truncation above band_eps everywhere) leave it entirely."""
     fs, f = 1000.0, np.geomspace(200.0, 2.0, 100)
     p = CwtPlan(1000000, 128, fs, f)
     si, info = p.scale_info(), p.info
     assert info["n_spectral"] == 100 and info["n_direct"] == 0 and info["n_fullband"] == 0
-    assert si["hop"].min() >= 210 and si["halo"].max() <= 32
+    assert si["hop"].min() >= 206 and si["halo"].max() <= 32
     assert np.all(si["theta_hi"] * si["decimation"] <= 2 * np.pi * (1 + 1e-12))
     assert 0.80 < (si["support"] / (si["length"] / 2)).max() < 0.86
     # default grid: the top scales reach Nyquist and are short -> time domain
