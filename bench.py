@@ -302,11 +302,47 @@ def run_rank(args):
             line["check"] = {"rows": "channels {0,7,C-1} x scales {0,57%%,S-1} vs the oracle, "
                                      "tiled channels c / c+%d bit-equal" % distinct,
                              "worst_rel_err": float("%.3g" % worst)}
+        if world == 1 and not cfg5 and args.output == "amplitude" and not args.no_other_modes:
+            # Secondary measurement, after and outside the timed region: the same workload with the
+            # complex coefficients stored (8 B per coefficient: SURVEY.md 8d's second target).
+            obuf.free()
+            plan.close()
+            line["other_modes"] = {"complex": other_mode("complex", N, C, fs, freqs, S, xbuf, dev, lib, check)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fs, 1000000, freqs)
         emit(line)
     comm.close()
     return 0
+
+
+def other_mode(output, N, C, fs, freqs, S, xbuf, dev, lib, check, steps=5):
+    """ms per step and whole-job fraction of the HBM peak for another output mode of the same
+    workload (device-resident, plan prebuilt, `steps` timed executions after two warm-ups)."""
+    from ghost_amd.engine import CwtPlan, DeviceBuffer
+    plan = CwtPlan(N, C, fs, freqs, output=output, device=dev)
+    plan.upload()
+    plan.set_profiling(True)
+    obuf = DeviceBuffer(plan.info["out_bytes"])
+    for _ in range(2):                               # warm-up: the result pages are touched for the first time
+        plan.execute_device(xbuf, obuf)
+    check(lib.gcwt_device_synchronize())
+    synth = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.execute_device(xbuf, obuf)
+        synth += plan.timings()["synth_ms"]
+    check(lib.gcwt_device_synchronize())
+    el = (time.perf_counter() - t0) / steps
+    b_out = 8 if output == "complex" else 4
+    alg = C * N * (4 + S * b_out)
+    res = {"ms_per_step": round(el * 1e3, 4), "value": round(C * N / el / 1e6, 2), "unit": "Msamples/s",
+           "steps": steps, "algorithmic_bytes": int(alg),
+           "whole_job_frac_of_hbm_peak": round(alg / el / 1e9 / HBM_PEAK_GBS, 4),
+           "kernel_ms": round(synth / steps, 4),
+           "kernel_frac_of_hbm_peak": round(alg / (synth / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    obuf.free()
+    plan.close()
+    return res
 
 
 def main():
@@ -324,6 +360,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the complex-output measurement after the timed steps")
     ap.add_argument("--dry-run", default="", metavar="DIR",
                     help="launcher rehearsal: every rank writes DIR/rank<r>.json and exits (no GPU)")
     args = ap.parse_args()
