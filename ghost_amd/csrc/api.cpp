@@ -64,6 +64,13 @@ struct EpochDev {
   int n_items7 = 0;
 };
 
+// First-pass inputs of the synthesis whose bins lie above the scale's band are skipped
+// (kernels.hip: k_scale_windows).  GHOSTCWT_PRUNE_INPUTS=0 computes them all (A/B runs).
+inline bool prune_inputs() {
+  const char* e = getenv("GHOSTCWT_PRUNE_INPUTS");
+  return !e || atoi(e) != 0;
+}
+
 enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_FULLBAND, ST_COUNT };
 
 }  // namespace
@@ -96,6 +103,7 @@ struct gcwt_plan {
   float2* d_level_tw = nullptr;
   double* d_sums = nullptr;   // [C]
   int32_t* d_scale_list = nullptr;
+  int n_listed = 0;           // entries of d_scale_list (all levels)
   BankScale* d_bank_sc = nullptr;
   DirectScale* d_direct_sc = nullptr;
   std::vector<EpochDev> ep_dev;
@@ -413,6 +421,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   }
   if ((rc = upload_vec(&p->d_half_tw, half_tw, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_scale_list, scale_list, p->stream))) return bail(rc);
+  p->n_listed = (int)scale_list.size();
   p->ep_dev.resize(hp.epochs.size());
   for (size_t e = 0; e < hp.epochs.size(); ++e) {
     const EpochPlan& ep = hp.epochs[e];
@@ -452,6 +461,9 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
 
   hipError_t he = launch_build_bank(p->d_bank, p->d_gain, p->d_bank_sc, p->d_amps, S, B, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_bank"));
+  he = launch_scale_windows(p->d_gain, p->d_scale_list, prune_inputs() ? p->n_listed : 0,
+                            (float)hp.band_tol, p->stream);
+  if (he != hipSuccess) return bail(hip_err(he, "scale_windows"));
   he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, p->d_amps, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_direct"));
   he = hipStreamSynchronize(p->stream);  // host vectors above go out of scope
@@ -913,6 +925,9 @@ int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, 
 int gcwt_internal_refresh_bank(gcwt_plan* p) {   // derived tables follow a (broadcast) bank
   hipError_t he = launch_bank_gain(p->d_bank, p->d_gain, p->d_bank_sc, p->hp.prm.n_freqs, p->stream);
   if (he != hipSuccess) return hip_err(he, "bank_gain");
+  he = launch_scale_windows(p->d_gain, p->d_scale_list, prune_inputs() ? p->n_listed : 0,
+                            (float)p->hp.band_tol, p->stream);
+  if (he != hipSuccess) return hip_err(he, "scale_windows");
   return GCWT_OK;
 }
 int gcwt_internal_set_error(int code, const char* msg) { return set_err(code, msg); }

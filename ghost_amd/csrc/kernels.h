@@ -121,6 +121,12 @@ hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double*
                               hipStream_t st);
 hipError_t launch_build_bank(float2* bank, float* gain, const BankScale* sc, const double* amps,
                              int n_scales, int B, hipStream_t st);
+// A level's scale list entry: scale index in the low 24 bits; in the top 8, 16 - j_hi: the
+// synthesis may skip the first-pass inputs j >= j_hi (bins from 16 j_hi up) of that scale
+// (k_scale_windows).
+constexpr int kScaleIndexMask = 0x00FFFFFF;
+hipError_t launch_scale_windows(const float* gain, int32_t* scale_list, int n_listed, float tol,
+                                hipStream_t st);
 hipError_t launch_bank_gain(const float2* bank, float* gain, const BankScale* sc, int n_scales,
                             hipStream_t st);
 // full-band scales (exact.hip): H[k] / P on the k1-major grid of a P-point spectrum, the

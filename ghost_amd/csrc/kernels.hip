@@ -211,6 +211,35 @@ __global__ void k_bank_gain(const cf* __restrict__ bank, float* __restrict__ gai
   gain[(int64_t)s * 256 + k] = h.x * cs - h.y * sn;
 }
 
+// Which of the sixteen first-pass inputs of the synthesis (input j = bins 16 j .. 16 j + 15 of
+// the scale's 256-bin block response) are negligible above the band: every bin from 16 j_hi up
+// is below tol = the plan's band tolerance times the peak gain -- the same tolerance that lets
+// the decimation drop everything from theta_hi up.  16 - j_hi goes into the top byte of the
+// scale's entry in its level's list.  (Nothing is skipped below the band: the L-tap
+// truncation's side lobes stay near 1e-8 of the peak down to zero frequency, and recordings
+// carry most of their power there.)
+// grid (n_listed), block (256)
+__global__ void k_scale_windows(const float* __restrict__ gain, int32_t* __restrict__ scale_list, float tol) {
+  __shared__ float red[4];
+  __shared__ int last;
+  const int k = threadIdx.x;
+  const int s = scale_list[blockIdx.x] & kScaleIndexMask;
+  const float g = fabsf(gain[(int64_t)s * 256 + k]);
+  float m = g;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((k & 63) == 0) red[k >> 6] = m;
+  if (k == 0) last = -1;
+  __syncthreads();
+  const float peak = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (g > tol * peak) atomicMax(&last, k);
+  __syncthreads();
+  if (k == 0) {
+    const int j_hi = min(16, max(9, (last + 16) >> 4));       // ceil((last + 1) / 16), inputs 0..8 always kept
+    scale_list[blockIdx.x] = s | ((16 - j_hi) << 24);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // literal kernels for direct scales: psi[n] = (1/L) sum_j A_j e^{i pi j (L+1)/L} e^{2 pi i j n / L}
 // over the scale's kept spectrum samples A_j (planner.h: amps)    (morseutils.py:147-149)
@@ -1126,6 +1155,14 @@ hipError_t launch_build_bank(cf* bank, float* gain, const BankScale* sc, const d
 hipError_t launch_bank_gain(const cf* bank, float* gain, const BankScale* sc, int n_scales,
                             hipStream_t st) {
   hipLaunchKernelGGL(k_bank_gain, dim3(n_scales), dim3(256), 0, st, bank, gain, sc);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_scale_windows(const float* gain, int32_t* scale_list, int n_listed, float tol,
+                                hipStream_t st) {
+  if (n_listed <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scale_windows, dim3(n_listed), dim3(256), 0, st, gain, scale_list, tol);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

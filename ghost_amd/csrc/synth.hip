@@ -86,7 +86,8 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   auto fill_stage = [&](int b0) {
     for (int i = tid; i < kChunk * 256; i += kThreads) {
       const int sb = min(b0 + (i >> 8), lv.n_scales - 1);
-      stage[(i >> 8) * kGainRow + (i & 15) * 20 + ((i >> 4) & 15)] = a.gain[(int64_t)scales[sb] * 256 + (i & 255)];
+      stage[(i >> 8) * kGainRow + (i & 15) * 20 + ((i >> 4) & 15)] =
+          a.gain[(int64_t)(scales[sb] & kScaleIndexMask) * 256 + (i & 255)];
     }
   };
   fill_stage(0);
@@ -204,20 +205,16 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
       }
     }
     const float4* const hs = reinterpret_cast<const float4*>(st_rd + (b & (kChunk - 1)) * kGainRow);
+    // the entry's top byte: 16 - j_hi, first-pass inputs j >= j_hi are left out for this scale (kernels.h)
+    const int entry = __builtin_amdgcn_readfirstlane(sc_lds[b]);
     v2f v[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 g = hs[q];
-      v[4 * q] = pw[4 * q] * g.x;
-      v[4 * q + 1] = pw[4 * q + 1] * g.y;
-      v[4 * q + 2] = pw[4 * q + 2] * g.z;
-      v[4 * q + 3] = pw[4 * q + 3] * g.w;
+    switch ((unsigned)entry >> 24) {             // wave-uniform; 16 - j_hi
+#define GCWT_WINDOW(hi) case 16 - (hi): gain_first_layer<hi>(v, pw, hs); break;
+      GCWT_WINDOW(15) GCWT_WINDOW(14) GCWT_WINDOW(13) GCWT_WINDOW(12) GCWT_WINDOW(11) GCWT_WINDOW(10) GCWT_WINDOW(9)
+#undef GCWT_WINDOW
+      default: gain_first_layer<16>(v, pw, hs); break;
     }
-#ifdef GCWT_PRUNE_TEST   // measurement build only (wrong results): upper bound of input pruning
-#pragma unroll
-    for (int j = 0; j < 16; ++j) if (j < GCWT_PRUNE_LO || j >= GCWT_PRUNE_HI) v[j] = (v2f){0.f, 0.f};
-#endif
-    idft16v(v);
+    idft16v_tail(v);
 #pragma unroll
     for (int j = 0; j < 16; ++j) exw[j * sstride] = cmulv(v[dft16_pos(j)], twl[16 * j + t]);
     if (!(a.drop_stores & 2)) __syncthreads();      // (measurement builds clear these bits: kernels.h)
@@ -227,7 +224,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     idft16v(v);
 
     // descriptor built from provably wave-uniform words (else hipcc waterfalls every store)
-    const int srow = __builtin_amdgcn_readfirstlane(sc_lds[b]);
+    const int srow = entry & kScaleIndexMask;
     const uint64_t dst_bits = reinterpret_cast<uint64_t>(out0 + (int64_t)srow * a.row_len * kElem);
     const uint32_t dst_lo = __builtin_amdgcn_readfirstlane((uint32_t)dst_bits);
     const uint32_t dst_hi = __builtin_amdgcn_readfirstlane((uint32_t)(dst_bits >> 32));

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(32 * NCOL) k_synth8(const Synth7Args a) {
   const bool wide = R > kCols;
   const int n_scales = lv.n_scales;
   const int* const scales = a.scale_list + lv.scale_offset;
-  for (int i = threadIdx.x; i < n_scales; i += 2 * kRole) sc_lds[i] = scales[i];
+  for (int i = threadIdx.x; i < n_scales; i += 2 * kRole) sc_lds[i] = scales[i] & kScaleIndexMask;   // (this kernel computes every first-pass input)
 
   // The two roles run separate loops (their registers never coexist); the workgroup barrier
   // counts waves, not call sites, and both loops pass it exactly 2 + n_scales times.
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(32 * NCOL) k_synth8(const Synth7Args a) {
       for (int q = 0; q < 4; ++q) {
         const int i = tid + kRole * q;
         const int sb = min(b0 + (i >> 8), n_scales - 1);
-        gq[q] = a.gain[(int64_t)scales[sb] * 256 + (i & 255)];
+        gq[q] = a.gain[(int64_t)(scales[sb] & kScaleIndexMask) * 256 + (i & 255)];
       }
     };
     auto park_gains = [&](int chunk) {      // registers -> stage[chunk & 1]

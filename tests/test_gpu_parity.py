@@ -769,6 +769,33 @@ def test_config5_regime_streamed_multichannel():
     np.testing.assert_array_equal(whole, out)
 
 
+def test_first_pass_windows_beside_strong_tones(monkeypatch):
+    """The synthesis skips, per scale, the first-pass inputs whose bins lie above the scale's
+    band (gain below band_eps of the peak there: k_scale_windows).  A recording with tones 20 x
+    the background just above the bands of three scales -- inside what is skipped -- must still
+    meet the gate, and must agree with the build that computes every input."""
+    from ghost_amd.synthetic import lfp_channel
+    fs, n = 1000.0, 60000
+    f = np.geomspace(100.0, 5.0, 24)
+    x = lfp_channel(n, fs, 3).astype(np.float64)
+    t = np.arange(n) / fs
+    amp = 20.0 * x.std()
+    for k in (3, 10, 17):
+        x += amp * np.sin(2 * np.pi * 1.9 * f[k] * t + k)
+    x = x.astype(np.float32)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f)
+    p, c = _plan(x, fs, f, output="complex")
+    assert rel_err(c[0], ref).max() < TOL
+    p, a = _plan(x, fs, f, output="amplitude")
+    assert rel_err(a[0], np.abs(ref)).max() < TOL
+    monkeypatch.setenv("GHOSTCWT_PRUNE_INPUTS", "0")
+    p, c_all = _plan(x, fs, f, output="complex")
+    monkeypatch.delenv("GHOSTCWT_PRUNE_INPUTS")
+    assert rel_err(c_all[0], ref).max() < TOL
+    diff = np.abs(c_all[0] - c[0]).max(axis=1) / np.abs(ref).max(axis=1)
+    assert 0 < diff.max() < 2e-6, diff          # inputs are skipped, and what they carried is below the tolerance
+
+
 def test_fft_length_2_22_blocks():
     """bench.py --config 5's own FFT length: time blocks of 2^22 points (a 1024-point column
     pass: k_fft_colsq with four interleaved FFT256s per column, real input), two channels with
