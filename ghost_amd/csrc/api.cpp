@@ -86,6 +86,9 @@ struct gcwt_plan {
   bool use_synth16 = false;   // GHOSTCWT_SYNTH16=1: 16-column kernel for every output mode (A/B tests)
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t aux[2] = {nullptr, nullptr};   // the level passes of a batch run beside each other (run_pipeline)
+  bool level_streams = true;  // GHOSTCWT_LEVEL_STREAMS=0: everything on `stream`
+  hipStream_t cur = nullptr;  // the stream the stage in hand is launched on (profiling spans follow it)
   // workspace
   float2* d_x = nullptr;      // [C][max_p]   spectrum (k1-major)
   float2* d_xr = nullptr;     // [C][max_xr]  decimated analytic signals, all levels
@@ -154,6 +157,7 @@ void free_dev(gcwt_plan* p) {
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
   p->ev_pool.clear();
   if (p->stream) { (void)hipStreamDestroy(p->stream); p->stream = nullptr; }
+  for (auto& q : p->aux) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
   p->uploaded = false;
 }
 
@@ -167,7 +171,7 @@ int get_event(gcwt_plan* p, hipEvent_t* e) {
   return GCWT_OK;
 }
 
-// RAII-less span helper: begin/end record events on the plan stream when profiling
+// RAII-less span helper: begin/end record events on the stage's stream when profiling
 struct SpanGuard {
   gcwt_plan* p;
   int stage;
@@ -176,14 +180,14 @@ struct SpanGuard {
   SpanGuard(gcwt_plan* p_, int st) : p(p_), stage(st) {
     if (!p->profiling) return;
     rc = get_event(p, &a);
-    if (rc == GCWT_OK && hipEventRecord(a, p->stream) != hipSuccess) rc = GCWT_ERR_HIP;
+    if (rc == GCWT_OK && hipEventRecord(a, p->cur ? p->cur : p->stream) != hipSuccess) rc = GCWT_ERR_HIP;
   }
   int end() {
     if (!p->profiling || rc) return rc;
     hipEvent_t b;
     rc = get_event(p, &b);
     if (rc) return rc;
-    if (hipEventRecord(b, p->stream) != hipSuccess) return GCWT_ERR_HIP;
+    if (hipEventRecord(b, p->cur ? p->cur : p->stream) != hipSuccess) return GCWT_ERR_HIP;
     p->spans.push_back({stage, a, b});
     return GCWT_OK;
   }
@@ -340,6 +344,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   const int S = hp.prm.n_freqs, B = hp.block;
   int rc;
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  for (auto& q : p->aux) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+  if (const char* e = getenv("GHOSTCWT_LEVEL_STREAMS")) p->level_streams = atoi(e) != 0;
   auto bail = [&](int code) { free_dev(p); return code; };
 
   const bool any_fft = hp.n_direct < S;   // spectral or full-band scales: they share X
@@ -564,10 +570,35 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
                                 hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0));
     // the production synthesis kernel computes its blocks' spectra itself (no XB pass)
     const bool fused_blocks = p->fuse_blocks && p->synth_kernel == 7 && !p->use_synth16;
+    // The levels are independent once the spectrum is there (rows pass -> column pass per
+    // level, disjoint x_R); run one after the other they leave 10 us between launches and the
+    // small ones (R >= 16: grids that do not fill the chip) cost 0.2 ms.  Three streams take
+    // them in turn -- level l on stream l mod 3, the plan's own stream being one of them --
+    // and join before the synthesis.
+    const bool side = p->level_streams && hp.levels.size() > 2;
+    bool forked[2] = {false, false};
+    hipEvent_t spectrum_ready = nullptr;
+    if (side) {
+      int rc_ = get_event(p, &spectrum_ready);
+      if (rc_) return rc_;
+      he = hipEventRecord(spectrum_ready, st);
+      if (he != hipSuccess) return hip_err(he, "hipEventRecord");
+    }
     for (size_t l = 0; l < hp.levels.size(); ++l) {
       const LevelPlan& lp = hp.levels[l];
       const EpochLevel& el = ep.lv[l];
       float2* xr = p->d_xr + el.xr_offset;
+      hipStream_t ls = st;
+      if (side) {                          // level (and whoever shares its x_R) -> its own stream
+        const int k = lp.xr_owner % 3;
+        ls = k == 0 ? st : p->aux[k - 1];
+        if (k > 0 && !forked[k - 1]) {
+          he = hipStreamWaitEvent(ls, spectrum_ready, 0);
+          if (he != hipSuccess) return hip_err(he, "hipStreamWaitEvent");
+          forked[k - 1] = true;
+        }
+        p->cur = ls;
+      }
       if (lp.xr_owner != (int)l) {
         // x_R of this decimation was made for the level that owns it (an earlier one)
       } else if (lp.decimation <= kMaxTwoPassDecimation) {
@@ -575,21 +606,33 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         // x_R[Q m1 + m2] = sum_{j1} e^{2 pi i j1 m1/P1} e^{2 pi i j1 m2/M} sum_{j2} X~[j1][j2] e^{2 pi i j2 m2/Q}
         RUN(ST_DECIM, launch_fft_rows(+1, p->d_x, xr, Q, P1, kRowLen, Q, P, hp.max_xr,
                                       P1 > 1 ? el.m : 0, p->d_tw4096,
-                                      fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, st));
+                                      fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, ls));
         if (P1 > 1)
           RUN(ST_DECIM, launch_fft_cols(+1, false, xr, xr, P1, Q, hp.max_xr, hp.max_xr, 0,
                                         p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums,
-                                        inv_n, 0, slots, st));
+                                        inv_n, 0, slots, ls));
       } else {
         // M = P/R <= 8192: rows j1 < n1 of X~, q leading entries each
         const int n1 = (int)std::min<int64_t>(P1, el.m);
         const int q = (int)(el.m / n1);
-        RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, slots, st));
+        RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, slots, ls));
       }
       const float scale = (float)(1.0 / ((double)hp.block * (double)P));
       if (!fused_blocks || !lp.fast)     // levels of the 16-column kernel read XB
         RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.blk_lo,
-                                       el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, slots, st));
+                                       el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, slots, ls));
+    }
+    if (side) {
+      p->cur = nullptr;
+      for (int k = 0; k < 2; ++k) {
+        if (!forked[k]) continue;
+        hipEvent_t done;
+        int rc_ = get_event(p, &done);
+        if (rc_) return rc_;
+        he = hipEventRecord(done, p->aux[k]);
+        if (he == hipSuccess) he = hipStreamWaitEvent(st, done, 0);
+        if (he != hipSuccess) return hip_err(he, "level streams join");
+      }
     }
     const EpochDev& dev = p->ep_dev[ep.batch_first];
     if (dev.n_items > 0) {
@@ -740,16 +783,30 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   }
   HIP_TRY(hipStreamSynchronize(p->stream));
   if (p->profiling) {
+    // A stage's time is the length of the union of its spans (the level passes run on three
+    // streams beside each other: their sum would count the same wall time up to three times).
     float acc[ST_COUNT] = {0};
-    for (const auto& s : p->spans) {
-      float ms = 0;
-      HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
-      acc[s.stage] += ms;
-    }
     if (!p->spans.empty()) {
-      float tot = 0;
-      HIP_TRY(hipEventElapsedTime(&tot, p->spans.front().a, p->spans.back().b));
-      p->last.total_ms = tot;
+      const hipEvent_t t0 = p->spans.front().a;
+      std::vector<std::pair<float, float>> iv[ST_COUNT];
+      float last_end = 0;
+      for (const auto& s : p->spans) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, t0, s.a));
+        HIP_TRY(hipEventElapsedTime(&b, t0, s.b));
+        iv[s.stage].push_back({a, b});
+        last_end = std::max(last_end, b);
+      }
+      for (int st = 0; st < ST_COUNT; ++st) {
+        std::sort(iv[st].begin(), iv[st].end());
+        float lo = 0, hi = -1;
+        for (const auto& x : iv[st]) {
+          if (hi < lo || x.first > hi) { if (hi >= lo) acc[st] += hi - lo; lo = x.first; hi = x.second; }
+          else hi = std::max(hi, x.second);
+        }
+        if (hi >= lo) acc[st] += hi - lo;
+      }
+      p->last.total_ms = last_end;
     }
     p->last.mean_ms = acc[ST_MEAN];
     p->last.fwd_fft_ms = acc[ST_FWD];
