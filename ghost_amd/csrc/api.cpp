@@ -490,6 +490,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
   const double inv_n = 1.0 / (double)N;
   hipStream_t st = p->stream;
   hipError_t he;
+  p->cur = nullptr;            // (an earlier call may have failed between a fork and its join)
 #define RUN(stage_id, call)                         \
   do {                                              \
     SpanGuard sg_(p, stage_id);                     \
