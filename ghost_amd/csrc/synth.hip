@@ -216,16 +216,8 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     }
     idft16v_tail(v);
 #pragma unroll
-    for (int j = 1; j < 16; ++j) v[dft16_pos(j)] = cmulv(v[dft16_pos(j)], twl[16 * j + t]);   // W256^(t j); j = 0 is 1
-    if (sstride == NCOL) {
-      // R >= NCOL: the row pitch is a compile-time constant, so pairs of rows go out as
-      // ds_write2_b64 (6.8 cycles per pair against 2 x 4.9: profiles/r02_synth_study.md 1)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) exw[j * NCOL] = v[dft16_pos(j)];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) exw[j * sstride] = v[dft16_pos(j)];
-    }
+    for (int j = 0; j < 16; ++j)              // W256^(t j); j = 0 is 1
+      exw[j * sstride] = j == 0 ? v[0] : cmulv(v[dft16_pos(j)], twl[16 * j + t]);
     if (!(a.drop_stores & 2)) __syncthreads();      // (measurement builds clear these bits: kernels.h)
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) v[k1] = exr[k1 * kPlane];
