@@ -796,6 +796,22 @@ def test_first_pass_windows_beside_strong_tones(monkeypatch):
     assert 0 < diff.max() < 2e-6, diff          # inputs are skipped, and what they carried is below the tolerance
 
 
+def test_repeated_executes_are_bit_identical():
+    """The level passes of a batch run on three streams that fork after the forward FFT and join
+    before the synthesis (api.cpp: run_pipeline); a missing dependency would show up as
+    run-to-run differences.  Seven decimation levels, two epochs, 8 repeats."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp
+    fs, C, n = 1000.0, 3, 120000
+    f = np.geomspace(200.0, 2.0, 60)
+    x = lfp(C, n, fs, seed=78)
+    p = CwtPlan(n, C, fs, f, output="amplitude", epoch_bounds=[[0, 70000], [70300, n]])
+    assert len(set(p.scale_info()["decimation"])) >= 6
+    first = p.execute(x)
+    for _ in range(8):
+        np.testing.assert_array_equal(p.execute(x), first)
+
+
 def test_fft_length_2_22_blocks():
     """bench.py --config 5's own FFT length: time blocks of 2^22 points (a 1024-point column
     pass: k_fft_colsq with four interleaved FFT256s per column, real input), two channels with
