@@ -23,15 +23,18 @@ namespace gcwt {
 // phases (R <= 32), or one block x 32 of its phases (R >= 64) -- and walks over
 // the SCALES of the level.  What never changes for a thread,
 //     P[k] = XB_blk[k] * W^{k r},   k = t + 16 j,
-// is built once and kept in 32 VGPRs; what changes per batch, the scale's filter
-// H_s[k] (2 KB), is fetched one batch ahead by the first 256 threads and parked in
-// LDS, from where every column reads it as a broadcast.  Per batch and thread:
-//   v = P * H_s          16 complex multiplies
-//   DFT16, W256 twiddle (table in LDS), transpose + re-deal through LDS
-//   DFT16, |.|, 14 stores of 4 B per lane: 256 contiguous bytes per wave store
+// is built once and kept in 32 VGPRs; what changes per batch, the scale's real gain
+// G_s[k] (1 KB), is fetched eight scales at a time and parked in LDS, each lane's sixteen
+// values side by side (four 16-byte reads per scale).  Per batch and thread:
+//   v = P * G_s          complex x real, only the inputs below the scale's j_hi (the bins
+//                        above its band are skipped: kernels.h, k_scale_windows), folded
+//                        into the first radix-4 layer
+//   rest of DFT16, W256 twiddle (table in LDS), transpose + re-deal through LDS
+//   DFT16, |.|, 14 stores of 4 B per lane: 256 contiguous bytes per wave store, nt
 // With 16 <= halo <= 32 rows 0 and 15 of a thread's 16 outputs are always halo,
 // rows 2..13 are always kept and rows 1 / 14 are kept lane-wise.
-// LDS: 16 x 513 complex + 256 complex + 8 x 320 gains + 256 indices = 71.9 KB -> two workgroups per CU.
+// LDS: 16 x 513 complex + 256 complex + 8 x 320 gains + 256 indices = 77 KB -> two
+// workgroups per CU.  128 VGPRs.
 // ---------------------------------------------------------------------------
 template <int MODE, int NCOL>
 __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
