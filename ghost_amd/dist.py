@@ -163,14 +163,28 @@ class Comm:
         return min(vals) if negate else max(vals)
 
     # -- interface ------------------------------------------------------------
+    def _rccl_failed(self, what, err):
+        """An RCCL call failed after set-up: note it, drop the communicator and let the caller
+        serve the operation from the file backend (a failure every rank sees -- the common kind --
+        leaves them all in step; ``backend`` then reads 'file' and ``rccl_error`` says why)."""
+        self.rccl_error = "%s: %s" % (what, err)
+        try:
+            self._drop_rccl()
+        except Exception:
+            self._handle = None
+        self.backend = "file"
+
     def barrier(self):
         if self.world == 1:
             return
         if self._handle:
             from ._lib import lib, check
-            check(lib.gcwt_comm_barrier(self._handle))
-        else:
-            self._file_allreduce_max(0.0, "barrier")
+            try:
+                check(lib.gcwt_comm_barrier(self._handle))
+                return
+            except Exception as e:
+                self._rccl_failed("barrier", e)
+        self._file_allreduce_max(0.0, "barrier")
 
     def allreduce_max(self, value):
         if self.world == 1:
@@ -178,8 +192,11 @@ class Comm:
         if self._handle:
             from ._lib import lib, check
             v = C.c_double(float(value))
-            check(lib.gcwt_comm_allreduce_max(self._handle, C.byref(v)))
-            return v.value
+            try:
+                check(lib.gcwt_comm_allreduce_max(self._handle, C.byref(v)))
+                return v.value
+            except Exception as e:
+                self._rccl_failed("allreduce_max", e)
         return self._file_allreduce_max(value, "max")
 
     def broadcast_bank(self, plan, root=0):
@@ -188,8 +205,11 @@ class Comm:
         plan.upload()                     # every rank builds its bank with the HIP kernel
         if self._handle:
             from ._lib import lib, check
-            check(lib.gcwt_comm_broadcast_bank(self._handle, plan._handle, root))
-            return "rccl_broadcast"
+            try:
+                check(lib.gcwt_comm_broadcast_bank(self._handle, plan._handle, root))
+                return "rccl_broadcast"
+            except Exception as e:        # every rank has built the same bank itself already
+                self._rccl_failed("broadcast_bank", e)
         return "local_build"
 
     def close(self):

@@ -128,3 +128,48 @@ def test_bench_launches_its_own_ranks(tmp_path):
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4",
                           "--dry-run", str(tmp_path)], env=env2, capture_output=True, timeout=120)
     assert res.returncode != 0 and b"WORLD_SIZE=2 but --gpus 4" in res.stderr
+
+
+def test_rccl_failure_after_setup_falls_back_to_files(tmp_path, monkeypatch):
+    """An RCCL call that fails after the communicator was set up must not take the run down:
+    the operation is served by the file backend, the communicator is dropped and the reason is
+    kept (bench.py prints it as config.rccl_error)."""
+    import threading
+    import ghost_amd._lib as _lib
+    from ghost_amd.dist import Comm
+
+    class Broken:                       # stands in for libghostcwt's RCCL entry points
+        destroyed = 0
+
+        def gcwt_comm_barrier(self, h):
+            return -7
+
+        def gcwt_comm_allreduce_max(self, h, v):
+            return -7
+
+        def gcwt_comm_destroy(self, h):
+            Broken.destroyed += 1
+            return 0
+
+        def gcwt_last_error(self):
+            return b"ncclAllReduce: unhandled system error"
+
+    monkeypatch.setattr(_lib, "lib", Broken())
+    out = {}
+
+    def rank(r):
+        c = Comm(r, 2, use_rccl=False, session=str(tmp_path), timeout=20.0)
+        c._handle, c.backend = object(), "rccl"          # as if set-up had succeeded
+        c.barrier()
+        out[r] = (c.allreduce_max(10.0 + r), c.backend, c.rccl_error, c._handle)
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    for r in range(2):
+        value, backend, err, handle = out[r]
+        assert value == 11.0 and backend == "file" and handle is None
+        assert "barrier" in err and "unhandled system error" in err
+    assert Broken.destroyed == 2
