@@ -10,6 +10,14 @@
 
 namespace gcwt {
 
+// Decimated samples a block gives up at each edge beyond the kernel's measured support.  One is
+// structural (a phase r/R of the synthesis looks up to one decimated sample past its block
+// position); the second is slack.  GHOSTCWT_HALO_MARGIN overrides (measurement).
+static int halo_margin() {
+  const char* e = getenv("GHOSTCWT_HALO_MARGIN");
+  return e ? std::max(0, atoi(e)) : 2;
+}
+
 double morse_log_gain(double u, double gamma, double beta) {
   return beta * std::log(u) - (beta / gamma) * (std::pow(u, gamma) - 1.0);
 }
@@ -296,7 +304,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       while (2 * r <= r_cap && sp.theta_hi * (2.0 * r) <= 2.0 * M_PI) r *= 2;
       sp.decimation = r;
       // decimated samples discarded at each block edge: the kernel's measured support
-      int halo = std::max((int)std::ceil(sp.support / (double)r) + 2, 16);
+      int halo = std::max((int)std::ceil(sp.support / (double)r) + halo_margin(), 16);
       if (r == 2) halo += halo & 1;   // keeps halo*R a multiple of 4: 16-byte aligned tile runs
       if (B - 2 * halo < 32) {        // does not fit the block at the largest decimation it allows
         sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
@@ -320,7 +328,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       auto halo_of = [&](int r, const std::vector<int>& idx) {
         int h = 16;
         for (int i : idx) {
-          int hs = std::max((int)std::ceil(hp->scales[i].support / (double)r) + 2, 16);
+          int hs = std::max((int)std::ceil(hp->scales[i].support / (double)r) + halo_margin(), 16);
           if (r == 2) hs += hs & 1;
           h = std::max(h, hs);
         }
@@ -412,7 +420,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     // Decimated samples discarded at each block edge: the kernel's measured support (the
     // reference length L is "4 footprints to be safe", morse.py:113-116; what lies beyond
     // `support` holds less than support_tol of the kernel's energy), plus two.
-    int halo = std::max((int)std::ceil(sp.support / (double)r) + 2, 16);
+    int halo = std::max((int)std::ceil(sp.support / (double)r) + halo_margin(), 16);
     if (r == 2) halo += halo & 1;   // keeps halo*R a multiple of 4: 16-byte aligned tile runs
     const std::pair<int, int> key(r, split && halo > 16 ? 1 : 0);
     auto it = level_of.find(key);
