@@ -15,8 +15,8 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-enum { PK_FMA, PK_ADD, SQRT, LDS_W64, LDS_R64, LDS_R128, EXCHANGE, STORE, MIX, MIXSTORE, STORE_DEF, STORE4, STORE4_DEF, STORE2, N_MODES };
-static const char* kNames[N_MODES] = {"pk_fma", "pk_add", "sqrt", "lds_w64", "lds_r64", "lds_r128", "exchange", "store", "mix", "mixstore", "store_def", "store4", "store4_def", "store2"};
+enum { PK_FMA, PK_ADD, SQRT, LDS_W64, LDS_R64, LDS_R128, EXCHANGE, STORE, MIX, MIXSTORE, STORE_DEF, STORE4, STORE4_DEF, STORE2, DPP_ADD, ADD, N_MODES };
+static const char* kNames[N_MODES] = {"pk_fma", "pk_add", "sqrt", "lds_w64", "lds_r64", "lds_r128", "exchange", "store", "mix", "mixstore", "store_def", "store4", "store4_def", "store2", "dpp_add", "add"};
 
 constexpr int kPlane = 513;
 
@@ -48,6 +48,24 @@ __global__ void __launch_bounds__(512) k_run(float* out, float* sink, int iters,
       for (int rep = 0; rep < 12; ++rep)
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
+    }
+    if (MODE == DPP_ADD) {               // plain f32 add with a cross-lane (quad_perm) source: 2 per pair
+#pragma unroll
+      for (int rep = 0; rep < 12; ++rep)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(a[(i + 1) & 15].x));
+          asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(a[i].y) : "v"(a[(i + 1) & 15].y));
+        }
+    }
+    if (MODE == ADD) {                   // plain f32 add, 2 per pair
+#pragma unroll
+      for (int rep = 0; rep < 12; ++rep)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i].x) : "v"(a[(i + 1) & 15].x));
+          asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i].y) : "v"(a[(i + 1) & 15].y));
+        }
     }
     if (MODE == SQRT) {
 #pragma unroll
@@ -124,7 +142,7 @@ __global__ void __launch_bounds__(512) k_run(float* out, float* sink, int iters,
 
 template <int MODE>
 void drive(double seconds, float* out, float* sink, long long* clk, int grid) {
-  const int iters = (MODE == STORE || MODE >= STORE_DEF) ? 200 : 2000;
+  const int iters = (MODE == STORE || (MODE >= STORE_DEF && MODE <= STORE2)) ? 200 : 2000;
   hipLaunchKernelGGL((k_run<MODE>), dim3(grid), dim3(512), 0, 0, out, sink, 10, clk);
   CK(hipDeviceSynchronize());
   const auto t0 = std::chrono::steady_clock::now();
@@ -141,7 +159,7 @@ void drive(double seconds, float* out, float* sink, long long* clk, int grid) {
   const double per_iter_us = el * 1e6 / ((double)launches * iters);
   printf("%-9s %.2f s, %.3f us per iteration of a CU's 16 waves, in-kernel clock %.3f GHz", kNames[MODE], el, per_iter_us,
          (double)h[0] / ((double)h[1] * 10.0) );
-  if (MODE == STORE || MODE == MIXSTORE || MODE >= STORE_DEF) printf(", %.2f TB/s", 14.0 * grid * 512 * 4 / per_iter_us / 1e6);
+  if (MODE == STORE || MODE == MIXSTORE || (MODE >= STORE_DEF && MODE <= STORE2)) printf(", %.2f TB/s", 14.0 * grid * 512 * 4 / per_iter_us / 1e6);
   printf("\n");
 }
 
@@ -154,7 +172,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&sink, (size_t)2048 * grid * 512 * 4));   // 2 GiB: 2048 rows of one float per thread
   if (!strcmp(mode, "idle")) { printf("idle\n"); fflush(stdout); std::this_thread::sleep_for(std::chrono::duration<double>(seconds)); return 0; }
 #define CASE(M) if (!strcmp(mode, kNames[M])) { drive<M>(seconds, out, sink, clk, grid); return 0; }
-  CASE(PK_FMA) CASE(PK_ADD) CASE(SQRT) CASE(LDS_W64) CASE(LDS_R64) CASE(LDS_R128) CASE(EXCHANGE) CASE(STORE) CASE(MIX) CASE(MIXSTORE) CASE(STORE_DEF) CASE(STORE4) CASE(STORE4_DEF) CASE(STORE2)
+  CASE(PK_FMA) CASE(PK_ADD) CASE(SQRT) CASE(LDS_W64) CASE(LDS_R64) CASE(LDS_R128) CASE(EXCHANGE) CASE(STORE) CASE(MIX) CASE(MIXSTORE) CASE(STORE_DEF) CASE(STORE4) CASE(STORE4_DEF) CASE(STORE2) CASE(DPP_ADD) CASE(ADD)
   printf("unknown mode %s\n", mode);
   return 1;
 }
