@@ -118,7 +118,7 @@ def cpu_baseline(fs, n_samples, freqs, budget_s=25.0):
                       "(%.2f s each)" % (n_samples, len(freqs), cores, reps, best)}
 
 
-def spot_check(obuf, base, fs, freqs, C, N, distinct):
+def spot_check(obuf, base, fs, freqs, C, N, distinct, output="amplitude"):
     """Looks at what the timed steps wrote: rows (channel, scale) of the device result
     against the oracle (transforms.py:187-204), and the tiled channels c and c + distinct
     (same input) bit for bit.  Returns (ok, worst relative error)."""
@@ -126,17 +126,25 @@ def spot_check(obuf, base, fs, freqs, C, N, distinct):
     S = len(freqs)
     chans = sorted({0, min(7, C - 1), C - 1})
     scales = sorted({0, (57 * S) // 100, S - 1})
+    dtype, width = (np.complex64, 8) if output == "complex" else (np.float32, 4)
     worst, same = 0.0, True
     for c in chans:
-        ref = orc.cwt_amplitude(base[c % distinct].astype(np.float64), fs, freqs[scales])
+        xc = base[c % distinct].astype(np.float64)
+        if output == "complex":
+            ref = orc.cwt_complex(xc, fs, freqs[scales])
+        else:
+            ref = orc.cwt_amplitude(xc, fs, freqs[scales])
+            if output == "power":
+                ref = ref ** 2
         for i, s in enumerate(scales):
-            row = obuf.download((N,), np.float32, offset_bytes=4 * (c * S + s) * N)
+            row = obuf.download((N,), dtype, offset_bytes=width * (c * S + s) * N)
             worst = max(worst, float(np.abs(row - ref[i]).max() / np.abs(ref[i]).max()))
             twin = c + distinct if c + distinct < C else c - distinct
             if 0 <= twin < C and twin != c:
-                other = obuf.download((N,), np.float32, offset_bytes=4 * (twin * S + s) * N)
+                other = obuf.download((N,), dtype, offset_bytes=width * (twin * S + s) * N)
                 same = same and np.array_equal(row, other)
-    return bool(worst <= 1e-5 and same), worst
+    gate = 2e-5 if output == "power" else 1e-5
+    return bool(worst <= gate and same), worst
 
 
 # ----------------------------------------------------------------------------
@@ -297,7 +305,7 @@ def run_rank(args):
         if comm.rccl_error:
             line["config"]["rccl_error"] = comm.rccl_error[:200]
         if not cfg5 and not args.no_check:
-            ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct)
+            ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=args.output)
             line["checked"] = ok
             line["check"] = {"rows": "channels {0,7,C-1} x scales {0,57%%,S-1} vs the oracle, "
                                      "tiled channels c / c+%d bit-equal" % distinct,
@@ -307,7 +315,8 @@ def run_rank(args):
             # complex coefficients stored (8 B per coefficient: SURVEY.md 8d's second target).
             obuf.free()
             plan.close()
-            line["other_modes"] = {"complex": other_mode("complex", N, C, fs, freqs, S, xbuf, dev, lib, check)}
+            line["other_modes"] = {"complex": other_mode("complex", N, C, fs, freqs, S, xbuf, dev, lib, check,
+                                                         check_against=None if args.no_check else (base, distinct))}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fs, 1000000, freqs)
         emit(line)
@@ -315,7 +324,7 @@ def run_rank(args):
     return 0
 
 
-def other_mode(output, N, C, fs, freqs, S, xbuf, dev, lib, check, steps=5):
+def other_mode(output, N, C, fs, freqs, S, xbuf, dev, lib, check, steps=5, check_against=None):
     """ms per step and whole-job fraction of the HBM peak for another output mode of the same
     workload (device-resident, plan prebuilt, `steps` timed executions after two warm-ups)."""
     from ghost_amd.engine import CwtPlan, DeviceBuffer
@@ -340,6 +349,10 @@ def other_mode(output, N, C, fs, freqs, S, xbuf, dev, lib, check, steps=5):
            "whole_job_frac_of_hbm_peak": round(alg / el / 1e9 / HBM_PEAK_GBS, 4),
            "kernel_ms": round(synth / steps, 4),
            "kernel_frac_of_hbm_peak": round(alg / (synth / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if check_against is not None:
+        base, distinct = check_against
+        ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=output)
+        res["checked"], res["worst_rel_err"] = ok, float("%.3g" % worst)
     obuf.free()
     plan.close()
     return res
