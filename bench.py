@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E data sheet (guides/MI355X_MICROARCH.md)
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # guides/MI355X_MICROARCH.md: Peak FP32 (vector), spec
 
 # The result line goes to the stdout this process was started with; fd 1 itself is pointed
 # at stderr for the whole run, so that nothing a library prints (RCCL's banner) can land
@@ -299,6 +300,18 @@ def run_rank(args):
             "stages_ms": {k: round(float(v) / args.steps, 4) for k, v in stats.items() if k.endswith("_ms")},
             "whole_job_frac_of_hbm_peak": round(alg_step * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
         }
+        if not cfg5:
+            # SURVEY.md 8d's secondary ceiling: fp32 vector flops, counted NOMINALLY -- one real
+            # forward FFT of P points per channel, one P-point inverse FFT + multiply + magnitude
+            # per (channel, scale) -- which is what the reference's method would execute; the
+            # engine's decimated synthesis executes about 0.4 of that.
+            P = float(info["fft_length"])
+            nominal = C * (2.5 * P * np.log2(P) + S * (5.0 * P * np.log2(P) + 3.0 * P + 4.0 * N))
+            line["roofline"]["fp32_vector"] = {
+                "nominal_flops_per_step": float("%.4g" % nominal),
+                "nominal_tflops": round(nominal * args.steps / elapsed / 1e12, 1),
+                "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
+                "nominal_frac": round(nominal * args.steps / elapsed / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)}
         if ceilings:
             line["roofline"]["frac_of_store_pattern_ceiling"] = round(
                 achieved / ceilings["store_pattern_ceiling"], 4)
