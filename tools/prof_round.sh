@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/$R
 python bench.py --steps 10 --warmup 2 > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err
 cat gpurun_out/$R/bench.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ceilings --no-check --no-other-modes > gpurun_out/$R/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -- python3 bench.py --steps 30 --warmup 2 --no-cpu-baseline --no-ceilings --no-check --no-other-modes > gpurun_out/$R/stats.log 2>&1
 echo stats done
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ceilings --no-check --no-other-modes > gpurun_out/$R/fetch.log 2>&1
 echo fetch done
