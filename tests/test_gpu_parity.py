@@ -560,6 +560,20 @@ def test_other_morse_parameters_public_api(golden, gamma, beta):
     np.testing.assert_allclose(cwt.amplitude.max(axis=1), g["d1_rowmax_" + tag], rtol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+def test_public_api_grid(golden, tag):
+    """G13, driver D1: the public call over sampling rates 200 Hz .. 30 kHz, odd lengths, 4 .. 48
+    voices per octave, limits the reference clamps (transforms.py:412-434) and timestamp gaps
+    that cut the recording into epochs (preprocessing.py:78-114)."""
+    g = golden("g13_api_grid.npz")
+    cwt = _cwt(g["x_" + tag], float(g["fs_" + tag]), timestamps=g["t_" + tag],
+               freq_limits=g["limits_" + tag].tolist(), voices_per_octave=int(g["voices_" + tag]))
+    np.testing.assert_allclose(cwt.frequencies, g["frequencies_" + tag], rtol=1e-13)
+    assert cwt.amplitude.dtype == np.float64 and cwt.amplitude.shape == (g["frequencies_" + tag].size, g["x_" + tag].size)
+    assert rel_err(cwt.amplitude[:, g["cols_" + tag]], g["amplitude_cols_" + tag]).max() < TOL
+    np.testing.assert_allclose(cwt.amplitude.max(axis=1), g["rowmax_" + tag], rtol=2e-5)
+
+
 def test_fullband_path_long_kernels_epochs_and_blocks():
     """The full-band path on its own terms: kernels of thousands of taps (small beta, low
     frequencies), two epochs, several channels, forced time blocks, execute_block."""

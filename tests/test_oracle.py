@@ -93,6 +93,21 @@ def test_two_epochs(golden):
     assert rel_err(c[:, g["cols"]], g["complex_cols"]).max() < 1e-12
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+def test_public_api_grid(golden, tag):
+    """G13 (driver D1 over sampling rates, odd lengths, 4..48 voices per octave, clamped
+    limits, timestamp gaps): the oracle's epochs, frequency grid and amplitude."""
+    g = golden("g13_api_grid.npz")
+    fs, x, t = float(g["fs_" + tag]), g["x_" + tag].astype(np.float64), g["t_" + tag]
+    eb = orc.contiguous_segments(t, fs)
+    f = orc.frequency_grid(fs, np.diff(eb, axis=1).min(), freq_limits=g["limits_" + tag].tolist(),
+                           voices_per_octave=int(g["voices_" + tag]))
+    np.testing.assert_allclose(f, g["frequencies_" + tag], rtol=1e-13)
+    a = orc.cwt_amplitude(x, fs, f, eb)
+    assert rel_err(a[:, g["cols_" + tag]], g["amplitude_cols_" + tag]).max() < 1e-11
+    np.testing.assert_allclose(a.max(axis=1), g["rowmax_" + tag], rtol=1e-10)
+
+
 def test_near_nyquist(golden):
     g = golden("g6_near_nyquist.npz")
     c = orc.cwt_complex(g["x"].astype(np.float64), float(g["fs"]), g["frequencies"])
