@@ -1,7 +1,8 @@
 """Randomised soak of the whole path against the oracle: many layouts (channels, lengths,
 epochs with gaps, sampling rates, frequency ranges down to large decimations, forced time
 blocks, output modes, block requests).  Prints the worst relative error per case; exits
-non-zero on the first case over the 1e-5 gate.  SOAK_N cases (default 60), SOAK_SEED."""
+non-zero on the first case over the 1e-5 gate.  SOAK_N cases (default 60), SOAK_SEED;
+SOAK_BIG=1 adds recordings of up to 2.5 M samples (FFT lengths up to 2^22)."""
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np
 from ghost_amd.engine import CwtPlan
@@ -15,7 +16,10 @@ t_start = time.time()
 for case in range(n_cases):
     fs = float(rng.choice([200.0, 1000.0, 1250.0, 30000.0]))
     n_ch = int(rng.integers(1, 4))
-    n = int(rng.choice([17, 500, 4096, 4097, 10000, 33333, 70000, 150000]))
+    sizes = [17, 500, 4096, 4097, 10000, 33333, 70000, 150000]
+    if os.environ.get("SOAK_BIG"):             # long recordings too: FFT lengths up to 2^22, time blocks
+        sizes += [400000, 1100000, 2500000]
+    n = int(rng.choice(sizes))
     x = (rng.standard_normal((n_ch, n)) * rng.uniform(0.1, 50) + rng.uniform(-100, 100, (n_ch, 1))).astype(np.float32)
     k = int(rng.integers(0, 7))
     cuts = np.sort(rng.choice(np.arange(1, n), size=min(n - 1, k), replace=False)) if n > 8 else np.array([], int)
@@ -36,7 +40,7 @@ for case in range(n_cases):
         beta = float(np.round(np.exp(rng.uniform(np.log(1.5), np.log(80.0))), 1))
         kw.update(gamma=gamma, beta=beta)
     if rng.random() < 0.35:
-        kw["max_fft_log2"] = int(rng.choice([12, 13, 14, 16]))
+        kw["max_fft_log2"] = int(rng.choice([12, 13, 14, 16] + ([20, 21, 22] if os.environ.get("SOAK_BIG") else [])))
     try:
         p = CwtPlan(n, n_ch, fs, f, **kw)
     except Exception as e:
