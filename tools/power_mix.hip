@@ -73,25 +73,17 @@ __global__ void __launch_bounds__(512) k_run(float* out, float* sink, int iters,
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i].x));
     }
-    if (MODE == LDS_W64) {
+    if (MODE == LDS_W64 || MODE == LDS_R64 || MODE == LDS_R128) {   // asm volatile: the compiler must not merge or drop them
+      const unsigned wa = (unsigned)(reinterpret_cast<size_t>(wr) & 0xffff), ra = (unsigned)(reinterpret_cast<size_t>(rd) & 0xffff);
 #pragma unroll
       for (int rep = 0; rep < 4; ++rep) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) wr[j * 32] = a[j];
-      }
-    }
-    if (MODE == LDS_R64) {
-#pragma unroll
-      for (int rep = 0; rep < 4; ++rep) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const v2f q = rd[j * kPlane]; a[j] += q; }
-      }
-    }
-    if (MODE == LDS_R128) {
-#pragma unroll
-      for (int rep = 0; rep < 4; ++rep) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const v4f q = rd4[j * 512]; a[2 * j].x += q.x; a[2 * j + 1].y += q.w; }
+        for (int j = 0; j < 16; ++j) {
+          if (MODE == LDS_W64) asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(wa), "v"(a[j]), "n"(j * 256) : "memory");
+          else if (MODE == LDS_R64) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[j]) : "v"(ra), "n"(j * 4104));
+          else { v4f q; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q) : "v"((unsigned)(tid * 16)), "n"((j & 7) * 8192)); a[j].x = q.x; a[j].y = q.w; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
     if (MODE == EXCHANGE || MODE == MIX || MODE == MIXSTORE) {
