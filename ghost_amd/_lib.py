@@ -41,13 +41,14 @@ class PlanInfo(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("n_levels", C.c_int32), ("n_spectral", C.c_int32),
                 ("n_direct", C.c_int32), ("block", C.c_int32), ("max_decimation", C.c_int32),
                 ("fft_length", C.c_int64), ("workspace_bytes", C.c_int64),
-                ("out_bytes", C.c_int64), ("n_fullband", C.c_int32), ("reserved", C.c_int32)]
+                ("out_bytes", C.c_int64), ("n_fullband", C.c_int32), ("n_interp", C.c_int32)]
 
 
 class Timings(C.Structure):
     _fields_ = [("mean_ms", C.c_float), ("fwd_fft_ms", C.c_float), ("decimate_ms", C.c_float),
                 ("block_fft_ms", C.c_float), ("synth_ms", C.c_float), ("direct_ms", C.c_float),
-                ("total_ms", C.c_float), ("synth_launches", C.c_int32), ("fullband_ms", C.c_float)]
+                ("total_ms", C.c_float), ("synth_launches", C.c_int32), ("fullband_ms", C.c_float),
+                ("interp_ms", C.c_float)]
 
 
 def _load():
@@ -96,6 +97,10 @@ def _load():
         "gcwt_debug_batch_of": (C.c_int, [vp, C.c_int, i32p, i32p]),
         "gcwt_debug_level_info": (C.c_int, [vp, C.c_int, C.c_int, i32p, i32p, i32p, i32p, i64p]),
         "gcwt_debug_exact_gain": (C.c_int, [vp, C.c_int, i64p, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
+        "gcwt_debug_measure_build": (C.c_int, []),
+        "gcwt_debug_interp_level": (C.c_int, [vp, C.c_int, i32p, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                            f32p, C.c_int64]),
+        "gcwt_debug_scale_demod": (C.c_int, [vp, i32p]),
         "gcwt_debug_clock": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "gcwt_debug_bandwidth": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_double)]),
         "gcwt_debug_fetch": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int64]),

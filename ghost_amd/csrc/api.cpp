@@ -62,16 +62,12 @@ struct EpochDev {
   Synth7Item* items7 = nullptr;      // production kernel
   Synth7Level* levels7 = nullptr;
   int n_items7 = 0;
+  SynthiItem* items_i = nullptr;     // interpolating kernel (synthi.hip)
+  SynthiLevel* levels_i = nullptr;
+  int n_items_i = 0;
 };
 
-// First-pass inputs of the synthesis whose bins lie above the scale's band are skipped
-// (kernels.hip: k_scale_windows).  GHOSTCWT_PRUNE_INPUTS=0 computes them all (A/B runs).
-inline bool prune_inputs() {
-  const char* e = getenv("GHOSTCWT_PRUNE_INPUTS");
-  return !e || atoi(e) != 0;
-}
-
-enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_FULLBAND, ST_COUNT };
+enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_FULLBAND, ST_INTERP, ST_COUNT };
 
 }  // namespace
 
@@ -81,13 +77,22 @@ struct gcwt_plan {
   bool profiling = false;
   int synth_cols = 32;        // columns per workgroup of k_synth7 (GHOSTCWT_SYNTH_COLS=16|32)
   bool fuse_blocks = true;    // k_synth7 makes its own block spectra from x_R (GHOSTCWT_FUSE_BLOCKS=0: separate pass)
-  int synth_kernel = 7;       // 7: k_synth7; 8: producer/consumer waves (synth8.hip, measured slower:
-                              // DESIGN.md 5) -- GHOSTCWT_SYNTH_KERNEL
+  int synth_kernel = 7;       // 7: k_synth7; 8 (measure build only): producer/consumer waves (synth8.hip,
+                              // measured slower: DESIGN.md 5) -- GHOSTCWT_SYNTH_KERNEL
+  // Every GHOSTCWT_* knob is read ONCE, when the plan is created; an execute never looks at the
+  // environment.
+  bool prune_inputs = true;   // first-pass inputs above a scale's band skipped (kernels.hip: k_scale_windows);
+                              // GHOSTCWT_PRUNE_INPUTS=0 computes them all (A/B runs)
+  bool fast_fft = true;       // GHOSTCWT_SLOW_FFT=1: the generic radix-2 passes (A/B runs, tests)
+  int drop_stores = 0;        // measure build only: GHOSTCWT_SYNTH_DROP_STORES (kernels.h)
+  bool clock_probe = false;   // measure build only: GHOSTCWT_CLOCK_PROBE
   bool use_synth16 = false;   // GHOSTCWT_SYNTH16=1: 16-column kernel for every output mode (A/B tests)
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t aux[2] = {nullptr, nullptr};   // the level passes of a batch run beside each other (run_pipeline)
   bool level_streams = true;  // GHOSTCWT_LEVEL_STREAMS=0: everything on `stream`
+  bool synth_streams = true;  // the interpolating kernel runs beside k_synth7 on aux[0] (its store-bound
+                              // workgroups share the CUs with the arithmetic-bound ones); GHOSTCWT_SYNTH_STREAMS=0: one after the other
   hipStream_t cur = nullptr;  // the stream the stage in hand is launched on (profiling spans follow it)
   // workspace
   float2* d_x = nullptr;      // [C][max_p]   spectrum (k1-major)
@@ -104,9 +109,11 @@ struct gcwt_plan {
   float2* d_tw4096 = nullptr; // exp(-2 pi i j/4096), j < 2048
   float2* d_tw256 = nullptr;  // exp(+2 pi i q/256)
   float2* d_level_tw = nullptr;
-  double* d_sums = nullptr;   // [C]
+  double* d_sums = nullptr;   // [C] sums (+ the partial sums and counters of k_channel_sum)
   int32_t* d_scale_list = nullptr;
   int n_listed = 0;           // entries of d_scale_list (all levels)
+  int32_t* d_scale_aux = nullptr;   // per list entry: demodulation bin | (even kernel length) << 16 (synthi.hip)
+  float* d_interp_coef = nullptr;   // interpolator coefficients of the interpolated levels
   BankScale* d_bank_sc = nullptr;
   DirectScale* d_direct_sc = nullptr;
   std::vector<EpochDev> ep_dev;
@@ -148,11 +155,11 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
   fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
-  fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_bank_sc); fr(p->d_direct_sc);
+  fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
   p->host_out.release();
-  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.levels7); }
+  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.levels7); fr(e.items_i); fr(e.levels_i); }
   p->ep_dev.clear();
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
   p->ev_pool.clear();
@@ -169,6 +176,16 @@ int get_event(gcwt_plan* p, hipEvent_t* e) {
   }
   *e = p->ev_pool[p->ev_used++];
   return GCWT_OK;
+}
+
+// Which synthesis kernel makes a level: the interpolating one when the planner designed it
+// (amplitude / power, R >= 16), else k_synth7 when the block layout allows, else the 16-column
+// fallback.  GHOSTCWT_SYNTH16=1 sends everything to the fallback (A/B tests).
+enum LevelKernel { LK_SYNTH16 = 0, LK_SYNTH7 = 7, LK_INTERP = 9 };
+inline LevelKernel level_kernel(const gcwt_plan* p, const LevelPlan& lp) {
+  if (p->use_synth16) return LK_SYNTH16;
+  if (lp.interp_q > 0) return LK_INTERP;
+  return lp.fast ? LK_SYNTH7 : LK_SYNTH16;
 }
 
 // RAII-less span helper: begin/end record events on the stage's stream when profiling
@@ -257,7 +274,15 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   if (const char* e = getenv("GHOSTCWT_SYNTH16")) p->use_synth16 = e[0] == '1';
   if (const char* e = getenv("GHOSTCWT_SYNTH_COLS")) p->synth_cols = atoi(e) == 16 ? 16 : 32;
   if (const char* e = getenv("GHOSTCWT_FUSE_BLOCKS")) p->fuse_blocks = e[0] != '0';
+  if (const char* e = getenv("GHOSTCWT_PRUNE_INPUTS")) p->prune_inputs = atoi(e) != 0;
+  if (getenv("GHOSTCWT_SLOW_FFT")) p->fast_fft = false;
+  if (const char* e = getenv("GHOSTCWT_LEVEL_STREAMS")) p->level_streams = atoi(e) != 0;
+  if (const char* e = getenv("GHOSTCWT_SYNTH_STREAMS")) p->synth_streams = atoi(e) != 0;
+#ifdef GCWT_MEASURE
   if (const char* e = getenv("GHOSTCWT_SYNTH_KERNEL")) p->synth_kernel = atoi(e) == 8 ? 8 : 7;
+  if (const char* e = getenv("GHOSTCWT_SYNTH_DROP_STORES")) p->drop_stores = std::max(1, atoi(e));   // tools/stage_times.py ablations
+  p->clock_probe = getenv("GHOSTCWT_CLOCK_PROBE") != nullptr;
+#endif
   for (const auto& s : p->hp.scales)
     if (s.method == GCWT_SCALE_DIRECT) p->max_direct_len = std::max(p->max_direct_len, s.length);
   *out = p;
@@ -281,7 +306,9 @@ int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info) {
   info->n_direct = hp.n_direct;
   info->n_spectral = (int32_t)hp.scales.size() - hp.n_direct - hp.n_fullband;
   info->n_fullband = hp.n_fullband;
-  info->reserved = 0;
+  info->n_interp = 0;
+  for (const auto& l : hp.levels)
+    if (level_kernel(plan, l) == LK_INTERP) info->n_interp += (int32_t)l.scales.size();
   info->block = hp.block;
   int r = 1;
   for (const auto& l : hp.levels) r = std::max(r, l.decimation);
@@ -345,7 +372,6 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   int rc;
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   for (auto& q : p->aux) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-  if (const char* e = getenv("GHOSTCWT_LEVEL_STREAMS")) p->level_streams = atoi(e) != 0;
   auto bail = [&](int code) { free_dev(p); return code; };
 
   const bool any_fft = hp.n_direct < S;   // spectral or full-band scales: they share X
@@ -361,7 +387,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     }
   }
   if ((rc = upload_vec(&p->d_amps, hp.amps, p->stream))) return bail(rc);
-  if (getenv("GHOSTCWT_CLOCK_PROBE")) {
+  if (p->clock_probe) {
     if ((rc = dev_alloc(&p->d_probe, 2))) return bail(rc);
     hipError_t he0 = hipMemsetAsync(p->d_probe, 0, 16, p->stream);
     if (he0 != hipSuccess) return bail(hip_err(he0, "probe reset"));
@@ -373,7 +399,11 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     hipError_t hz = hipMemsetAsync(p->d_psi, 0, sizeof(float2) * (size_t)std::max<int64_t>(1, hp.direct_total), p->stream);
     if (hz != hipSuccess) return bail(hip_err(hz, "psi reset"));
   }
-  if ((rc = dev_alloc(&p->d_sums, (size_t)C))) return bail(rc);
+  if ((rc = dev_alloc(&p->d_sums, channel_sum_doubles((size_t)C)))) return bail(rc);
+  {   // results and partial sums of k_channel_sum
+    hipError_t hz = hipMemsetAsync(p->d_sums, 0, sizeof(double) * channel_sum_doubles((size_t)C), p->stream);
+    if (hz != hipSuccess) return bail(hip_err(hz, "sums reset"));
+  }
 
   // tables, computed in double on the host
   std::vector<float2> tw4096(kRowLen / 2), tw256(256), ltw((size_t)hp.level_twiddle_total);
@@ -408,7 +438,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   if ((rc = upload_vec(&p->d_bank_sc, bsc, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_direct_sc, dsc, p->stream))) return bail(rc);
 
-  std::vector<int32_t> scale_list;
+  std::vector<int32_t> scale_list, scale_aux;
   std::vector<int> scale_off(hp.levels.size());
   std::vector<int> n_plain(hp.levels.size());
   std::vector<float2> half_tw(hp.levels.size() * 256);
@@ -425,8 +455,12 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       half_tw[l * 256 + k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
   }
+  for (int sidx : scale_list)
+    scale_aux.push_back(hp.scales[sidx].demod_bin | (hp.scales[sidx].half_delay != 0.0 ? 1 << 16 : 0));
   if ((rc = upload_vec(&p->d_half_tw, half_tw, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_scale_list, scale_list, p->stream))) return bail(rc);
+  if ((rc = upload_vec(&p->d_scale_aux, scale_aux, p->stream))) return bail(rc);
+  if ((rc = upload_vec(&p->d_interp_coef, hp.interp_coef, p->stream))) return bail(rc);
   p->n_listed = (int)scale_list.size();
   p->ep_dev.resize(hp.epochs.size());
   for (size_t e = 0; e < hp.epochs.size(); ++e) {
@@ -436,7 +470,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     // most 256 scales), else to the 16-column kernel; GHOSTCWT_SYNTH16=1 sends everything there
     std::vector<SynthItemDev> items;
     for (size_t i = 0; i < ep.items.size(); ++i)
-      if (p->use_synth16 || !hp.levels[ep.items[i].level].fast)
+      if (level_kernel(p, hp.levels[ep.items[i].level]) == LK_SYNTH16)
         items.push_back({ep.items[i].level, ep.items[i].scale, ep.items[i].blk0, ep.items[i].nblk});
     p->ep_dev[e].n_items = (int)items.size();
     std::vector<SynthLevelDev> lv(hp.levels.size());
@@ -456,18 +490,38 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
                 lp.twiddle_offset, ep.lv[l].xr_offset, ep.lv[l].m - 1};
       const int bpb = std::max(1, p->synth_cols / lp.decimation);
       const int n_rtiles = std::max(1, lp.decimation / p->synth_cols);
-      if (p->use_synth16 || !lp.fast) continue;
+      if (level_kernel(p, lp) != LK_SYNTH7) continue;
       for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
         for (int rt = 0; rt < n_rtiles; ++rt) items7.push_back({(int32_t)l, b0, rt, 0});
     }
     p->ep_dev[e].n_items7 = (int)items7.size();
     if ((rc = upload_vec(&p->ep_dev[e].items7, items7, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels7, lv7, p->stream))) return bail(rc);
+    // interpolated levels: one workgroup per block, the longest-running (largest R) first
+    std::vector<SynthiItem> items_i;
+    std::vector<SynthiLevel> lvi(hp.levels.size());
+    std::vector<int> order;
+    for (size_t l = 0; l < hp.levels.size(); ++l)
+      if (level_kernel(p, hp.levels[l]) == LK_INTERP) order.push_back((int)l);
+    std::sort(order.begin(), order.end(),
+              [&](int x, int y) { return hp.levels[x].decimation > hp.levels[y].decimation; });
+    for (int l : order) {
+      const LevelPlan& lp = hp.levels[l];
+      int lgq = 0;
+      while ((1 << lgq) < lp.interp_q) ++lgq;
+      lvi[l] = {lp.decimation, lp.interp_q, lgq, lp.interp_factor, lp.hop, lp.halo, ep.lv[l].nblk,
+                (int32_t)lp.scales.size(), scale_off[l], ep.lv[l].blk_lo, 0, 0, lp.twiddle_offset,
+                ep.lv[l].xr_offset, ep.lv[l].m - 1, lp.coef_offset};
+      for (int b0 = 0; b0 < ep.lv[l].nblk; ++b0) items_i.push_back({(int32_t)l, b0});
+    }
+    p->ep_dev[e].n_items_i = (int)items_i.size();
+    if ((rc = upload_vec(&p->ep_dev[e].items_i, items_i, p->stream))) return bail(rc);
+    if ((rc = upload_vec(&p->ep_dev[e].levels_i, lvi, p->stream))) return bail(rc);
   }
 
   hipError_t he = launch_build_bank(p->d_bank, p->d_gain, p->d_bank_sc, p->d_amps, S, B, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_bank"));
-  he = launch_scale_windows(p->d_gain, p->d_scale_list, prune_inputs() ? p->n_listed : 0,
+  he = launch_scale_windows(p->d_gain, p->d_scale_list, p->prune_inputs ? p->n_listed : 0,
                             (float)hp.band_tol, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "scale_windows"));
   he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, p->d_amps, p->stream);
@@ -528,7 +582,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
   }
 
   const bool any_fft = hp.n_direct < S;
-  const bool fast_fft = !getenv("GHOSTCWT_SLOW_FFT");
+  const bool fast_fft = p->fast_fft;
   for (size_t e0 = 0; any_fft && e0 < hp.epochs.size();) {
     // one batch: segments e0 .. e0 + count - 1 share the FFT length and the level grids;
     // those with something to write in [r0, r1) become extra sets of "channels"
@@ -619,7 +673,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, slots, ls));
       }
       const float scale = (float)(1.0 / ((double)hp.block * (double)P));
-      if (!fused_blocks || !lp.fast)     // levels of the 16-column kernel read XB
+      const LevelKernel lk = level_kernel(p, lp);
+      if (lk == LK_SYNTH16 || (lk == LK_SYNTH7 && !fused_blocks))     // the kernels that read XB
         RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.blk_lo,
                                        el.nblk, hp.max_xr, hp.max_xb, p->d_tw256, scale, slots, ls));
     }
@@ -636,6 +691,41 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       }
     }
     const EpochDev& dev = p->ep_dev[ep.batch_first];
+    // The interpolating kernel is launched first, on a stream of its own, and k_synth7 beside it:
+    // the two share the CUs (store-bound workgroups next to arithmetic-bound ones) and each
+    // fills the other's tail.  Both only read what the level passes left and write disjoint rows.
+    hipStream_t si = st;
+    if (dev.n_items_i > 0) {
+      const bool beside = p->synth_streams && (dev.n_items7 > 0 || dev.n_items > 0);
+      if (beside) {
+        hipEvent_t levels_done;
+        int rc_ = get_event(p, &levels_done);
+        if (rc_) return rc_;
+        he = hipEventRecord(levels_done, st);
+        if (he == hipSuccess) he = hipStreamWaitEvent(p->aux[0], levels_done, 0);
+        if (he != hipSuccess) return hip_err(he, "synthesis fork");
+        si = p->aux[0];
+      }
+      SynthiArgs ai{};
+      ai.tw256 = p->d_tw256;
+      ai.level_tw = p->d_level_tw;
+      ai.items = dev.items_i;
+      ai.levels = dev.levels_i;
+      ai.scale_list = p->d_scale_list;
+      ai.scale_aux = p->d_scale_aux;
+      ai.gain = p->d_gain;
+      ai.coef = p->d_interp_coef;
+      ai.out = dout;
+      ai.row_len = row_len;
+      ai.xr = p->d_xr;
+      ai.xr_cstride = hp.max_xr;
+      ai.xb_scale = (float)(1.0 / ((double)hp.block * (double)P));
+      ai.n_scales = S;
+      ai.seg = sout;
+      p->cur = si;
+      RUN(ST_INTERP, launch_synthi(mode, ai, dev.n_items_i, slots, si));
+      p->cur = nullptr;
+    }
     if (dev.n_items > 0) {
       SynthArgs a{};
       a.xb = p->d_xb;
@@ -666,7 +756,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       a7.xb_cstride = hp.max_xb;
       a7.row_len = row_len;
       a7.n_scales = S;
-      if (const char* e = getenv("GHOSTCWT_SYNTH_DROP_STORES")) a7.drop_stores = std::max(1, atoi(e));   // tools/stage_times.py ablations
+      a7.drop_stores = p->drop_stores;
       a7.seg = sout;
       a7.clock_probe = p->d_probe;
       if (fused_blocks) {
@@ -674,10 +764,20 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         a7.xr_cstride = hp.max_xr;
         a7.xb_scale = (float)(1.0 / ((double)hp.block * (double)P));
       }
+#ifdef GCWT_MEASURE
       if (p->synth_kernel == 8)
         RUN(ST_SYNTH, launch_synth8(mode, p->synth_cols, a7, dev.n_items7, slots, st));
       else
+#endif
         RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, dev.n_items7, slots, st));
+    }
+    if (si != st) {                        // join: the batch is done when both kernels are
+      hipEvent_t interp_done;
+      int rc_ = get_event(p, &interp_done);
+      if (rc_) return rc_;
+      he = hipEventRecord(interp_done, si);
+      if (he == hipSuccess) he = hipStreamWaitEvent(st, interp_done, 0);
+      if (he != hipSuccess) return hip_err(he, "synthesis join");
     }
     if (p->profiling && !hp.levels.empty()) p->last.synth_launches++;
     // full-band scales: W = IFFT_P(X H_s), one scale at a time for every slot of the batch
@@ -771,7 +871,11 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   if (p->profiling) { p->last = gcwt_timings{}; }
   const bool reuse = (flags & GCWT_REUSE_MEANS) && p->have_means;
   rc = run_pipeline(p, dx, dout, r0, r1, row_len, reuse);
-  if (rc) { (void)hipStreamSynchronize(p->stream); return rc; }
+  if (rc) {   // a failure between a fork and its join: nothing may still be running on any of the plan's streams
+    (void)hipStreamSynchronize(p->stream);
+    for (auto& q : p->aux) (void)hipStreamSynchronize(q);
+    return rc;
+  }
   p->have_means = true;
   if (!(flags & GCWT_OUT_ON_DEVICE)) {
     // complex rows are float pairs: the same routine moves (and widens) them
@@ -796,6 +900,7 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
         HIP_TRY(hipEventElapsedTime(&a, t0, s.a));
         HIP_TRY(hipEventElapsedTime(&b, t0, s.b));
         iv[s.stage].push_back({a, b});
+        if (s.stage == ST_INTERP) iv[ST_SYNTH].push_back({a, b});   // synth_ms: every synthesis kernel
         last_end = std::max(last_end, b);
       }
       for (int st = 0; st < ST_COUNT; ++st) {
@@ -814,6 +919,7 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
     p->last.decimate_ms = acc[ST_DECIM];
     p->last.block_fft_ms = acc[ST_BLOCK];
     p->last.synth_ms = acc[ST_SYNTH];
+    p->last.interp_ms = acc[ST_INTERP];
     p->last.direct_ms = acc[ST_DIRECT];
     p->last.fullband_ms = acc[ST_FULLBAND];
     p->have_timings = true;
@@ -896,6 +1002,8 @@ int gcwt_execute_block(gcwt_plan* p, const void* x, void* out, int64_t start, in
 
 
 // ---- debug hooks (include/ghostcwt_debug.h) --------------------------------
+int gcwt_debug_measure_build(void) { return kMeasureBuild ? 1 : 0; }
+
 int gcwt_debug_level_count(const gcwt_plan* p) { return p ? (int)p->hp.levels.size() : -1; }
 
 int gcwt_debug_level_info(const gcwt_plan* p, int epoch, int level, int32_t* decimation,
@@ -911,6 +1019,30 @@ int gcwt_debug_level_info(const gcwt_plan* p, int epoch, int level, int32_t* dec
   if (hop) *hop = lp.hop;
   if (nblk) *nblk = el.nblk;
   if (m) *m = el.m;
+  return GCWT_OK;
+}
+
+int gcwt_debug_interp_level(const gcwt_plan* p, int level, int32_t* q, int32_t* factor, double* alpha,
+                            double* err_bound, float* coef, int64_t max_floats) {
+  if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  if (level < 0 || level >= (int)p->hp.levels.size()) return set_err(GCWT_ERR_INVALID, "level out of range");
+  const LevelPlan& lp = p->hp.levels[level];
+  const bool on = level_kernel(p, lp) == LK_INTERP;
+  if (q) *q = on ? lp.interp_q : 0;
+  if (factor) *factor = on ? lp.interp_factor : 0;
+  if (alpha) *alpha = lp.interp_alpha;
+  if (err_bound) *err_bound = lp.interp_err;
+  if (coef && on) {
+    const int64_t n = (int64_t)2 * lp.interp_factor * 8;
+    if (n > max_floats) return set_err(GCWT_ERR_INVALID, "destination too small");
+    memcpy(coef, p->hp.interp_coef.data() + lp.coef_offset, sizeof(float) * (size_t)n);
+  }
+  return GCWT_OK;
+}
+
+int gcwt_debug_scale_demod(const gcwt_plan* p, int32_t* demod) {
+  if (!p || !demod) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  for (size_t i = 0; i < p->hp.scales.size(); ++i) demod[i] = p->hp.scales[i].demod_bin;
   return GCWT_OK;
 }
 
@@ -936,7 +1068,9 @@ int gcwt_debug_exact_gain(const gcwt_plan* p, int scale, const int64_t* a, int64
 
 int gcwt_debug_clock(gcwt_plan* p, double* ghz, double* workgroup_seconds) {
   if (!p || !ghz) return set_err(GCWT_ERR_INVALID, "NULL argument");
-  if (!p->d_probe) return set_err(GCWT_ERR_INVALID, "plan was not created with GHOSTCWT_CLOCK_PROBE=1");
+  if (!p->d_probe)
+    return set_err(GCWT_ERR_INVALID, kMeasureBuild ? "plan was not created with GHOSTCWT_CLOCK_PROBE=1"
+                                                   : "the clock probe exists only in libghostcwt_measure.so (make measure)");
   unsigned long long v[2] = {0, 0};
   HIP_TRY(hipMemcpy(v, p->d_probe, sizeof(v), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(p->d_probe, 0, sizeof(v)));
@@ -983,7 +1117,7 @@ int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, 
 int gcwt_internal_refresh_bank(gcwt_plan* p) {   // derived tables follow a (broadcast) bank
   hipError_t he = launch_bank_gain(p->d_bank, p->d_gain, p->d_bank_sc, p->hp.prm.n_freqs, p->stream);
   if (he != hipSuccess) return hip_err(he, "bank_gain");
-  he = launch_scale_windows(p->d_gain, p->d_scale_list, prune_inputs() ? p->n_listed : 0,
+  he = launch_scale_windows(p->d_gain, p->d_scale_list, p->prune_inputs ? p->n_listed : 0,
                             (float)p->hp.band_tol, p->stream);
   if (he != hipSuccess) return hip_err(he, "scale_windows");
   return GCWT_OK;

@@ -11,6 +11,15 @@ namespace gcwt {
 
 constexpr int kRowLenDev = 4096;
 
+// Measurement hooks (stores dropped, barriers removed, in-kernel clock probe, the slower
+// k_synth8) exist only in the second build, `make measure` -> libghostcwt_measure.so, which
+// tools/ load through GHOSTCWT_LIB; the product library has none of those paths.
+#ifdef GCWT_MEASURE
+constexpr bool kMeasureBuild = true;
+#else
+constexpr bool kMeasureBuild = false;
+#endif
+
 struct BankScale {
   double omega;
   double half_delay;
@@ -103,20 +112,56 @@ struct Synth7Args {
   int64_t xr_cstride;    //   (k_synth7 only; the block-spectra pass and the XB array are skipped)
   float xb_scale;        //   1 / (256 P)
   int32_t pad0;
-  unsigned long long* clock_probe;   // measurement only (GHOSTCWT_CLOCK_PROBE=1): [0] += shader cycles,
-                                     // [1] += 100 MHz ticks each workgroup lived; NULL in normal runs
+  unsigned long long* clock_probe;   // measure build only (GHOSTCWT_CLOCK_PROBE=1): [0] += shader cycles,
+                                     // [1] += 100 MHz ticks each workgroup lived; NULL otherwise
   int32_t n_scales;
-  int32_t drop_stores;   // measurement only (GHOSTCWT_SYNTH_DROP_STORES=bits; results are WRONG): 1 stores get
+  int32_t drop_stores;   // measure build only (GHOSTCWT_SYNTH_DROP_STORES=bits; results are WRONG): 1 stores get
                          // an empty range (kernel time without HBM writes), 2 no workgroup barriers
   SegOut seg;
 };
 
 hipError_t launch_synth7(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
                          hipStream_t st);
+
+// Interpolating synthesis (synthi.hip): one workgroup = one block of one level, all its scales.
+struct SynthiItem {
+  int32_t level, blk0;
+};
+struct SynthiLevel {
+  int32_t decimation, q, log2q, factor;   // R, phases per (block, scale), I = R / q
+  int32_t hop, halo, nblk, n_scales, scale_offset, blk_base;
+  int32_t pad0, pad1;
+  int64_t tw_offset;    // into level_tw
+  int64_t xr_offset;    // per-channel offset of this level's decimated signal x_R (complex elems)
+  int64_t m_mask;       // M - 1, M = P / R samples of x_R (circular index)
+  int64_t coef_offset;  // into coef: [2][I][T] floats
+};
+struct SynthiArgs {
+  const float2* tw256;
+  const float2* level_tw;
+  const SynthiItem* items;
+  const SynthiLevel* levels;
+  const int32_t* scale_list;   // as Synth7Args: scale index | (16 - j_hi) << 24, grouped by level
+  const int32_t* scale_aux;    // per list entry: demodulation bin | (kernel length is even) << 16
+  const float* gain;           // G_s[k], [S][256]
+  const float* coef;           // interpolator coefficients
+  float* out;
+  int64_t row_len;
+  const float2* xr;
+  int64_t xr_cstride;
+  float xb_scale;              // 1 / (256 P)
+  int32_t n_scales;
+  SegOut seg;
+};
+hipError_t launch_synthi(int mode, const SynthiArgs& a, int n_items, int n_channels, hipStream_t st);
 // same work items and arguments as launch_synth7 (synth8.hip)
 hipError_t launch_synth8(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
                          hipStream_t st);
 
+// sums: channel_sum_doubles(n_channels) doubles -- the results, then the workgroups' partial
+// sums (kernels.hip: k_channel_sum, k_channel_sum_final)
+constexpr int kSumParts = 64;
+constexpr size_t channel_sum_doubles(size_t n_channels) { return n_channels * (kSumParts + 1); }
 hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,
                               hipStream_t st);
 hipError_t launch_build_bank(float2* bank, float* gain, const BankScale* sc, const double* amps,

@@ -131,12 +131,16 @@ __device__ __forceinline__ void fft256_16t_ldstw(cf v[16], const cf* tw_t, float
 }
 
 // ---------------------------------------------------------------------------
-// per-channel sum (fp64 accumulate), partial sums combined with one atomic per
-// workgroup.  grid (parts, C)
+// per-channel sum (fp64 accumulate).  The workgroups of a channel leave their partial sums
+// in a scratch row and a second, tiny launch adds them up in index order, so the result does
+// not depend on the order the workgroups ran in (repeat executes are bit-identical by
+// construction; the launch boundary is the only synchronisation: a device-scope fence inside
+// the kernel costs a write-back of the XCD's L2, 0.4 ms beside 50 GB of fresh results).
+// sums: [C] results, then [C][kSumParts] partials.  grid (parts, C)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_channel_sum(const float* __restrict__ x, int64_t n,
                                                      double* __restrict__ sums) {
-  const int c = blockIdx.y;
+  const int c = blockIdx.y, n_ch = gridDim.y;
   const float* xc = x + (int64_t)c * n;
   // 16-byte loads over the aligned middle of the row, four independent fp64 accumulators
   const int64_t head = std::min<int64_t>(n, (4 - (((uintptr_t)xc >> 2) & 3)) & 3);
@@ -167,7 +171,18 @@ __global__ void __launch_bounds__(256) k_channel_sum(const float* __restrict__ x
   __shared__ double part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&sums[c], part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0)
+    sums[n_ch + (int64_t)c * kSumParts + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// sums[c] = partials[c][0] + partials[c][1] + ...  in index order.  grid (ceil(C / 64)), block 64
+__global__ void __launch_bounds__(64) k_channel_sum_final(double* __restrict__ sums, int n_ch, int parts) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= n_ch) return;
+  const double* const partials = sums + n_ch + (int64_t)c * kSumParts;
+  double total = 0.0;
+  for (int q = 0; q < parts; ++q) total += partials[q];
+  sums[c] = total;
 }
 
 // ---------------------------------------------------------------------------
@@ -1136,11 +1151,11 @@ static int ilog2(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return l; }
 
 hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,
                               hipStream_t st) {
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * n_channels, st);
-  if (e != hipSuccess) return e;
-  int parts = (int)std::min<int64_t>(64, (n + 256 * 32 - 1) / (256 * 32));
+  int parts = (int)std::min<int64_t>(kSumParts, (n + 256 * 32 - 1) / (256 * 32));
   if (parts < 1) parts = 1;
   hipLaunchKernelGGL(k_channel_sum, dim3(parts, n_channels), dim3(256), 0, st, x, n, sums);
+  GCWT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_channel_sum_final, dim3((n_channels + 63) / 64), dim3(64), 0, st, sums, n_channels, parts);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

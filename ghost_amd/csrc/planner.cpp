@@ -1,5 +1,6 @@
 // planner.cpp -- see planner.h
 #include "planner.h"
+#include "interp.h"
 #include "morse_exact.h"
 
 #include <algorithm>
@@ -195,6 +196,88 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
       break;
     }
   }
+}
+
+// Decides whether a level is made by the interpolating synthesis and, if so, designs it: the
+// demodulation bin of every scale (the centre of the bins where its gain exceeds 1e-4 of the
+// peak, a multiple of q), the design band (the widest such half-band of the level), the
+// coefficient tables of both kernel-length parities, and -- from the scales' own gains -- a bound
+// on the error the interpolation adds: max over bins of |G_s[k]| / peak times the interpolator's
+// error at that bin's distance from the demodulation centre.  A level whose bound exceeds
+// interp_tol stays on the FFT-per-sample kernels.
+static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
+  constexpr int T = kInterpTaps;
+  const int B = hp->block, R = lp->decimation;
+  lp->interp_q = 0;
+  if (hp->prm.out_mode == GCWT_OUT_COMPLEX_C64) return;   // the demodulation would have to be undone per sample
+  // Below R = 32 the q = 4 phases through the block transform are a quarter or more of the
+  // FFT-per-sample work and the interpolation does not pay (measured per level:
+  // profiles/r03_synth_study.md); GHOSTCWT_INTERP_MIN_R moves the line (A/B runs).
+  int min_r = 32;
+  if (const char* e = getenv("GHOSTCWT_INTERP_MIN_R")) min_r = std::max(16, atoi(e));
+  if (R < min_r || lp->scales.empty()) return;
+  int q = 4;
+  while (R / q > kInterpMaxFactor) q *= 2;
+  if (q > 32) return;                                      // 32 columns per workgroup: at most 32 phases
+  const int I = R / q;
+  for (int sidx : lp->scales)
+    if (hp->scales[sidx].n_bins > 4096) return;            // 'energy' members with very long kernels: the gain
+                                                           // probes below would take seconds
+  // gains on the level's grid, band edges and demodulation bins
+  std::vector<std::vector<double>> gains(lp->scales.size(), std::vector<double>((size_t)B));
+  double hw_max = 1.0;
+  for (size_t n = 0; n < lp->scales.size(); ++n) {
+    ScalePlan& sp = hp->scales[lp->scales[n]];
+    std::vector<double>& g = gains[n];
+    double pk = 0.0;
+    for (int k = 0; k < B; ++k) {
+      g[(size_t)k] = std::fabs(exact_gain(hp->amps.data() + sp.amp_offset, sp.bin_lo, sp.n_bins, sp.length, k,
+                                          (int64_t)B * R));
+      pk = std::max(pk, g[(size_t)k]);
+    }
+    if (!(pk > 0.0)) return;
+    int klo = B, khi = -1;
+    for (int k = 0; k < B; ++k) {
+      g[(size_t)k] /= pk;
+      if (g[(size_t)k] > 1e-4) { klo = std::min(klo, k); khi = std::max(khi, k); }
+    }
+    int kc = ((klo + khi + q) / (2 * q)) * q;              // nearest multiple of q to the middle
+    kc = std::min(std::max(kc, 0), B - q);
+    sp.demod_bin = kc;
+    hw_max = std::max(hw_max, (double)std::max(khi - kc, kc - klo) + 1.0);
+  }
+  const double alpha = hw_max / (0.5 * B) / (double)q;
+  if (alpha > 0.45) return;
+  std::vector<double> c((size_t)2 * I * T);
+  design_interp(T, I, alpha, 0.0, c.data());
+  design_interp(T, I, alpha, 0.5, c.data() + (size_t)I * T);
+  // interpolator error against the distance d (bins of the level's grid) from the demodulation
+  // centre, worst over a few sub-sample positions of both parities
+  std::vector<double> err((size_t)2 * B, 0.0);             // d = -B .. B-1 at index d + B
+  const int n_probe = std::min(I, 8);
+  for (int par = 0; par < 2; ++par)
+    for (int pr = 0; pr < n_probe; ++pr) {
+      const int rho = (int)(((int64_t)(2 * pr + 1) * I) / (2 * n_probe));
+      const double tau = ((double)rho - 0.5 * par) / (double)I;
+      const double* cr = c.data() + ((size_t)par * I + rho) * T;
+      for (int d = -B; d < B; ++d) {
+        double th = 2.0 * M_PI * (double)d / ((double)B * q);
+        th = std::remainder(th, 2.0 * M_PI);
+        err[(size_t)(d + B)] = std::max(err[(size_t)(d + B)], interp_error_at(T, cr, tau, th));
+      }
+    }
+  double bound = 0.0;
+  for (size_t n = 0; n < lp->scales.size(); ++n) {
+    const int kc = hp->scales[lp->scales[n]].demod_bin;
+    for (int k = 0; k < B; ++k) bound = std::max(bound, gains[n][(size_t)k] * err[(size_t)(k - kc + B)]);
+  }
+  lp->interp_err = bound;
+  lp->interp_alpha = alpha;
+  if (!(bound <= hp->interp_tol)) return;
+  lp->interp_q = q;
+  lp->interp_factor = I;
+  lp->coef_offset = (int64_t)hp->interp_coef.size();
+  for (double v : c) hp->interp_coef.push_back((float)v);
 }
 
 static int64_t next_pow2(int64_t v) {
@@ -448,6 +531,12 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     if (!lp.fast) hp->halo_static = false;
     lp.twiddle_offset = hp->level_twiddle_total;
     hp->level_twiddle_total += (int64_t)kSynthCols * lp.decimation;
+  }
+  // GHOSTCWT_INTERP=0: every level on the FFT-per-sample kernels (A/B runs, tests)
+  {
+    const char* e = getenv("GHOSTCWT_INTERP");
+    if (!e || atoi(e) != 0)
+      for (LevelPlan& lp : hp->levels) plan_interp_level(hp, &lp);
   }
 
   // per-segment block ranges of every level

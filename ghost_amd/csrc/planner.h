@@ -46,6 +46,8 @@ struct ScalePlan {
   double support = 0;              // samples either side of the centre that hold all but
                                    // support_tol of the kernel's energy (L2)
   bool band_ok = false;            // theta_hi <= pi: some decimation R >= 2 is exact to band_tol
+  int demod_bin = 0;               // interpolated levels: bin of the level's 256-point grid the scale's
+                                   // oversampled output is demodulated by (its band centre; a multiple of q)
 };
 
 struct LevelPlan {
@@ -57,6 +59,13 @@ struct LevelPlan {
   int xr_owner = -1;               // first level with this decimation: its x_R is shared (a
                                    // decimation's scales are split by halo into up to two levels)
   int64_t twiddle_offset = 0;      // offset into the level twiddle table (complex elems)
+  // Interpolating synthesis (synthi.hip, interp.h; amplitude and power only): the level's scales
+  // are made at q x the level's rate and brought to the full rate by a T-tap polyphase FIR.
+  int interp_q = 0;                // phases of the 256-point inverse FFT per (block, scale); 0: not interpolated
+  int interp_factor = 0;           // I = R / q
+  int64_t coef_offset = 0;         // into HostPlan::interp_coef: [2][I][T] floats (odd / even kernel lengths)
+  double interp_alpha = 0;         // design band of the interpolator, fraction of the oversampled Nyquist
+  double interp_err = 0;           // bound on what the interpolation adds, relative to a scale's peak gain
 };
 
 struct EpochLevel {
@@ -112,6 +121,8 @@ struct HostPlan {
   int64_t direct_total = 0;        // complex elements of all direct kernels
   int64_t level_twiddle_total = 0;
   int64_t max_p = 0, max_xr = 0, max_xb = 0;
+  std::vector<float> interp_coef;  // interpolator coefficients of every interpolated level
+  double interp_tol = 1.5e-7;      // largest interp_err a level may have and still be interpolated
   int max_fft_log2 = 22;
   int max_batch = 1;               // largest batch_count in the plan: workspace slots per channel
   size_t out_elem_bytes = 4;

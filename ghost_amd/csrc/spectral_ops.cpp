@@ -54,7 +54,7 @@ struct ChirpEngine {
     CE(hipMalloc((void**)&bspec, sizeof(float2) * P));
     CE(hipMalloc((void**)&out, sizeof(float2) * out_count));
     CE(hipMalloc((void**)&in, in_bytes));
-    CE(hipMalloc((void**)&sum, sizeof(double)));
+    CE(hipMalloc((void**)&sum, sizeof(double) * channel_sum_doubles(1)));
     std::vector<float2> t4(kRowLen / 2), t2(256);
     for (int j = 0; j < kRowLen / 2; ++j) {
       const double x = -2.0 * M_PI * j / kRowLen;
@@ -68,7 +68,7 @@ struct ChirpEngine {
     CE(hipMalloc((void**)&tw256, sizeof(float2) * 256));
     CE(hipMemcpyAsync(tw4096, t4.data(), sizeof(float2) * t4.size(), hipMemcpyHostToDevice, st));
     CE(hipMemcpyAsync(tw256, t2.data(), sizeof(float2) * 256, hipMemcpyHostToDevice, st));
-    CE(hipMemsetAsync(sum, 0, sizeof(double), st));
+    CE(hipMemsetAsync(sum, 0, sizeof(double) * channel_sum_doubles(1), st));
     CE(hipStreamSynchronize(st));   // the host vectors go out of scope
     // spectrum of the chirp kernel, in the forward FFT's k1-major order
     CE(launch_chirp_kernel(bspec, N, P, st));

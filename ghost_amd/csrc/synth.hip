@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   }
   const int tid = threadIdx.x;
   long long probe_c0 = 0, probe_t0 = 0;
-  if (a.clock_probe) { probe_c0 = __builtin_amdgcn_s_memtime(); probe_t0 = __builtin_amdgcn_s_memrealtime(); }
+  if (kMeasureBuild && a.clock_probe) { probe_c0 = __builtin_amdgcn_s_memtime(); probe_t0 = __builtin_amdgcn_s_memrealtime(); }
   const int colw = tid >> 4, t = tid & 15;
   const bool wide = R > NCOL;
   const int blk_l = wide ? 0 : (colw >> lg);
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   const int64_t n_b = (int64_t)(lv.blk_base + it.blk0) * hop * R;   // first sample of the block group
   const int64_t w_lo = a.seg.w_lo[seg];
   const int64_t w_len = a.seg.w_hi[seg] - w_lo;
-  const unsigned ext_bytes = w_len > 0 && !(a.drop_stores & 1) ? (unsigned)(w_len * (4 * kElem)) : 0u;
+  const unsigned ext_bytes = w_len > 0 && !(kMeasureBuild && (a.drop_stores & 1)) ? (unsigned)(w_len * (4 * kElem)) : 0u;
   float* const out0 = a.out + ((int64_t)ch * a.n_scales * a.row_len + a.seg.seg_col[seg] + w_lo) * kElem;
   const unsigned voff0 = (unsigned)(((int)(n_b - w_lo) + off0) * (4 * kElem));
   const unsigned vstep = (unsigned)(m1step * (4 * kElem));
@@ -221,10 +221,10 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j)              // W256^(t j); j = 0 is 1
       exw[j * sstride] = j == 0 ? v[0] : cmulv(v[dft16_pos(j)], twl[16 * j + t]);
-    if (!(a.drop_stores & 2)) __syncthreads();      // (measurement builds clear these bits: kernels.h)
+    if (!(kMeasureBuild && (a.drop_stores & 2))) __syncthreads();      // (always taken in the product build: kernels.h)
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) v[k1] = exr[k1 * kPlane];
-    if (!(a.drop_stores & 2)) __syncthreads();
+    if (!(kMeasureBuild && (a.drop_stores & 2))) __syncthreads();
     idft16v(v);
 
     // descriptor built from provably wave-uniform words (else hipcc waterfalls every store)
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
       }
     }
   }
-  if (a.clock_probe && tid == 0) {
+  if (kMeasureBuild && a.clock_probe && tid == 0) {
     atomicAdd(a.clock_probe, (unsigned long long)(__builtin_amdgcn_s_memtime() - probe_c0));
     atomicAdd(a.clock_probe + 1, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - probe_t0));
   }

@@ -1,0 +1,351 @@
+// synthi.hip -- interpolating synthesis: the amplitude / power rows of the levels whose scales
+// are heavily oversampled at the full rate (R >= 16: every scale of such a level occupies at most
+// a fifth of the rate its block transform produces once q = 4 phases are taken).
+// (transforms.py:203-204: convolve each epoch with each scale's kernel, keep abs.)
+//
+// k_synth7 pays one point of a 256-point inverse FFT for every stored sample.  Here a (block,
+// scale) goes through that transform only for q of its R phases -- the scale's complex output z
+// at q x the level's rate, demodulated to its band centre so that it is a low-pass signal -- and
+// the R / q = I samples between two of those come from an 8-tap polyphase FIR with real
+// coefficients (interp.h: least-squares design on the level's band; what it adds is bounded per
+// level from the scales' own gains, planner.cpp: plan_interp_level, and stays below 1.5e-7 of a
+// scale's peak).  |.| does not see the demodulation.  Per stored sample: 8 packed FMAs + |.|
+// against ~20 VALU and 5 LDS instructions, and the stores are whole 1 KB runs per wave.
+//
+// One workgroup (512 threads) = one block of one level; it walks the level's scales 32 / q at a
+// time ("slots").  Per pass:
+//   A  32 columns (slot, phase): P * G_s, DFT16, W256 twiddle, exchange through LDS, DFT16 -- the
+//      loop body of k_synth7 -- with the demodulation folded in: bins are counted from the
+//      scale's centre k_c (twiddle exponent (t - k_c) a - (k_c / q) p, exchange planes read
+//      rotated by k_c), so z needs no multiply of its own.  z lands in LDS in time order.
+//   B  every wave takes runs of 256 consecutive output samples of one scale: a lane makes 4
+//      consecutive samples from the 8 z values around them (coefficients of its 4 sub-sample
+//      positions in registers), |.|, one 16-byte store; a wave store is 1 KB contiguous.
+// Kernels of even length carry a half-sample delay: their rows are interpolated at
+// tau - 1/(2 I) with a second coefficient table instead of a phase on the spectrum.
+#include <hip/hip_runtime.h>
+
+#include "interp.h"
+#include "kernels.h"
+#include "synth_math.h"
+
+#ifndef GCWT_STORE_AUX
+#define GCWT_STORE_AUX 2   // nt: the rows are written once and not read by this launch
+#endif
+
+namespace gcwt {
+
+namespace {
+constexpr int kT = kInterpTaps;
+static_assert(kT == 8, "the FIR loop below is written for 8 taps");
+// Columns per pass.  16 (256 threads, three workgroups and 12 waves per CU, up to 168 VGPRs: the
+// persistent operand, the FIR coefficients and both transforms' working sets fit without spills)
+// or 32 (512 threads, two workgroups and 16 waves per CU, 128 VGPRs).
+#ifndef GCWT_SYNTHI_COLS
+#define GCWT_SYNTHI_COLS 16
+#endif
+constexpr int kColsI = GCWT_SYNTHI_COLS;
+constexpr int kLgColsI = kColsI == 32 ? 5 : kColsI == 16 ? 4 : 3;
+constexpr int kThreadsI = 16 * kColsI;
+constexpr int kWavesI = kThreadsI / 64;
+constexpr int kPlaneI = kThreadsI + 1;
+constexpr int kZPad = 4;                         // v2f entries between the slots of the z buffer: their
+                                                 // writes fall on different banks
+constexpr int kSlotsMax = kColsI / 4;            // q >= 4
+constexpr int kZElems = 256 * kColsI + kSlotsMax * kZPad;     // z buffer
+constexpr int kExElems = kZElems > 16 * kPlaneI ? kZElems : 16 * kPlaneI;   // ... in place of the 16 exchange planes
+constexpr int kGainRowI = 16 * 20;
+constexpr int kLdsBytes = kExElems * 8 + 256 * 8 + kSlotsMax * kGainRowI * 4 + 2 * 256 * 4;
+
+// acc += z * c.x  /  acc += z * c.y: complex z, real coefficient broadcast to both halves
+__device__ __forceinline__ v2f fir_mul_lo(v2f z, v2f c) {
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(z), "v"(c));
+  return r;
+}
+__device__ __forceinline__ v2f fir_fma_lo(v2f acc, v2f z, v2f c) {
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(z), "v"(c), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ v2f fir_fma_hi(v2f acc, v2f z, v2f c) {
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(z), "v"(c), "v"(acc));
+  return r;
+}
+}  // namespace
+
+template <int MODE>
+__global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(const SynthiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* const ex = reinterpret_cast<v2f*>(smem);
+  v2f* const twl = ex + kExElems;                                   // exp(+2 pi i n / 256)
+  float* const stage = reinterpret_cast<float*>(twl + 256);         // gains of the pass's scales
+  int* const sc_lds = reinterpret_cast<int*>(stage + kSlotsMax * kGainRowI);
+  int* const aux_lds = sc_lds + 256;
+
+  const SynthiItem it = a.items[blockIdx.x];
+  const SynthiLevel lv = a.levels[it.level];
+  const int c = blockIdx.y;               // workspace slot: segment * n_channels + channel
+  const int seg = c / a.seg.n_channels, ch = c - seg * a.seg.n_channels;
+  const int R = lv.decimation, q = lv.q, lgq = lv.log2q, hop = lv.hop, halo = lv.halo;
+  const int64_t n_b = (int64_t)(lv.blk_base + it.blk0) * hop * R;   // first kept sample of the block
+  const int64_t w_lo = a.seg.w_lo[seg];
+  const int64_t w_len = a.seg.w_hi[seg] - w_lo;
+  // the level grids are the union over the batch's segments: nothing of this block inside the
+  // segment's window -> leave (workgroup-uniform)
+  if (n_b + (int64_t)hop * R <= w_lo || n_b >= w_lo + w_len) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int colw = tid >> 4, t = tid & 15;
+  const int slot = colw >> lgq, p = colw & (q - 1), ns = kColsI >> lgq;
+  const int n_scales = lv.n_scales;
+  const int* const scales = a.scale_list + lv.scale_offset;
+  const int* const auxs = a.scale_aux + lv.scale_offset;
+  for (int i = tid; i < n_scales; i += kThreadsI) { sc_lds[i] = scales[i]; aux_lds[i] = auxs[i]; }
+  if (tid < 256) {
+    const float2 w = a.tw256[tid];
+    twl[tid] = (v2f){w.x, w.y};
+  }
+  // gains of one pass in LDS, lane t's sixteen values (bins t + 16 j) side by side at a pitch of
+  // 20 floats (four conflict-free 16-byte reads per thread), as k_synth7 parks them
+  auto stage_slot = [&](int i) { return (i >> 8) * kGainRowI + (i & 15) * 20 + ((i >> 4) & 15); };
+  for (int i = tid; i < ns * 256; i += kThreadsI) {
+    const int sb = min(i >> 8, n_scales - 1);
+    stage[stage_slot(i)] = a.gain[(int64_t)(scales[sb] & kScaleIndexMask) * 256 + (i & 255)];
+  }
+
+  // Block spectrum XB = FFT_256(x_R[(b hop - halo + n) mod M]) / (256 P), made by 16 threads as
+  // conj(IFFT(conj .)) on the packed inverse DFT16 (k_synth7's prologue), left in LDS for all.
+  v2f* const fx = ex;
+  v2f* const xbs = ex + 256;
+  {
+    v2f v[16];
+    if (colw == 0) {
+      const int64_t base = (int64_t)(lv.blk_base + it.blk0) * hop - halo + t;
+      const float2* xr = a.xr + (int64_t)c * a.xr_cstride + lv.xr_offset;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float2 u = xr[(base + 16 * j) & lv.m_mask];
+        v[j] = (v2f){u.x, -u.y};
+      }
+      idft16v(v);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float2 w = a.tw256[(t * m) & 255];
+        fx[t * 16 + (m ^ t)] = cmulv(v[dft16_pos(m)], (v2f){w.x, w.y});
+      }
+    }
+    __syncthreads();
+    if (colw == 0) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) v[k1] = fx[k1 * 16 + (t ^ k1)];
+      idft16v(v);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const v2f z = v[dft16_pos(j)];
+        xbs[t + 16 * j] = (v2f){z.x * a.xb_scale, -z.y * a.xb_scale};
+      }
+    }
+    __syncthreads();
+  }
+  // what never changes for a thread: P[k] = XB[k] W^{k r}, k = t + 16 j, r = p I the phase of its column
+  v2f pw[16];
+  {
+    const int r = p * lv.factor;
+    const float2* ltw = a.level_tw + lv.tw_offset;
+    const float2 b0 = ltw[t * r], st = ltw[16 * r];
+    v2f wcur = (v2f){b0.x, b0.y};
+    const v2f wstep = (v2f){st.x, st.y};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      pw[j] = cmulv(xbs[t + 16 * j], wcur);
+      wcur = cmulv(wcur, wstep);
+    }
+  }
+
+  // second half of the transform: thread (a2, col2) takes output samples a2 + 16 c of its column
+  const int a2 = tid >> kLgColsI, col2 = tid & (kColsI - 1);
+  const int slot2 = col2 >> lgq, p2 = col2 & (q - 1);
+  const int zstride = (256 << lgq) + kZPad;
+  v2f* const zw = ex + slot2 * zstride + (a2 << lgq) + p2;   // + 16 q c
+
+  // phase B geometry: lane-tasks of 4 consecutive samples, 64 of them per wave-task
+  const int I = lv.factor;
+  int lgi4 = 0;
+  while ((4 << lgi4) < I) ++lgi4;                             // I / 4 = 1 << lgi4
+  const int tps = hop * (R >> 2);                             // lane-tasks per (block, scale)
+  const int wps = (tps + 63) >> 6;
+  const int sigma = lane & ((1 << lgi4) - 1);                 // which 4 of the I sub-sample positions
+  const float* const coef0 = a.coef + lv.coef_offset + (int64_t)sigma * 4 * kT;
+  constexpr int kElem = 1;
+  const unsigned ext_bytes = w_len > 0 ? (unsigned)(w_len * (4 * kElem)) : 0u;
+  float* const out0 = a.out + ((int64_t)ch * a.n_scales * a.row_len + a.seg.seg_col[seg] + w_lo) * kElem;
+  const int s_base = (int)(n_b - w_lo);                       // window-relative sample of the block's first
+  const int n_pass = (n_scales + ns - 1) >> (kLgColsI - lgq);
+  int cur_par = -1;                       // which coefficient table cf holds: kernels of odd (0) / even (1) length
+  v2f cf[4][kT / 2];
+  __syncthreads();
+
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int b0 = pass * ns;
+    const bool has_next = pass + 1 < n_pass;
+    // next pass's gains: loaded now (nothing of this pass is in flight yet), parked after the exchange
+    float nxt[4];
+    if (has_next) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = tid + kThreadsI * u;
+        if (i < ns * 256) {
+          const int sb = min(b0 + ns + (i >> 8), n_scales - 1);
+          nxt[u] = a.gain[(int64_t)(sc_lds[sb] & kScaleIndexMask) * 256 + (i & 255)];
+        }
+      }
+    }
+    // ---- A: 32 columns through the 256-point inverse transform --------------------------------
+    {
+      const int bs = min(b0 + slot, n_scales - 1);
+      const int entry = sc_lds[bs];
+      const int kc = aux_lds[bs] & 0xffff;
+      const float4* const hs = reinterpret_cast<const float4*>(stage + slot * kGainRowI + t * 20);
+      v2f v[16];
+      // (16 - j_hi) in the entry's top byte: first-pass inputs j >= j_hi are left out (kernels.h);
+      // a wave's four columns belong to one slot (q >= 4), so the choice is wave-uniform
+      switch ((unsigned)__builtin_amdgcn_readfirstlane(entry) >> 24) {
+#define GCWT_WINDOW(hi) case 16 - (hi): gain_first_layer<hi>(v, pw, hs); break;
+        GCWT_WINDOW(15) GCWT_WINDOW(14) GCWT_WINDOW(13) GCWT_WINDOW(12) GCWT_WINDOW(11) GCWT_WINDOW(10) GCWT_WINDOW(9)
+#undef GCWT_WINDOW
+        default: gain_first_layer<16>(v, pw, hs); break;
+      }
+      idft16v_tail(v);
+      // twiddle W256^{(t - k_c) a - (k_c / q) p}: bins counted from the demodulation centre
+      const int step = (t - kc) & 255;
+      int idx = (-(kc >> lgq) * p) & 255;
+      v2f* const exw = ex + t * kPlaneI + colw;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        exw[j * kColsI] = cmulv(v[dft16_pos(j)], twl[idx]);
+        idx = (idx + step) & 255;
+      }
+    }
+    __syncthreads();
+    if (has_next) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = tid + kThreadsI * u;
+        if (i < ns * 256) stage[stage_slot(i)] = nxt[u];
+      }
+    }
+    {
+      v2f v[16];
+      const int rot = aux_lds[min(b0 + slot2, n_scales - 1)] & 15;   // k_c mod 16
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) v[k1] = ex[((k1 + rot) & 15) * kPlaneI + tid];
+      __syncthreads();                      // every plane is read before z takes their place
+      idft16v(v);
+#pragma unroll
+      for (int m1 = 0; m1 < 16; ++m1) zw[(16 * m1) << lgq] = v[dft16_pos(m1)];
+    }
+    __syncthreads();
+
+    // ---- B: interpolate, |.|, store -----------------------------------------------------------
+    {
+      const int n_valid = min(ns, n_scales - b0);
+      for (int sl = 0; sl < n_valid; ++sl) {                  // everything here is wave-uniform
+        const int entry = __builtin_amdgcn_readfirstlane(sc_lds[b0 + sl]);
+        const int par = (__builtin_amdgcn_readfirstlane(aux_lds[b0 + sl]) >> 16) & 1;
+        if (par != cur_par) {                                 // at most twice per workgroup: the level's list
+          const float4* const cp = reinterpret_cast<const float4*>(coef0 + (int64_t)par * I * kT);   // is ordered by parity
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float4 u0 = cp[2 * i], u1 = cp[2 * i + 1];
+            cf[i][0] = (v2f){u0.x, u0.y}; cf[i][1] = (v2f){u0.z, u0.w};
+            cf[i][2] = (v2f){u1.x, u1.y}; cf[i][3] = (v2f){u1.z, u1.w};
+          }
+          cur_par = par;
+        }
+        // descriptor from provably wave-uniform words (else hipcc waterfalls every store); it spans
+        // exactly the samples this launch may write, [w_lo, w_hi) of the segment
+        const int srow = entry & kScaleIndexMask;
+        const uint64_t dst_bits = reinterpret_cast<uint64_t>(out0 + (int64_t)srow * a.row_len * kElem);
+        const uint32_t dst_lo = __builtin_amdgcn_readfirstlane((uint32_t)dst_bits);
+        const uint32_t dst_hi = __builtin_amdgcn_readfirstlane((uint32_t)(dst_bits >> 32));
+        float* const dst = reinterpret_cast<float*>(((uint64_t)dst_hi << 32) | dst_lo);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            dst, 0, __builtin_amdgcn_readfirstlane(ext_bytes), 0x00020000);
+        const v2f* const zs = ex + sl * zstride + (halo << lgq) - (kT / 2 - 1);
+        // the slot's wave-tasks are dealt round-robin over the waves, continuing where the previous
+        // slot stopped
+        for (int wt = (wave - sl * wps) & (kWavesI - 1); wt < wps; wt += kWavesI) {
+          const int k = wt * 64 + lane;
+          const int s_first = s_base + 256 * wt;              // window-relative sample of the wave-task's first
+          const bool whole = wt * 64 + 64 <= tps && s_first >= 0 && (int64_t)s_first + 256 <= w_len;
+          if (whole || k < tps) {
+            const v2f* const zp = zs + (k >> lgi4);
+            // tap by tap: four accumulators live, two z values at a time
+            v2f acc[4];
+            {
+              const v2f w0 = zp[0], w1 = zp[1];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[i] = fir_fma_hi(fir_mul_lo(w0, cf[i][0]), w1, cf[i][0]);
+            }
+#pragma unroll
+            for (int j = 1; j < kT / 2; ++j) {
+              const v2f w0 = zp[2 * j], w1 = zp[2 * j + 1];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[i] = fir_fma_hi(fir_fma_lo(acc[i], w0, cf[i][j]), w1, cf[i][j]);
+            }
+            float res[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float p2v = __builtin_fmaf(acc[i].y, acc[i].y, acc[i].x * acc[i].x);
+              res[i] = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2v) : p2v;
+            }
+            const int s0 = s_base + 4 * k;                    // window-relative sample of res[0]
+            if (whole) {                                      // wave-uniform: no lane looks at its own range
+              typedef unsigned v4u __attribute__((ext_vector_type(4)));
+              const v4u pk = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
+                              __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
+              __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (unsigned)s0 * 4u, 0, GCWT_STORE_AUX);
+            } else {
+              // the window's edge (or the block's last samples) runs through this wave-task: one
+              // sample at a time, the range check drops what lies outside (negative offsets wrap)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rsrc,
+                                                      (unsigned)(s0 + i) * 4u, 0, GCWT_STORE_AUX);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                        // z is read out before the next pass's exchange overwrites it
+  }
+}
+
+hipError_t launch_synthi(int mode, const SynthiArgs& a, int n_items, int n_channels, hipStream_t st) {
+  if (n_items == 0) return hipSuccess;
+  if (mode != GCWT_OUT_AMPLITUDE_F32 && mode != GCWT_OUT_POWER_F32) return hipErrorInvalidValue;
+  static bool attr_done[64] = {};            // per device: one process may drive several
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  bool& attr_set = attr_done[dev_ & 63];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_synthi<GCWT_OUT_AMPLITUDE_F32>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_synthi<GCWT_OUT_POWER_F32>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(n_items, n_channels), block(kThreadsI);
+  if (mode == GCWT_OUT_AMPLITUDE_F32)
+    hipLaunchKernelGGL((k_synthi<GCWT_OUT_AMPLITUDE_F32>), grid, block, kLdsBytes, st, a);
+  else
+    hipLaunchKernelGGL((k_synthi<GCWT_OUT_POWER_F32>), grid, block, kLdsBytes, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace gcwt

@@ -235,6 +235,29 @@ class CwtPlan:
                         "nblk": nb.value, "m": m.value})
         return res
 
+    def debug_interp(self):
+        """Per level: None when it is made by the FFT-per-sample kernels, else the interpolating
+        synthesis' design -- q, factor I = R / q, alpha, err_bound, coef[2][I][8] -- and, under
+        "demod", the demodulation bin of every scale of the plan (csrc/synthi.hip)."""
+        n = lib.gcwt_debug_level_count(self._handle)
+        f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        levels = []
+        for l in range(n):
+            q, fac, al, eb = C.c_int32(), C.c_int32(), C.c_double(), C.c_double()
+            check(lib.gcwt_debug_interp_level(self._handle, l, C.byref(q), C.byref(fac), C.byref(al),
+                                              C.byref(eb), None, 0))
+            if q.value == 0:
+                levels.append(None)
+                continue
+            coef = np.empty((2, fac.value, 8), dtype=np.float32)
+            check(lib.gcwt_debug_interp_level(self._handle, l, None, None, None, None,
+                                              coef.ctypes.data_as(f32p), coef.size))
+            levels.append({"q": q.value, "factor": fac.value, "alpha": al.value,
+                           "err_bound": eb.value, "coef": coef})
+        demod = np.zeros(self.n_freqs, dtype=np.int32)
+        check(lib.gcwt_debug_scale_demod(self._handle, demod.ctypes.data_as(i32p)))
+        return {"levels": levels, "demod": demod}
+
     def debug_batches(self):
         """[(first_segment, count)] of the launch batches the plan's segments form."""
         res, seg, n = [], 0, lib.gcwt_plan_segment_count(self._handle)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GCWT_ABI_VERSION 2
+#define GCWT_ABI_VERSION 3
 
 typedef enum {
   GCWT_OK = 0,
@@ -104,7 +104,8 @@ typedef struct {
   int64_t workspace_bytes;     /* device workspace the plan will allocate         */
   int64_t out_bytes;           /* size of the out buffer gcwt_execute fills       */
   int32_t n_fullband;          /* scales on the full-band path                    */
-  int32_t reserved;
+  int32_t n_interp;            /* of n_spectral: scales made by the interpolating
+                                  synthesis (amplitude / power, R >= 16)          */
 } gcwt_plan_info;
 
 /* Stage timings of the last gcwt_execute on a plan created with profiling on,
@@ -119,6 +120,7 @@ typedef struct {
   float total_ms;       /* first kernel start to last kernel end                  */
   int32_t synth_launches;
   float fullband_ms;    /* full-band scales (filter, product, inverse FFT, store) */
+  float interp_ms;      /* of synth_ms: the interpolating synthesis kernel        */
 } gcwt_timings;
 
 /* Library / device ------------------------------------------------------- */

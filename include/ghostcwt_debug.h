@@ -29,7 +29,22 @@ int gcwt_debug_fetch(gcwt_plan* plan, int what, int channel, int epoch, int leve
  * (csrc/morse_exact.h).  Needs no GPU. */
 int gcwt_debug_exact_gain(const gcwt_plan* plan, int scale, const int64_t* a, int64_t b, int64_t n,
                           double* gain);
-/* Measurement only, plans uploaded with GHOSTCWT_CLOCK_PROBE=1 in the environment: the shader
+/* Interpolating synthesis (csrc/synthi.hip) of one level: phases q of the block transform per
+ * (block, scale) -- 0 when the level is made by the FFT-per-sample kernels -- the interpolation
+ * factor I = R / q, the design band (fraction of the oversampled Nyquist) and the planner's bound
+ * on the error the interpolation adds, relative to a scale's peak gain.  coef (may be NULL):
+ * [2][I][8] floats, the 8-tap interpolators of the I sub-sample positions for kernels of odd and
+ * of even length.  demod (may be NULL): per SCALE of the plan, the bin of its level's 256-point
+ * grid its oversampled output is demodulated by.  Host only. */
+int gcwt_debug_interp_level(const gcwt_plan* plan, int level, int32_t* q, int32_t* factor,
+                            double* alpha, double* err_bound, float* coef, int64_t max_floats);
+int gcwt_debug_scale_demod(const gcwt_plan* plan, int32_t* demod);
+/* 1 in libghostcwt_measure.so (`make -C ghost_amd/csrc measure`: -DGCWT_MEASURE), the build that
+ * carries the measurement hooks -- stores dropped / barriers removed (GHOSTCWT_SYNTH_DROP_STORES,
+ * results WRONG), the in-kernel clock probe, the slower k_synth8 (GHOSTCWT_SYNTH_KERNEL=8);
+ * 0 in the product library, which has none of those paths. */
+int gcwt_debug_measure_build(void);
+/* Measure build only, plans created with GHOSTCWT_CLOCK_PROBE=1 in the environment: the shader
  * clock the synthesis workgroups ran at since the last call (sum of s_memtime deltas over
  * sum of s_memrealtime deltas, one pair per workgroup: MI355X_MICROARCH.md "DVFS
  * give-back" item 6) and the summed workgroup lifetimes. */
