@@ -509,10 +509,18 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       const LevelPlan& lp = hp.levels[l];
       int lgq = 0;
       while ((1 << lgq) < lp.interp_q) ++lgq;
+      // Blocks per workgroup: a workgroup's prologue (its blocks' spectra, 16 threads each) takes
+      // about as long whatever their number, and a block of a low decimation is little work --
+      // four blocks at R = 16, two at R = 32, one from R = 64 up (the 16 columns of a pass are
+      // blocks x scales x phases).
+      int lgnb = 0;
+      while (lgnb < 2 && (lp.decimation << lgnb) < 64 && (lp.interp_q << (lgnb + 1)) <= 16) ++lgnb;
+      if (const char* e = getenv("GHOSTCWT_INTERP_LGNB")) lgnb = std::min(std::max(atoi(e), 0), 2);   // (A/B runs; read at upload)
+      while ((lp.interp_q << lgnb) > 16) --lgnb;
       lvi[l] = {lp.decimation, lp.interp_q, lgq, lp.interp_factor, lp.hop, lp.halo, ep.lv[l].nblk,
-                (int32_t)lp.scales.size(), scale_off[l], ep.lv[l].blk_lo, 0, 0, lp.twiddle_offset,
+                (int32_t)lp.scales.size(), scale_off[l], ep.lv[l].blk_lo, lgnb, 0, lp.twiddle_offset,
                 ep.lv[l].xr_offset, ep.lv[l].m - 1, lp.coef_offset};
-      for (int b0 = 0; b0 < ep.lv[l].nblk; ++b0) items_i.push_back({(int32_t)l, b0});
+      for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += 1 << lgnb) items_i.push_back({(int32_t)l, b0});
     }
     p->ep_dev[e].n_items_i = (int)items_i.size();
     if ((rc = upload_vec(&p->ep_dev[e].items_i, items_i, p->stream))) return bail(rc);

@@ -89,17 +89,22 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   const int c = blockIdx.y;               // workspace slot: segment * n_channels + channel
   const int seg = c / a.seg.n_channels, ch = c - seg * a.seg.n_channels;
   const int R = lv.decimation, q = lv.q, lgq = lv.log2q, hop = lv.hop, halo = lv.halo;
-  const int64_t n_b = (int64_t)(lv.blk_base + it.blk0) * hop * R;   // first kept sample of the block
+  const int lgnb = lv.log2nb, nb = 1 << lgnb;                       // blocks per workgroup
+  const int64_t n_b = (int64_t)(lv.blk_base + it.blk0) * hop * R;   // first kept sample of the first block
   const int64_t w_lo = a.seg.w_lo[seg];
   const int64_t w_len = a.seg.w_hi[seg] - w_lo;
-  // the level grids are the union over the batch's segments: nothing of this block inside the
+  // the level grids are the union over the batch's segments: nothing of these blocks inside the
   // segment's window -> leave (workgroup-uniform)
-  if (n_b + (int64_t)hop * R <= w_lo || n_b >= w_lo + w_len) return;
+  if (n_b + (int64_t)nb * hop * R <= w_lo || n_b >= w_lo + w_len) return;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int colw = tid >> 4, t = tid & 15;
-  const int slot = colw >> lgq, p = colw & (q - 1), ns = kColsI >> lgq;
+  // column -> (block of the group, scale slot of the pass, phase); a "z slot" is a (block, scale) pair
+  const int lgns = kLgColsI - lgq - lgnb, ns = 1 << lgns;
+  const int zslot = colw >> lgq, p = colw & (q - 1);
+  const int slot = zslot & (ns - 1), blk_l = zslot >> lgns;
+  const int nzs = kColsI >> lgq;
   const int n_scales = lv.n_scales;
   const int* const scales = a.scale_list + lv.scale_offset;
   const int* const auxs = a.scale_aux + lv.scale_offset;
@@ -119,11 +124,12 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   // Block spectrum XB = FFT_256(x_R[(b hop - halo + n) mod M]) / (256 P), made by 16 threads as
   // conj(IFFT(conj .)) on the packed inverse DFT16 (k_synth7's prologue), left in LDS for all.
   v2f* const fx = ex;
-  v2f* const xbs = ex + 256;
+  v2f* const xbs = ex + kSlotsMax * 256;
   {
     v2f v[16];
-    if (colw == 0) {
-      const int64_t base = (int64_t)(lv.blk_base + it.blk0) * hop - halo + t;
+    if (colw < nb) {
+      // blocks past the level's last one reuse it and are never stored
+      const int64_t base = (int64_t)(lv.blk_base + min(it.blk0 + colw, lv.nblk - 1)) * hop - halo + t;
       const float2* xr = a.xr + (int64_t)c * a.xr_cstride + lv.xr_offset;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -134,18 +140,18 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const float2 w = a.tw256[(t * m) & 255];
-        fx[t * 16 + (m ^ t)] = cmulv(v[dft16_pos(m)], (v2f){w.x, w.y});
+        fx[colw * 256 + t * 16 + (m ^ t)] = cmulv(v[dft16_pos(m)], (v2f){w.x, w.y});
       }
     }
     __syncthreads();
-    if (colw == 0) {
+    if (colw < nb) {
 #pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) v[k1] = fx[k1 * 16 + (t ^ k1)];
+      for (int k1 = 0; k1 < 16; ++k1) v[k1] = fx[colw * 256 + k1 * 16 + (t ^ k1)];
       idft16v(v);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const v2f z = v[dft16_pos(j)];
-        xbs[t + 16 * j] = (v2f){z.x * a.xb_scale, -z.y * a.xb_scale};
+        xbs[colw * 256 + t + 16 * j] = (v2f){z.x * a.xb_scale, -z.y * a.xb_scale};
       }
     }
     __syncthreads();
@@ -160,16 +166,16 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
     const v2f wstep = (v2f){st.x, st.y};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      pw[j] = cmulv(xbs[t + 16 * j], wcur);
+      pw[j] = cmulv(xbs[blk_l * 256 + t + 16 * j], wcur);
       wcur = cmulv(wcur, wstep);
     }
   }
 
   // second half of the transform: thread (a2, col2) takes output samples a2 + 16 c of its column
   const int a2 = tid >> kLgColsI, col2 = tid & (kColsI - 1);
-  const int slot2 = col2 >> lgq, p2 = col2 & (q - 1);
+  const int zslot2 = col2 >> lgq, p2 = col2 & (q - 1);
   const int zstride = (256 << lgq) + kZPad;
-  v2f* const zw = ex + slot2 * zstride + (a2 << lgq) + p2;   // + 16 q c
+  v2f* const zw = ex + zslot2 * zstride + (a2 << lgq) + p2;   // + 16 q c
 
   // phase B geometry: lane-tasks of 4 consecutive samples, 64 of them per wave-task
   const int I = lv.factor;
@@ -183,7 +189,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   const unsigned ext_bytes = w_len > 0 ? (unsigned)(w_len * (4 * kElem)) : 0u;
   float* const out0 = a.out + ((int64_t)ch * a.n_scales * a.row_len + a.seg.seg_col[seg] + w_lo) * kElem;
   const int s_base = (int)(n_b - w_lo);                       // window-relative sample of the block's first
-  const int n_pass = (n_scales + ns - 1) >> (kLgColsI - lgq);
+  const int n_pass = (n_scales + ns - 1) >> lgns;
   int cur_par = -1;                       // which coefficient table cf holds: kernels of odd (0) / even (1) length
   v2f cf[4][kT / 2];
   __syncthreads();
@@ -239,7 +245,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
     }
     {
       v2f v[16];
-      const int rot = aux_lds[min(b0 + slot2, n_scales - 1)] & 15;   // k_c mod 16
+      const int rot = aux_lds[min(b0 + (zslot2 & (ns - 1)), n_scales - 1)] & 15;   // k_c mod 16
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) v[k1] = ex[((k1 + rot) & 15) * kPlaneI + tid];
       __syncthreads();                      // every plane is read before z takes their place
@@ -251,8 +257,9 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
 
     // ---- B: interpolate, |.|, store -----------------------------------------------------------
     {
-      const int n_valid = min(ns, n_scales - b0);
-      for (int sl = 0; sl < n_valid; ++sl) {                  // everything here is wave-uniform
+      for (int zi = 0; zi < nzs; ++zi) {                      // everything here is wave-uniform
+        const int sl = zi & (ns - 1), bl = zi >> lgns;
+        if (b0 + sl >= n_scales || it.blk0 + bl >= lv.nblk) continue;
         const int entry = __builtin_amdgcn_readfirstlane(sc_lds[b0 + sl]);
         const int par = (__builtin_amdgcn_readfirstlane(aux_lds[b0 + sl]) >> 16) & 1;
         if (par != cur_par) {                                 // at most twice per workgroup: the level's list
@@ -274,12 +281,13 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
         float* const dst = reinterpret_cast<float*>(((uint64_t)dst_hi << 32) | dst_lo);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             dst, 0, __builtin_amdgcn_readfirstlane(ext_bytes), 0x00020000);
-        const v2f* const zs = ex + sl * zstride + (halo << lgq) - (kT / 2 - 1);
+        const v2f* const zs = ex + zi * zstride + (halo << lgq) - (kT / 2 - 1);
+        const int s_blk = s_base + bl * hop * R;              // window-relative sample of this block's first
         // the slot's wave-tasks are dealt round-robin over the waves, continuing where the previous
         // slot stopped
-        for (int wt = (wave - sl * wps) & (kWavesI - 1); wt < wps; wt += kWavesI) {
+        for (int wt = (wave - zi * wps) & (kWavesI - 1); wt < wps; wt += kWavesI) {
           const int k = wt * 64 + lane;
-          const int s_first = s_base + 256 * wt;              // window-relative sample of the wave-task's first
+          const int s_first = s_blk + 256 * wt;               // window-relative sample of the wave-task's first
           const bool whole = wt * 64 + 64 <= tps && s_first >= 0 && (int64_t)s_first + 256 <= w_len;
           if (whole || k < tps) {
             const v2f* const zp = zs + (k >> lgi4);
@@ -302,7 +310,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
               const float p2v = __builtin_fmaf(acc[i].y, acc[i].y, acc[i].x * acc[i].x);
               res[i] = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2v) : p2v;
             }
-            const int s0 = s_base + 4 * k;                    // window-relative sample of res[0]
+            const int s0 = s_blk + 4 * k;                     // window-relative sample of res[0]
             if (whole) {                                      // wave-uniform: no lane looks at its own range
               typedef unsigned v4u __attribute__((ext_vector_type(4)));
               const v4u pk = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
