@@ -510,11 +510,10 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       int lgq = 0;
       while ((1 << lgq) < lp.interp_q) ++lgq;
       // Blocks per workgroup: a workgroup's prologue (its blocks' spectra, 16 threads each) takes
-      // about as long whatever their number, and a block of a low decimation is little work --
-      // four blocks at R = 16, two at R = 32, one from R = 64 up (the 16 columns of a pass are
-      // blocks x scales x phases).
-      int lgnb = 0;
-      while (lgnb < 2 && (lp.decimation << lgnb) < 64 && (lp.interp_q << (lgnb + 1)) <= 16) ++lgnb;
+      // about as long whatever their number, and a block of a low decimation is little work:
+      // two blocks per workgroup up to R = 32, one from R = 64 up (measured per level,
+      // profiles/r03_synth_study.md; the 16 columns of a pass are blocks x scales x phases).
+      int lgnb = lp.decimation <= 32 ? 1 : 0;
       if (const char* e = getenv("GHOSTCWT_INTERP_LGNB")) lgnb = std::min(std::max(atoi(e), 0), 2);   // (A/B runs; read at upload)
       while ((lp.interp_q << lgnb) > 16) --lgnb;
       lvi[l] = {lp.decimation, lp.interp_q, lgq, lp.interp_factor, lp.hop, lp.halo, ep.lv[l].nblk,

@@ -210,10 +210,11 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
   const int B = hp->block, R = lp->decimation;
   lp->interp_q = 0;
   if (hp->prm.out_mode == GCWT_OUT_COMPLEX_C64) return;   // the demodulation would have to be undone per sample
-  // Below R = 32 the q = 4 phases through the block transform are a quarter or more of the
-  // FFT-per-sample work and the interpolation does not pay (measured per level:
-  // profiles/r03_synth_study.md); GHOSTCWT_INTERP_MIN_R moves the line (A/B runs).
-  int min_r = 32;
+  // Below R = 16 the q = 4 phases through the block transform are half or more of the
+  // FFT-per-sample work and the interpolation does not pay (at R = 16 it breaks even per level
+  // and wins 2 % on the headline mix: profiles/r03_synth_study.md); GHOSTCWT_INTERP_MIN_R moves
+  // the line (A/B runs).
+  int min_r = 16;
   if (const char* e = getenv("GHOSTCWT_INTERP_MIN_R")) min_r = std::max(16, atoi(e));
   if (R < min_r || lp->scales.empty()) return;
   int q = 4;

@@ -16,7 +16,7 @@
 // time ("slots").  Per pass:
 //   A  32 columns (slot, phase): P * G_s, DFT16, W256 twiddle, exchange through LDS, DFT16 -- the
 //      loop body of k_synth7 -- with the demodulation folded in: bins are counted from the
-//      scale's centre k_c (twiddle exponent (t - k_c) a - (k_c / q) p, exchange planes read
+//      scale's centre k_c (twiddle exponent (t - k_c) a - (k_c / q) p, exchange planes written
 //      rotated by k_c), so z needs no multiply of its own.  z lands in LDS in time order.
 //   B  every wave takes runs of 256 consecutive output samples of one scale: a lane makes 4
 //      consecutive samples from the 8 z values around them (coefficients of its 4 sub-sample
@@ -225,14 +225,17 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
         default: gain_first_layer<16>(v, pw, hs); break;
       }
       idft16v_tail(v);
-      // twiddle W256^{(t - k_c) a - (k_c / q) p}: bins counted from the demodulation centre
-      const int step = (t - kc) & 255;
-      int idx = (-(kc >> lgq) * p) & 255;
-      v2f* const exw = ex + t * kPlaneI + colw;
+      // twiddle W256^{(t - k_c) a - (k_c / q) p}: bins counted from the demodulation centre; the
+      // column's values go to exchange plane (t - k_c) mod 16, so that the second half reads its
+      // sixteen planes in order (index arithmetic in bytes: one add and one mask per twiddle)
+      const unsigned step8 = (unsigned)((t - kc) & 255) << 3;
+      unsigned idx8 = (unsigned)((-(kc >> lgq) * p) & 255) << 3;
+      v2f* const exw = ex + ((t - kc) & 15) * kPlaneI + colw;
+      const char* const twb = reinterpret_cast<const char*>(twl);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        exw[j * kColsI] = cmulv(v[dft16_pos(j)], twl[idx]);
-        idx = (idx + step) & 255;
+        exw[j * kColsI] = cmulv(v[dft16_pos(j)], *reinterpret_cast<const v2f*>(twb + idx8));
+        idx8 = (idx8 + step8) & 0x7f8u;
       }
     }
     __syncthreads();
@@ -245,9 +248,8 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
     }
     {
       v2f v[16];
-      const int rot = aux_lds[min(b0 + (zslot2 & (ns - 1)), n_scales - 1)] & 15;   // k_c mod 16
 #pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) v[k1] = ex[((k1 + rot) & 15) * kPlaneI + tid];
+      for (int k1 = 0; k1 < 16; ++k1) v[k1] = ex[k1 * kPlaneI + tid];
       __syncthreads();                      // every plane is read before z takes their place
       idft16v(v);
 #pragma unroll
