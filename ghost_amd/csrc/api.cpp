@@ -14,6 +14,7 @@
 #include "../../include/ghostcwt.h"
 #include "../../include/ghostcwt_debug.h"
 #include "host_out.h"
+#include "interp.h"
 #include "kernels.h"
 #include "morse_exact.h"
 #include "planner.h"
@@ -515,7 +516,13 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       // profiles/r03_synth_study.md; the 16 columns of a pass are blocks x scales x phases).
       int lgnb = lp.decimation <= 32 ? 1 : 0;
       if (const char* e = getenv("GHOSTCWT_INTERP_LGNB")) lgnb = std::min(std::max(atoi(e), 0), 2);   // (A/B runs; read at upload)
-      while ((lp.interp_q << lgnb) > 16) --lgnb;
+      while (lgnb > 0 && (lp.interp_q << lgnb) > kInterpMaxPhases) --lgnb;
+      // what k_synthi's indexing assumes (synthi.hip); the planner guarantees it
+      if (lp.interp_q < 4 || lp.interp_q > kInterpMaxPhases || (lp.interp_q & (lp.interp_q - 1)) ||
+          lp.interp_factor * lp.interp_q != lp.decimation || lp.interp_factor < 4 ||
+          lp.interp_factor > kInterpMaxFactor || lp.scales.size() > 256 || lp.halo < 16 ||
+          lp.hop != hp.block - 2 * lp.halo || lp.hop < 1 || hp.block != 256)
+        return bail(set_err(GCWT_ERR_INVALID, "internal: interpolated level outside the kernel's limits"));
       lvi[l] = {lp.decimation, lp.interp_q, lgq, lp.interp_factor, lp.hop, lp.halo, ep.lv[l].nblk,
                 (int32_t)lp.scales.size(), scale_off[l], ep.lv[l].blk_lo, lgnb, 0, lp.twiddle_offset,
                 ep.lv[l].xr_offset, ep.lv[l].m - 1, lp.coef_offset};

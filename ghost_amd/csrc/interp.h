@@ -21,6 +21,7 @@ namespace gcwt {
 
 constexpr int kInterpTaps = 8;       // T
 constexpr int kInterpMaxFactor = 256;   // I = R / q at most: a lane's coefficient set is lane & (I/4 - 1)
+constexpr int kInterpMaxPhases = 16;    // q at most: the columns of one pass of k_synthi (synthi.hip)
 
 inline double interp_sinc(double x) {   // sin(pi x) / (pi x)
   if (std::fabs(x) < 1e-12) return 1.0;

@@ -219,7 +219,8 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
   if (R < min_r || lp->scales.empty()) return;
   int q = 4;
   while (R / q > kInterpMaxFactor) q *= 2;
-  if (q > 32) return;                                      // 32 columns per workgroup: at most 32 phases
+  if (q > kInterpMaxPhases) return;                        // a pass of the kernel has 16 columns (R <= 4096)
+  if (lp->scales.size() > 256) return;                     // the kernel parks a level's scale list in LDS
   const int I = R / q;
   for (int sidx : lp->scales)
     if (hp->scales[sidx].n_bins > 4096) return;            // 'energy' members with very long kernels: the gain

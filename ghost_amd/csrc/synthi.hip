@@ -52,6 +52,7 @@ constexpr int kPlaneI = kThreadsI + 1;
 constexpr int kZPad = 4;                         // v2f entries between the slots of the z buffer: their
                                                  // writes fall on different banks
 constexpr int kSlotsMax = kColsI / 4;            // q >= 4
+static_assert(kInterpMaxPhases <= kColsI, "a scale's q phases are columns of one pass");
 constexpr int kZElems = 256 * kColsI + kSlotsMax * kZPad;     // z buffer
 constexpr int kExElems = kZElems > 16 * kPlaneI ? kZElems : 16 * kPlaneI;   // ... in place of the 16 exchange planes
 constexpr int kGainRowI = 16 * 20;
