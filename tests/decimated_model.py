@@ -10,6 +10,12 @@ convolution with the reference's L-tap kernel:
   full-band  y = IFFT_P(X * H_s(2 pi k/P))[0:N_e]
   direct     the literal kernel, time domain
 
+  interpolated (amplitude / power at R >= 16, csrc/synthi.hip): only q of the R phases go through
+             the block transform, z[q m + p] = IFFT_B(XB_b * G_s * exp(2 pi i (k - k_c)(q m + p)/(B q)))[m]
+             -- bins counted from the scale's demodulation bin k_c, real gain G_s -- and
+             |y[I m' + rho]| = |sum_j c_rho[j] z[m' + j - 3]|, I = R/q, with the planner's 8-tap
+             coefficient tables (tau = rho/I for odd kernel lengths, (rho - 1/2)/I for even ones)
+
 with H_s the exact response of the reference's kernel (``exact_gain`` below, the
 closed form csrc/morse_exact.h evaluates).  The decisions (method, R, halo, hop) are
 taken from the planner itself (``CwtPlan.scale_info``), so this model checks on the CPU,
@@ -105,5 +111,61 @@ def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=25
                 XB = fft(xr[idx])
                 blk = ifft((XB * H)[:, None] * tw, axis=0)        # [m, r]
                 y[R * b * hop: R * (b + 1) * hop] = blk[lh:lh + hop].reshape(-1)
+            out[i, start:stop] = y[lead:lead + ne]
+    return out
+
+
+def amplitude_interpolated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=256, plan=None):
+    """|W| (S, N) float64 the way the engine makes it for amplitude output: the levels the
+    planner designed an interpolator for (``plan.debug_interp()``) through q phases + the 8-tap
+    FIR with the planner's own float32 coefficients and demodulation bins, every other scale
+    as in ``cwt_decimated``.  Whole epochs only."""
+    from ghost_amd.engine import CwtPlan
+    x = np.asarray(x).squeeze().astype(np.float64)
+    n = x.size
+    if epoch_bounds is None:
+        epoch_bounds = np.array([[0, n]])
+    freqs_hz = np.atleast_1d(np.asarray(freqs_hz, dtype=np.float64))
+    if plan is None:
+        plan = CwtPlan(n, 1, fs, freqs_hz, gamma=gamma, beta=beta, epoch_bounds=epoch_bounds, output="amplitude")
+    out = np.abs(cwt_decimated(x, fs, freqs_hz, epoch_bounds, gamma, beta, B, plan=plan))
+    si, di, levels = plan.scale_info(), plan.debug_interp(), plan.debug_levels()
+    by_r = {lv["decimation"]: d for lv, d in zip(levels, di["levels"])}
+    omegas = orc.hz_to_rad(freqs_hz, fs)
+    xc = x - x.mean()
+    fft_len = {(a, b): p for (a, b, p) in plan.segments()}
+    T = 8
+    for start, stop in epoch_bounds:
+        ne = stop - start
+        p_big = fft_len[(start, stop)]
+        lead = start - (start & ~63)
+        X = fft(np.concatenate([np.zeros(lead), xc[start:stop]]), n=p_big)
+        for i, (om, L) in enumerate(zip(omegas, si["length"])):
+            R = int(si["decimation"][i])
+            d = by_r.get(R) if si["method"][i] == 0 else None
+            if d is None:
+                continue
+            q, I, lh, hop = d["q"], d["factor"], int(si["halo"][i]), int(si["hop"][i])
+            coef = d["coef"][1 if int(L) % 2 == 0 else 0].astype(np.float64)   # [I][8]
+            kc = int(di["demod"][i])
+            assert kc % q == 0
+            M = p_big // R
+            xr = ifft(X[:M]) / R
+            k = np.arange(B)
+            G = exact_gain(2 * np.pi * k / (B * R), om, int(L), gamma, beta)
+            tw = np.exp(2j * np.pi * np.outer(k, np.arange(q)) / (B * q))            # phase p of bin k
+            demod = np.exp(-2j * np.pi * kc * np.arange(B * q) / (B * q))           # bins counted from k_c
+            nblk = int(math.ceil(math.ceil((lead + ne) / R) / hop))
+            y = np.zeros(R * nblk * hop)
+            for b in range(nblk):
+                idx = (b * hop - lh + np.arange(B)) % M
+                XB = fft(xr[idx])
+                z = ifft((XB * G)[:, None] * tw, axis=0).reshape(-1) * demod        # z[q m + p]
+                m0 = lh * q
+                acc = np.zeros((hop * q, I), dtype=np.complex128)
+                for j in range(T):
+                    seg = z[m0 + j - (T // 2 - 1): m0 + j - (T // 2 - 1) + hop * q]
+                    acc += seg[:, None] * coef[None, :, j]
+                y[R * b * hop: R * (b + 1) * hop] = np.abs(acc.reshape(-1))
             out[i, start:stop] = y[lead:lead + ne]
     return out

@@ -725,24 +725,47 @@ def test_nelpy_round_trip_end_to_end(monkeypatch):
         output_numpy_or_asa(np.zeros(3), spectrogram, output_type="asa")
 
 
-def test_role_split_synthesis_kernel_matches(monkeypatch):
-    """k_synth8 (producer / consumer waves, kept selectable as a measured alternative) gives
-    the same numbers as the production kernel, every output mode, 16 and 32 columns."""
+def test_synthesis_kernels_agree(monkeypatch):
+    """The three ways a level can be synthesised -- the interpolating kernel (k_synthi: amplitude
+    and power at R >= 16), k_synth7 (GHOSTCWT_INTERP=0 sends every level there) and the 16-column
+    fallback (GHOSTCWT_SYNTH16=1) -- give the same rows, both epochs of a recording whose gap and
+    ends fall on no multiple of 4 samples (the interpolating kernel stores 16 bytes at a time and
+    switches to single samples where a window edge runs through them).  In the measure build
+    (GHOSTCWT_LIB=libghostcwt_measure.so) k_synth8 is compared as well."""
+    from ghost_amd._lib import lib
     from ghost_amd.synthetic import lfp
     fs = 1000.0
-    x = lfp(2, 40000, fs)
+    x = lfp(2, 40001, fs)
     f = np.geomspace(180.0, 3.0, 37)
-    eb = [[0, 15000], [15003, 40000]]
-    for output in ("amplitude", "power", "complex"):
-        monkeypatch.delenv("GHOSTCWT_SYNTH_KERNEL", raising=False)
-        p7, ref = _plan(x, fs, f, output=output, epoch_bounds=eb)
-        for cols in ("32", "16"):
-            monkeypatch.setenv("GHOSTCWT_SYNTH_KERNEL", "8")
-            monkeypatch.setenv("GHOSTCWT_SYNTH_COLS", cols)
-            p8, got = _plan(x, fs, f, output=output, epoch_bounds=eb)
-            scale = np.abs(ref).max(axis=-1, keepdims=True)
-            assert (np.abs(got - ref) / scale).max() < 2e-6, (output, cols)
-        monkeypatch.delenv("GHOSTCWT_SYNTH_COLS")
+    eb = [[0, 15001], [15006, 40001]]
+    for output in ("amplitude", "power"):
+        for var in ("GHOSTCWT_INTERP", "GHOSTCWT_SYNTH16", "GHOSTCWT_SYNTH_KERNEL", "GHOSTCWT_SYNTH_COLS"):
+            monkeypatch.delenv(var, raising=False)
+        p, prod = _plan(x, fs, f, output=output, epoch_bounds=eb)
+        assert p.info["n_interp"] > 0 and any(d is not None for d in p.debug_interp()["levels"])
+        scale = np.abs(prod).max(axis=-1, keepdims=True)
+        monkeypatch.setenv("GHOSTCWT_INTERP", "0")
+        p7, ref7 = _plan(x, fs, f, output=output, epoch_bounds=eb)
+        assert p7.info["n_interp"] == 0
+        assert (np.abs(prod - ref7) / scale).max() < 2e-6, output
+        monkeypatch.setenv("GHOSTCWT_SYNTH16", "1")
+        _, ref16 = _plan(x, fs, f, output=output, epoch_bounds=eb)
+        assert (np.abs(prod - ref16) / scale).max() < 2e-6, output
+        monkeypatch.delenv("GHOSTCWT_SYNTH16")
+        if lib.gcwt_debug_measure_build():
+            for cols in ("32", "16"):
+                monkeypatch.setenv("GHOSTCWT_SYNTH_KERNEL", "8")
+                monkeypatch.setenv("GHOSTCWT_SYNTH_COLS", cols)
+                _, got = _plan(x, fs, f, output=output, epoch_bounds=eb)
+                assert (np.abs(got - ref7) / scale).max() < 2e-6, (output, cols)
+            monkeypatch.delenv("GHOSTCWT_SYNTH_KERNEL")
+            monkeypatch.delenv("GHOSTCWT_SYNTH_COLS")
+        # zeros outside the epochs survive (transforms.py:185)
+        assert not prod[:, :, 15001:15006].any()
+    monkeypatch.delenv("GHOSTCWT_INTERP")
+    # complex coefficients are never interpolated (the demodulation would have to be undone)
+    pc, _ = _plan(x, fs, f, output="complex", epoch_bounds=eb)
+    assert pc.info["n_interp"] == 0
 
 
 def test_config5_regime_streamed_multichannel():

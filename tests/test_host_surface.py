@@ -285,6 +285,38 @@ def test_decimated_model_matches_oracle(golden):
     assert rel_err(c[:, g["cols"]], g["complex_cols"][::6]).max() < 5e-7
 
 
+def test_interpolated_levels_model_matches_oracle(golden):
+    """Amplitude rows of the levels the planner hands to the interpolating synthesis
+    (csrc/synthi.hip): q phases of the block transform, demodulated to each scale's band centre,
+    then the planner's own 8-tap interpolators -- in float64 NumPy against the goldens.  Also
+    what the planner promises about the design: a bound below 1.5e-7, demodulation bins that are
+    multiples of q, interpolators that reproduce a constant."""
+    from decimated_model import amplitude_interpolated
+    from conftest import rel_err
+    from ghost_amd.engine import CwtPlan
+    g = golden("g1_config1.npz")
+    x, f = g["x"], g["frequencies"]
+    plan = CwtPlan(x.size, 1, 1000.0, f, output="amplitude")
+    di = plan.debug_interp()
+    designed = [(lv, d) for lv, d in zip(plan.debug_levels(), di["levels"]) if d is not None]
+    assert designed and all(lv["decimation"] >= 16 for lv, _ in designed)
+    assert plan.info["n_interp"] == sum((plan.scale_info()["decimation"] == lv["decimation"]).sum() for lv, _ in designed)
+    for lv, d in designed:
+        assert d["q"] * d["factor"] == lv["decimation"] and d["q"] in (4, 8, 16)
+        assert 0 < d["err_bound"] <= 1.5e-7 and 0 < d["alpha"] < 0.45
+        assert d["coef"].shape == (2, d["factor"], 8)
+        np.testing.assert_allclose(d["coef"].sum(axis=2), 1.0, atol=2e-6)      # DC passes unchanged
+    demod = di["demod"][np.isin(plan.scale_info()["decimation"], [lv["decimation"] for lv, _ in designed])]
+    assert (demod % 4 == 0).all() and (demod > 0).all() and (demod < 256).all()
+    a = amplitude_interpolated(x, 1000.0, f, plan=plan)
+    assert rel_err(a[:, g["cols"]], g["amplitude_cols"]).max() < 5e-7
+    # complex output is never interpolated; GHOSTCWT_INTERP=0 switches the design off (A/B runs)
+    assert CwtPlan(x.size, 1, 1000.0, f, output="complex").info["n_interp"] == 0
+    g = golden("g5_two_epochs.npz")
+    a = amplitude_interpolated(g["x"], float(g["fs"]), g["frequencies"][::4], g["epoch_bounds"])
+    assert rel_err(a[:, g["cols"]], np.abs(g["complex_cols"][::4])).max() < 5e-7
+
+
 GB_PAIRS = [(3, 8), (3, 4), (3, 2), (2, 8), (4, 30), (1, 5)]
 
 
