@@ -61,7 +61,11 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, deadline_s=3600.0):
+    """Starts the n ranks, relays rank 0's result line.  Rank 0's pipe is drained by a reader
+    thread and every rank is polled in one loop under one deadline: the first rank that exits
+    non-zero (or the deadline) ends the others, and the launcher exits non-zero."""
+    import threading
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
     for r in range(n):
@@ -71,22 +75,32 @@ def launch_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr,
                                       stderr=sys.stderr))
-    line = procs[0].stdout.read().decode()
-    codes = []
-    deadline = time.time() + 3600
-    for p in procs:
-        try:
-            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            codes.append(-9)
-    if any(codes):
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-        sys.stderr.write("bench.py: ranks exited with %s\n" % codes)
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + deadline_s
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = "rank %d exited with %d" % (r, codes[r])
+        if failed is None and time.time() > deadline:
+            failed = "no result after %.0f s" % deadline_s
+        if failed is not None:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.kill()
+                    codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(5.0)
+    if failed is not None:
+        sys.stderr.write("bench.py: %s; ranks ended with %s\n" % (failed, codes))
         return 1
-    _RESULT.write(line)
+    _RESULT.write(b"".join(chunks).decode())
     _RESULT.flush()
     return 0
 
@@ -94,29 +108,118 @@ def launch_ranks(n, argv):
 # ----------------------------------------------------------------------------
 # checkers (rank 0, N = 1, outside the timed region): the oracle is test infrastructure
 # ----------------------------------------------------------------------------
-def cpu_baseline(fs, n_samples, freqs, budget_s=25.0):
-    """The oracle's literal path (port of transforms.py:187-224 + convolution.py:16-87)
-    on this box's cores: config 2 shape, ThreadPool over scales like parallel=True."""
+def cpu_baseline(fs, freqs, budget_s=25.0):
+    """The oracle's literal path (port of transforms.py:187-224 + convolution.py:16-87) on this
+    box's cores, the legs BASELINE.md plans: config 2's shape (1 ch x 1e6 samples, the bench's
+    scales) with ThreadPool over scales like ``parallel=True`` (transforms.py:206-218) -- the
+    headline `value` -- and serially (:219-224), plus config 1's shape (1 ch x 16 384 samples,
+    32 scales 200..5.57 Hz) serially.  About 25 s of CPU work in all."""
     from oracle import ghost_oracle as orc
     from ghost_amd.synthetic import lfp_channel
     affinity = len(os.sched_getaffinity(0))
     cores = min(affinity, 16)                       # a 1-GPU box's CPU share is 16 cores
-    x = lfp_channel(n_samples, fs, 0).astype(np.float64)
-    best, reps = None, 0
-    t_start = time.time()
-    while reps < 3 or (time.time() - t_start < 10.0 and reps < 60):   # ~10 s of CPU work
-        t0 = time.time()
-        orc.cwt_amplitude(x, fs, freqs, n_threads=cores)
-        dt = time.time() - t0
-        best = dt if best is None else min(best, dt)
-        reps += 1
-        if time.time() - t_start > budget_s:
-            break
-    return {"value": round(n_samples / best / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+
+    def leg(n, f, threads, min_reps, max_s):
+        x = lfp_channel(n, fs, 0).astype(np.float64)
+        best, reps, t_start = None, 0, time.time()
+        while reps < min_reps or (time.time() - t_start < max_s and reps < 60):
+            t0 = time.time()
+            orc.cwt_amplitude(x, fs, f, n_threads=threads)
+            dt = time.time() - t0
+            best = dt if best is None else min(best, dt)
+            reps += 1
+            if time.time() - t_start > max_s:
+                break
+        return {"value": round(n / best / 1e6, 4), "unit": "Msamples/s", "threads": threads,
+                "shape": "1 ch x %d samples x %d scales" % (n, len(f)), "best_s": round(best, 3), "runs": reps}
+
+    f1 = 200.0 / 2.0 ** (np.arange(32) / 6.0)          # config 1: 32 scales, 6 voices per octave
+    pool = leg(1000000, freqs, cores, 2, budget_s * 0.4)
+    serial = leg(1000000, freqs, 1, 1, budget_s * 0.45)
+    m1 = leg(16384, f1, 1, 3, budget_s * 0.1)
+    return {"value": pool["value"], "unit": "Msamples/s", "cores": cores,
             "os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "kind": "port",
-            "sample": "1 ch x %d samples x %d scales (config 2 of the same fs and scales), float64, "
-                      "scipy.fft overlap-add, ThreadPool(%d) over scales, best of %d runs "
-                      "(%.2f s each)" % (n_samples, len(freqs), cores, reps, best)}
+            "sample": "1 ch x 1000000 samples x %d scales (config 2 of the same fs and scales), float64, "
+                      "scipy.fft overlap-add, ThreadPool(%d) over scales, best of %d runs (%.2f s each)"
+                      % (len(freqs), cores, pool["runs"], pool["best_s"]),
+            "legs": {"config2_threadpool": pool, "config2_serial": serial, "config1_serial": m1}}
+
+
+def oracle_rows_window(x_full, fs, freqs, a, b):
+    """|W| of samples [a, b) of one channel at a few scales, from the oracle's own pieces
+    (transforms.py:142-143 global mean, morse.py:108-122 lengths, morseutils.py:93-198 kernel,
+    convolution.py:16-87 overlap-add) on a window of the recording: every output needs the
+    input within (L-1)/2 of it, so [a - L, b + L) gives the same numbers as the whole array."""
+    from oracle import ghost_oracle as orc
+    xc = np.asarray(x_full, dtype=np.float64)
+    xc = xc - xc.mean()
+    n = xc.size
+    om = orc.hz_to_rad(freqs, fs)
+    out = []
+    for w, L in zip(om, orc.morse_lengths(om)):
+        psi, _ = orc.morse_kernel(int(L), w)
+        w0, w1 = max(0, a - int(L)), min(n, b + int(L))
+        y = orc.overlap_add_convolve(xc[w0:w1], psi)
+        out.append(np.abs(y[a - w0:b - w0]))
+    return np.array(out)
+
+
+class PowerSampler:
+    """Package power and shader clock of the busiest AMD GPU while the timed steps run: a side
+    thread that only reads sysfs (hwmon power1_average / power1_input, freq1_input; no HIP call,
+    no subprocess of a GPU tool)."""
+
+    def __init__(self, period=0.02):
+        import glob
+        self.period, self.rows, self._stop, self._th = period, [], False, None
+        self.cards = []
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pw = [f for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))]
+            if pw:
+                self.cards.append({"hw": hw, "power": os.path.join(hw, pw[0]),
+                                   "sclk": os.path.join(hw, "freq1_input"),
+                                   "cap": os.path.join(hw, "power1_cap")})
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop:
+            self.rows.append([(self._read(c["power"]), self._read(c["sclk"])) for c in self.cards])
+            time.sleep(self.period)
+
+    def start(self):
+        if self.cards:
+            import threading
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th:
+            self._th.join(1.0)
+        if not self.rows:
+            return None
+        best = None
+        for i, c in enumerate(self.cards):
+            pw = [r[i][0] for r in self.rows if r[i][0] is not None]
+            ck = [r[i][1] for r in self.rows if r[i][1] is not None]
+            if not pw:
+                continue
+            mean_w = sum(pw) / len(pw) / 1e6
+            if best is None or mean_w > best["power_w"]:
+                cap = self._read(c["cap"])
+                best = {"power_w": round(mean_w, 1), "power_w_max": round(max(pw) / 1e6, 1),
+                        "power_cap_w": round(cap / 1e6, 1) if cap else None,
+                        "sclk_ghz": round(sum(ck) / len(ck) / 1e9, 3) if ck else None,
+                        "sclk_ghz_min": round(min(ck) / 1e9, 3) if ck else None,
+                        "samples": len(pw), "source": c["hw"]}
+        return best
 
 
 def spot_check(obuf, base, fs, freqs, C, N, distinct, output="amplitude"):
@@ -162,6 +265,11 @@ def run_rank(args):
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if args.dry_run:                                # launcher rehearsal: no HIP call at all
+        fail = os.environ.get("GHOSTCWT_BENCH_FAIL_RANK")   # (tests: one rank dies, the others would wait)
+        if fail is not None:
+            if int(fail) == rank:
+                return 3
+            time.sleep(120)
         path = os.path.join(args.dry_run, "rank%d.json" % rank)
         json.dump({"rank": rank, "local_rank": local, "world": world,
                    "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))},
@@ -245,21 +353,29 @@ def run_rank(args):
     for _ in range(args.warmup):
         step({})
     check(lib.gcwt_device_synchronize())
+    sampler = PowerSampler() if rank == 0 else None
     comm.barrier()
     stats = {}
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(stats)
     check(lib.gcwt_device_synchronize())
+    own = time.perf_counter() - t0                   # this rank's own K steps, before it waits for the others
     comm.barrier()
     elapsed = time.perf_counter() - t0
+    power = sampler.stop() if sampler else None
     elapsed = comm.allreduce_max(elapsed)
+    per_rank = comm.allgather(own / args.steps * 1e3)
+    devices = comm.allgather(dev)
 
     if rank == 0:
         units = world * C * N * args.steps
         value = units / elapsed / 1e6
         launches = max(1, stats["synth_launches"])
         k_ms = stats["synth_ms"] / launches
+        ki_ms = stats.get("interp_ms", 0.0) / launches
         alg_step = C * N * (4 + S * b_out)           # per channel-sample 4 + S*b_out
         alg_launch = alg_step * args.steps / launches
         achieved = alg_launch / (k_ms * 1e-3) / 1e9
@@ -290,33 +406,73 @@ def run_rank(args):
                        "plan_create_ms": round(plan_ms, 2),
                        "scales": {"spectral": info["n_spectral"], "direct": info["n_direct"],
                                   "fullband": info["n_fullband"]}},
-            "roofline": {"bound": "hbm", "kernel": "k_synth7", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm",
+                         "kernel": "synthesis: k_synthi (%d interpolated scales, R >= 16) + k_synth7 (%d scales), "
+                                   "one launch each per step, back to back" % (info["n_interp"], info["n_spectral"] - info["n_interp"])
+                                   if info["n_interp"] else "k_synth7",
+                         "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": round(k_ms, 4), "launches_per_step": launches // args.steps,
-                         "algorithmic_bytes": int(alg_launch), **ceilings,
-                         "limited_by": "package power (sclk held below 2 GHz with the HBM writes on: "
-                                       "DESIGN.md 5)"},
+                         "algorithmic_bytes": int(alg_launch), **ceilings},
             "stages_ms": {k: round(float(v) / args.steps, 4) for k, v in stats.items() if k.endswith("_ms")},
             "whole_job_frac_of_hbm_peak": round(alg_step * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
         }
+        rl = line["roofline"]
+        if info["n_interp"]:
+            # the two synthesis kernels apart: rows x samples x 4 B each wrote, over its own launch time
+            b_i = C * N * info["n_interp"] * b_out
+            b_7 = C * N * (S - info["n_interp"]) * b_out
+            k7_ms = max(1e-9, k_ms - ki_ms)
+            rl["kernels"] = {
+                "k_synthi": {"ms": round(ki_ms, 4), "scales": info["n_interp"],
+                             "achieved": round(b_i / (ki_ms * 1e-3) / 1e9, 1) if ki_ms > 0 else None},
+                "k_synth7": {"ms": round(k7_ms, 4), "scales": S - info["n_interp"],
+                             "achieved": round(b_7 / (k7_ms * 1e-3) / 1e9, 1)}}
+        if power:
+            # measured in this run (sysfs, 20 ms period, the timed steps only)
+            rl["power_w"], rl["sclk_ghz"] = power["power_w"], power["sclk_ghz"]
+            rl["power_detail"] = power
+            cap = power.get("power_cap_w")
+            near_cap = cap is not None and power["power_w_max"] >= 0.9 * cap
+            at_store = bool(ceilings) and achieved >= 0.9 * ceilings["store_pattern_ceiling"]
+            rl["limited_by"] = ("hbm stores (within 10 % of this box's store-pattern ceiling)" if at_store else
+                                "package power (peak %.0f W of the %.0f W cap, mean sclk %.2f GHz)"
+                                % (power["power_w_max"], cap, power["sclk_ghz"] or 0.0) if near_cap else
+                                "instruction issue / latency (neither the power cap nor the store ceiling is reached)")
+        else:
+            rl["power_w"] = rl["sclk_ghz"] = rl["limited_by"] = None   # no readable hwmon: not asserted
         if not cfg5:
-            # SURVEY.md 8d's secondary ceiling: fp32 vector flops, counted NOMINALLY -- one real
-            # forward FFT of P points per channel, one P-point inverse FFT + multiply + magnitude
-            # per (channel, scale) -- which is what the reference's method would execute; the
-            # engine's decimated synthesis executes about 0.4 of that.
+            # SURVEY.md 8d's secondary ceiling, fp32 vector flops.  `reference_method_*`: what the
+            # reference's method implies -- one real P-point FFT per channel, one P-point inverse
+            # FFT + multiply + magnitude per (channel, scale); NOT what this engine executes.
+            # `executed_*`: the engine's own arithmetic, counted from its kernels:
+            # 46 flops per stored sample on the FFT-per-sample levels, 2 x 8 x 2 + 3 = 35 on the
+            # interpolated ones plus their q / R share of the transform.
             P = float(info["fft_length"])
             nominal = C * (2.5 * P * np.log2(P) + S * (5.0 * P * np.log2(P) + 3.0 * P + 4.0 * N))
-            line["roofline"]["fp32_vector"] = {
-                "nominal_flops_per_step": float("%.4g" % nominal),
-                "nominal_tflops": round(nominal * args.steps / elapsed / 1e12, 1),
+            executed = C * N * ((S - info["n_interp"]) * 46.0 + info["n_interp"] * (35.0 + 46.0 * 0.1))
+            rl["fp32_vector"] = {
                 "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
-                "nominal_frac": round(nominal * args.steps / elapsed / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)}
+                "executed_flops_per_step": float("%.4g" % executed),
+                "executed_tflops": round(executed * args.steps / elapsed / 1e12, 1),
+                "executed_frac": round(executed * args.steps / elapsed / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
+                "reference_method_flops_per_step": float("%.4g" % nominal),
+                "reference_method_tflops": round(nominal * args.steps / elapsed / 1e12, 1)}
         if ceilings:
             line["roofline"]["frac_of_store_pattern_ceiling"] = round(
                 achieved / ceilings["store_pattern_ceiling"], 4)
         if comm.rccl_error:
             line["config"]["rccl_error"] = comm.rccl_error[:200]
+        if world > 1:
+            # where the skew is: every rank's own ms per step (before the closing barrier) and device
+            slow = int(np.argmax(per_rank))
+            line["ranks"] = {"ms_per_step": [round(v, 4) for v in per_rank],
+                             "min": round(min(per_rank), 4), "max": round(max(per_rank), 4), "rank_of_max": slow,
+                             "devices": [int(d) for d in devices]}
+        if cfg5 and not args.no_check:
+            line["checked"], line["check"] = check_config5(plan, xbuf, ring[0], base, distinct, fs, freqs, N, S,
+                                                           group, segs)
         if not cfg5 and not args.no_check:
             ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=args.output)
             line["checked"] = ok
@@ -329,39 +485,67 @@ def run_rank(args):
             obuf.free()
             plan.close()
             line["other_modes"] = {"complex": other_mode("complex", N, C, fs, freqs, S, xbuf, dev, lib, check,
+                                                         steps=args.steps, warmup=args.warmup,
                                                          check_against=None if args.no_check else (base, distinct))}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(fs, 1000000, freqs)
+            line["cpu_baseline"] = cpu_baseline(fs, freqs)
         emit(line)
     comm.close()
     return 0
 
 
-def other_mode(output, N, C, fs, freqs, S, xbuf, dev, lib, check, steps=5, check_against=None):
-    """ms per step and whole-job fraction of the HBM peak for another output mode of the same
-    workload (device-resident, plan prebuilt, `steps` timed executions after two warm-ups)."""
+def check_config5(plan, xbuf, ring_buf, base, distinct, fs, freqs, N, S, group, segs):
+    """After the timed steps of --config 5: one (channel group, time block) is computed again
+    into a ring buffer and rows channels {0, group-1} x scales {0, S/2, S-1 = 1 Hz} are compared
+    with the oracle over that block's window (transforms.py:529-597 is the streaming design,
+    :187-204 the numbers).  The block in the middle of the recording: both its edges are seams."""
+    import ctypes
+    i_mid = len(segs) // 2
+    a, b, _ = segs[i_mid]
+    xg = ctypes.c_void_p(xbuf.ptr.value)              # channel group 0
+    plan.execute_block_device(xg, ring_buf, a, b - a, reuse_means=False)
+    scales = sorted({0, S // 2, S - 1})
+    worst = 0.0
+    for c in sorted({0, group - 1}):
+        ref = oracle_rows_window(base[c % distinct], fs, freqs[scales], a, b)
+        for i, sc in enumerate(scales):
+            row = ring_buf.download((b - a,), np.float32, offset_bytes=4 * (c * S + sc) * (b - a))
+            worst = max(worst, float(np.abs(row - ref[i]).max() / np.abs(ref[i]).max()))
+    return bool(worst <= 1e-5), {
+        "rows": "time block %d of %d (samples %d..%d), channels {0, %d} x scales {0, %d, %d} vs the oracle"
+                % (i_mid, len(segs), a, b, group - 1, S // 2, S - 1),
+        "worst_rel_err": float("%.3g" % worst)}
+
+
+def other_mode(output, N, C, fs, freqs, S, xbuf, dev, lib, check, steps=10, warmup=2, check_against=None):
+    """The same workload with another output mode (device-resident, plan prebuilt): `warmup`
+    untimed executions -- the fresh result buffer's pages are touched for the first time there --
+    then `steps` executions timed one by one: minimum and median."""
     from ghost_amd.engine import CwtPlan, DeviceBuffer
     plan = CwtPlan(N, C, fs, freqs, output=output, device=dev)
     plan.upload()
     plan.set_profiling(True)
     obuf = DeviceBuffer(plan.info["out_bytes"])
-    for _ in range(2):                               # warm-up: the result pages are touched for the first time
+    for _ in range(warmup):
         plan.execute_device(xbuf, obuf)
     check(lib.gcwt_device_synchronize())
-    synth = 0.0
-    t0 = time.perf_counter()
+    synth, wall = [], []
     for _ in range(steps):
-        plan.execute_device(xbuf, obuf)
-        synth += plan.timings()["synth_ms"]
-    check(lib.gcwt_device_synchronize())
-    el = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        plan.execute_device(xbuf, obuf)               # returns after the stream has drained
+        wall.append(time.perf_counter() - t0)
+        synth.append(plan.timings()["synth_ms"])
     b_out = 8 if output == "complex" else 4
     alg = C * N * (4 + S * b_out)
-    res = {"ms_per_step": round(el * 1e3, 4), "value": round(C * N / el / 1e6, 2), "unit": "Msamples/s",
-           "steps": steps, "algorithmic_bytes": int(alg),
+    el, el_min = float(np.median(wall)), min(wall)
+    k_med, k_min = float(np.median(synth)), min(synth)
+    res = {"ms_per_step": round(el * 1e3, 4), "ms_per_step_min": round(el_min * 1e3, 4),
+           "value": round(C * N / el / 1e6, 2), "value_best": round(C * N / el_min / 1e6, 2), "unit": "Msamples/s",
+           "steps": steps, "warmup": warmup, "statistic": "median of the timed steps (and the best one)",
+           "algorithmic_bytes": int(alg),
            "whole_job_frac_of_hbm_peak": round(alg / el / 1e9 / HBM_PEAK_GBS, 4),
-           "kernel_ms": round(synth / steps, 4),
-           "kernel_frac_of_hbm_peak": round(alg / (synth / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+           "kernel_ms": round(k_med, 4), "kernel_ms_min": round(k_min, 4),
+           "kernel_frac_of_hbm_peak": round(alg / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if check_against is not None:
         base, distinct = check_against
         ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=output)

@@ -89,6 +89,7 @@ def _load():
         "gcwt_comm_unique_id": (C.c_int, [vp]),
         "gcwt_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp]),
         "gcwt_comm_destroy": (None, [vp]),
+        "gcwt_comm_abort": (None, [vp]),
         "gcwt_comm_barrier": (C.c_int, [vp]),
         "gcwt_comm_allreduce_max": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "gcwt_comm_broadcast_bank": (C.c_int, [vp, vp, C.c_int]),

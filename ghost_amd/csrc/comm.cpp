@@ -34,6 +34,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -56,6 +57,7 @@ Rccl& rccl() {
   LOAD(GetUniqueId, "ncclGetUniqueId");
   LOAD(CommInitRank, "ncclCommInitRank");
   LOAD(CommDestroy, "ncclCommDestroy");
+  LOAD(CommAbort, "ncclCommAbort");
   LOAD(Broadcast, "ncclBroadcast");
   LOAD(AllReduce, "ncclAllReduce");
   LOAD(GetErrorString, "ncclGetErrorString");
@@ -136,6 +138,19 @@ void gcwt_comm_destroy(gcwt_comm* c) {
   if (c->d_val) (void)hipFree(c->d_val);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->comm) rccl().CommDestroy(c->comm);
+  delete c;
+}
+
+// After a failed collective: a peer may never arrive, so nothing here may wait on the
+// communicator's stream -- ncclCommAbort tears the communicator down without completing what
+// is in flight; the stream and the 8-byte scratch are left to process exit (hipFree and
+// hipStreamDestroy synchronise).
+void gcwt_comm_abort(gcwt_comm* c) {
+  if (!c) return;
+  if (c->comm) {
+    if (rccl().CommAbort) rccl().CommAbort(c->comm);
+    // (no ncclCommAbort in this librccl: leak the communicator rather than block in its destructor)
+  }
   delete c;
 }
 

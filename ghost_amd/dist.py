@@ -149,10 +149,13 @@ class Comm:
             self.rccl_error = "%s: %s" % (type(e).__name__, e)
             self._handle = None
 
-    def _drop_rccl(self):
+    def _drop_rccl(self, abort=False):
+        """destroy: every operation on the communicator has completed (set-up disagreement,
+        close).  abort: a collective failed -- a peer may never arrive, so nothing may wait on
+        what is in flight (ncclCommAbort, no stream sync, no hipFree)."""
         from ._lib import lib
-        lib.gcwt_comm_destroy(self._handle)
-        self._handle = None
+        h, self._handle = self._handle, None
+        (lib.gcwt_comm_abort if abort else lib.gcwt_comm_destroy)(h)
 
     # -- file backend ---------------------------------------------------------
     def _file_allreduce_max(self, value, tag, negate=False):
@@ -164,15 +167,24 @@ class Comm:
 
     # -- interface ------------------------------------------------------------
     def _rccl_failed(self, what, err):
-        """An RCCL call failed after set-up: note it, drop the communicator and let the caller
-        serve the operation from the file backend (a failure every rank sees -- the common kind --
-        leaves them all in step; ``backend`` then reads 'file' and ``rccl_error`` says why)."""
+        """An RCCL call failed after set-up.  Only an error raised when the collective is
+        ENQUEUED (GCWT_ERR_COMM: bad communicator, library state) is the same on every rank, so
+        only then is the operation served from the file backend instead -- with a short
+        time-out, so that a rank whose peers did not fail exits instead of waiting.  A
+        collective that was enqueued and did not complete means a peer is gone: the
+        communicator is aborted (never destroyed: that would wait for the peer) and the error
+        goes to the caller, whose process ends non-zero so that the launcher stops the rest."""
+        from ._lib import ERR_COMM
         self.rccl_error = "%s: %s" % (what, err)
+        symmetric = getattr(err, "code", None) == ERR_COMM
         try:
-            self._drop_rccl()
+            self._drop_rccl(abort=True)
         except Exception:
             self._handle = None
         self.backend = "file"
+        self.timeout = min(self.timeout, 20.0)
+        if not symmetric:
+            raise RuntimeError("RCCL %s did not complete (%s): a peer rank is gone" % (what, err))
 
     def barrier(self):
         if self.world == 1:
@@ -198,6 +210,14 @@ class Comm:
             except Exception as e:
                 self._rccl_failed("allreduce_max", e)
         return self._file_allreduce_max(value, "max")
+
+    def allgather(self, value):
+        """[value of rank 0, ..., value of rank world-1] on every rank (world max-reduces: the
+        control plane has no other collective and needs none)."""
+        if self.world == 1:
+            return [float(value)]
+        return [self.allreduce_max(float(value) if r == self.rank else float("-inf"))
+                for r in range(self.world)]
 
     def broadcast_bank(self, plan, root=0):
         """RCCL broadcast of rank ``root``'s filter bank into every rank's plan.

@@ -251,6 +251,10 @@ typedef struct gcwt_comm gcwt_comm;
 int gcwt_comm_unique_id(void* id128);
 int gcwt_comm_create(gcwt_comm** out, int rank, int n_ranks, const void* id128);
 void gcwt_comm_destroy(gcwt_comm* comm);
+/* Tears a communicator down after a failed collective without waiting for anything in flight
+ * (ncclCommAbort; its stream and scratch are left to process exit).  gcwt_comm_destroy is for
+ * communicators whose operations have all completed. */
+void gcwt_comm_abort(gcwt_comm* comm);
 int gcwt_comm_barrier(gcwt_comm* comm);
 int gcwt_comm_allreduce_max(gcwt_comm* comm, double* value);
 int gcwt_comm_broadcast_bank(gcwt_comm* comm, gcwt_plan* plan, int root);

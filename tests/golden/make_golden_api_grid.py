@@ -18,6 +18,9 @@ import numpy as np
 
 logging.disable(logging.WARNING)
 
+import ghost as _ref_pkg                                          # refuses the alias package at this repo's root:
+assert os.path.realpath(_ref_pkg.__file__).startswith("/root/reference/"), \
+    "fixtures must come from the reference: put /root/reference FIRST on PYTHONPATH"
 from ghost.wave import ContinuousWaveletTransform                 # reference
 
 from ghost_amd.synthetic import lfp_channel                       # this repo

@@ -20,6 +20,9 @@ import numpy as np
 
 logging.disable(logging.WARNING)
 
+import ghost as _ref_pkg                                          # refuses the alias package at this repo's root:
+assert os.path.realpath(_ref_pkg.__file__).startswith("/root/reference/"), \
+    "fixtures must come from the reference: put /root/reference FIRST on PYTHONPATH"
 from ghost.wave import Morse                                      # reference
 from ghost.wave.morseutils import morsewave                       # reference
 from ghost.sigtools import fastconv_scipy                         # reference

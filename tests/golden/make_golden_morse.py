@@ -14,6 +14,9 @@ import numpy as np
 
 warnings.simplefilter("ignore")
 
+import ghost as _ref_pkg                                          # refuses the alias package at this repo's root:
+assert os.path.realpath(_ref_pkg.__file__).startswith("/root/reference/"), \
+    "fixtures must come from the reference: put /root/reference FIRST on PYTHONPATH"
 from ghost.wave import Morse, Morlet            # reference
 from ghost.wave import morseutils as mu         # reference
 

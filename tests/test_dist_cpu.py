@@ -130,26 +130,52 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert res.returncode != 0 and b"WORLD_SIZE=2 but --gpus 4" in res.stderr
 
 
-def test_rccl_failure_after_setup_falls_back_to_files(tmp_path, monkeypatch):
-    """An RCCL call that fails after the communicator was set up must not take the run down:
-    the operation is served by the file backend, the communicator is dropped and the reason is
-    kept (bench.py prints it as config.rccl_error)."""
+def test_a_failing_rank_stops_the_launcher(tmp_path):
+    """One rank dies while the others would still wait (an RCCL collective whose peer is gone
+    looks like this): the launcher must end the remaining ranks and exit non-zero, promptly --
+    not block reading rank 0's pipe.  Either rank 0 or another rank may be the one that dies."""
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dead in ("0", "2"):
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+        env["GHOSTCWT_BENCH_FAIL_RANK"] = dead
+        t0 = time.time()
+        res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3",
+                              "--dry-run", str(tmp_path)], env=env, capture_output=True, timeout=100)
+        assert res.returncode != 0
+        assert time.time() - t0 < 60, "the launcher waited for ranks that would never finish"
+        assert ("rank %s exited with 3" % dead).encode() in res.stderr
+        assert res.stdout.strip() == b""
+
+
+def test_rccl_failure_after_setup(tmp_path, monkeypatch):
+    """An RCCL call that fails when it is ENQUEUED (GCWT_ERR_COMM: every rank sees it) must not
+    take the run down: the operation is served by the file backend, the communicator is aborted
+    -- never destroyed, which would wait for work in flight -- and the reason is kept (bench.py
+    prints it as config.rccl_error).  A collective that was enqueued and did not complete
+    (GCWT_ERR_HIP) means a peer is gone: the communicator is aborted and the error is raised,
+    so that the rank exits non-zero and the launcher stops the others."""
     import threading
     import ghost_amd._lib as _lib
     from ghost_amd.dist import Comm
 
     class Broken:                       # stands in for libghostcwt's RCCL entry points
-        destroyed = 0
+        destroyed = aborted = 0
+        code = _lib.ERR_COMM
 
         def gcwt_comm_barrier(self, h):
-            return -7
+            return Broken.code
 
         def gcwt_comm_allreduce_max(self, h, v):
-            return -7
+            return Broken.code
 
         def gcwt_comm_destroy(self, h):
             Broken.destroyed += 1
-            return 0
+
+        def gcwt_comm_abort(self, h):
+            Broken.aborted += 1
 
         def gcwt_last_error(self):
             return b"ncclAllReduce: unhandled system error"
@@ -161,7 +187,7 @@ def test_rccl_failure_after_setup_falls_back_to_files(tmp_path, monkeypatch):
         c = Comm(r, 2, use_rccl=False, session=str(tmp_path), timeout=20.0)
         c._handle, c.backend = object(), "rccl"          # as if set-up had succeeded
         c.barrier()
-        out[r] = (c.allreduce_max(10.0 + r), c.backend, c.rccl_error, c._handle)
+        out[r] = (c.allreduce_max(10.0 + r), c.backend, c.rccl_error, c._handle, c.allgather(float(r)))
 
     ts = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
     for t in ts:
@@ -169,7 +195,15 @@ def test_rccl_failure_after_setup_falls_back_to_files(tmp_path, monkeypatch):
     for t in ts:
         t.join(30)
     for r in range(2):
-        value, backend, err, handle = out[r]
-        assert value == 11.0 and backend == "file" and handle is None
+        value, backend, err, handle, gathered = out[r]
+        assert value == 11.0 and backend == "file" and handle is None and gathered == [0.0, 1.0]
         assert "barrier" in err and "unhandled system error" in err
-    assert Broken.destroyed == 2
+    assert Broken.aborted == 2 and Broken.destroyed == 0
+    # a collective that did not complete: no fall-back, the rank gives up
+    Broken.code = _lib.ERR_HIP
+    lone = Comm.__new__(Comm)
+    lone.rank, lone.world, lone.timeout, lone.dir, lone._seq = 0, 2, 5.0, str(tmp_path), 0
+    lone._handle, lone.backend, lone.rccl_error = object(), "rccl", None
+    with pytest.raises(RuntimeError, match="peer rank is gone"):
+        lone.barrier()
+    assert lone._handle is None and Broken.aborted == 3 and lone.timeout <= 20.0

@@ -285,6 +285,23 @@ def test_decimated_model_matches_oracle(golden):
     assert rel_err(c[:, g["cols"]], g["complex_cols"][::6]).max() < 5e-7
 
 
+def test_reference_import_name_is_an_alias():
+    """`from ghost.wave import ContinuousWaveletTransform, Morse` -- the reference's import line
+    (ghost/wave/__init__.py:3-5) -- works from the repository root and yields ghost_amd's own
+    objects (SURVEY 2 #12)."""
+    import ghost_amd
+    import ghost_amd.wave.transforms
+    from ghost.wave import ContinuousWaveletTransform, Morse
+    import ghost.wave.morseutils as mu
+    import ghost.sigtools.convolution as conv
+    from ghost.formats import standardize_asa
+    import ghost
+    assert ContinuousWaveletTransform is ghost_amd.wave.transforms.ContinuousWaveletTransform
+    assert Morse is ghost_amd.wave.Morse and mu is ghost_amd.wave.morseutils
+    assert conv is ghost_amd.sigtools.convolution and standardize_asa is ghost_amd.formats.standardize_asa
+    assert ghost.__version__ == ghost_amd.__version__
+
+
 def test_interpolated_levels_model_matches_oracle(golden):
     """Amplitude rows of the levels the planner hands to the interpolating synthesis
     (csrc/synthi.hip): q phases of the block transform, demodulated to each scale's band centre,
