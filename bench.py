@@ -367,6 +367,23 @@ def run_rank(args):
     elapsed = time.perf_counter() - t0
     power = sampler.stop() if sampler else None
     elapsed = comm.allreduce_max(elapsed)
+    sustained = None
+    if rank == 0 and world == 1 and power and args.sustain > 0:
+        # hwmon's power reading is a moving average that lags a 0.1 s burst: the same step is run
+        # for `--sustain` seconds more, AFTER and OUTSIDE the timed region, and sampled again
+        s2 = PowerSampler()
+        t_s = time.perf_counter()
+        time.sleep(0.0)
+        n_s = 0
+        while time.perf_counter() - t_s < args.sustain:
+            if n_s == 3:
+                s2.start()                               # (the first steps bring the average up)
+            step({})
+            n_s += 1
+        check(lib.gcwt_device_synchronize())
+        sustained = s2.stop()
+        if sustained:
+            sustained["steps"], sustained["seconds"] = n_s, round(time.perf_counter() - t_s, 2)
     per_rank = comm.allgather(own / args.steps * 1e3)
     devices = comm.allgather(dev)
 
@@ -430,15 +447,19 @@ def run_rank(args):
                 "k_synth7": {"ms": round(k7_ms, 4), "scales": S - info["n_interp"],
                              "achieved": round(b_7 / (k7_ms * 1e-3) / 1e9, 1)}}
         if power:
-            # measured in this run (sysfs, 20 ms period, the timed steps only)
+            # measured in this run (sysfs, 20 ms period): during the timed steps, and -- because the
+            # power reading is a slow moving average -- over a longer run of the same step after them
             rl["power_w"], rl["sclk_ghz"] = power["power_w"], power["sclk_ghz"]
-            rl["power_detail"] = power
-            cap = power.get("power_cap_w")
-            near_cap = cap is not None and power["power_w_max"] >= 0.9 * cap
+            rl["power_detail"] = {"timed_steps": power, "sustained": sustained}
+            ref = sustained or power
+            cap = ref.get("power_cap_w")
+            if sustained:
+                rl["power_w_sustained"], rl["sclk_ghz_sustained"] = sustained["power_w"], sustained["sclk_ghz"]
+            near_cap = cap is not None and ref["power_w_max"] >= 0.9 * cap
             at_store = bool(ceilings) and achieved >= 0.9 * ceilings["store_pattern_ceiling"]
             rl["limited_by"] = ("hbm stores (within 10 % of this box's store-pattern ceiling)" if at_store else
                                 "package power (peak %.0f W of the %.0f W cap, mean sclk %.2f GHz)"
-                                % (power["power_w_max"], cap, power["sclk_ghz"] or 0.0) if near_cap else
+                                % (ref["power_w_max"], cap, ref["sclk_ghz"] or 0.0) if near_cap else
                                 "instruction issue / latency (neither the power cap nor the store ceiling is reached)")
         else:
             rl["power_w"] = rl["sclk_ghz"] = rl["limited_by"] = None   # no readable hwmon: not asserted
@@ -567,6 +588,8 @@ def main():
     ap.add_argument("--output", default="amplitude", choices=["amplitude", "power", "complex"])
     ap.add_argument("--group", type=int, default=0, help="config 5: channels per plan execution (default 24)")
     ap.add_argument("--max-fft-log2", type=int, default=0, help="longest FFT of the plan (time-block size), 0 = library default")
+    ap.add_argument("--sustain", type=float, default=2.0,
+                    help="seconds the step is repeated after the timed region to read sustained power / sclk (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true")

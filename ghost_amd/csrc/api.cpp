@@ -500,6 +500,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     if ((rc = upload_vec(&p->ep_dev[e].levels7, lv7, p->stream))) return bail(rc);
     // interpolated levels: one workgroup per block, the longest-running (largest R) first
     std::vector<SynthiItem> items_i;
+    std::vector<std::pair<int, int>> pending;          // (level, log2 blocks per workgroup)
     std::vector<SynthiLevel> lvi(hp.levels.size());
     std::vector<int> order;
     for (size_t l = 0; l < hp.levels.size(); ++l)
@@ -526,7 +527,31 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       lvi[l] = {lp.decimation, lp.interp_q, lgq, lp.interp_factor, lp.hop, lp.halo, ep.lv[l].nblk,
                 (int32_t)lp.scales.size(), scale_off[l], ep.lv[l].blk_lo, lgnb, 0, lp.twiddle_offset,
                 ep.lv[l].xr_offset, ep.lv[l].m - 1, lp.coef_offset};
-      for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += 1 << lgnb) items_i.push_back({(int32_t)l, b0});
+      pending.push_back({l, lgnb});
+    }
+    // A workgroup walks all the scales of its blocks unless that is too much for one: the passes
+    // of a level's walk (kInterpCols / (q nb) scales each) are cut into runs of at most
+    // `target` output bytes, halved until the launch has a few rounds of workgroups per CU
+    // (long recordings at high decimations: 5 blocks x 24 channels would be 120 workgroups of
+    // 76 MB each).  A run's prologue -- its blocks' spectra -- costs ~8 us.
+    {
+      const int64_t n_ch_slots = (int64_t)hp.prm.n_channels * std::max(1, ep.batch_count);
+      int64_t target = (int64_t)4 << 20;
+      for (int attempt = 0;; ++attempt) {
+        items_i.clear();
+        for (const auto& pl : pending) {
+          const LevelPlan& lp = hp.levels[pl.first];
+          const int nb = 1 << pl.second, ns = kInterpCols / (lp.interp_q * nb);
+          const int n_pass = ((int)lp.scales.size() + ns - 1) / ns;
+          const int64_t pass_bytes = (int64_t)ns * nb * lp.hop * lp.decimation * 4;
+          const int run = (int)std::max<int64_t>(1, std::min<int64_t>(n_pass, target / std::max<int64_t>(1, pass_bytes)));
+          for (int b0 = 0; b0 < ep.lv[pl.first].nblk; b0 += nb)
+            for (int p0 = 0; p0 < n_pass; p0 += run)
+              items_i.push_back({(int32_t)pl.first, b0, p0, std::min(run, n_pass - p0)});
+        }
+        if ((int64_t)items_i.size() * n_ch_slots >= 3072 || target <= ((int64_t)1 << 19) || attempt > 6) break;
+        target >>= 1;
+      }
     }
     p->ep_dev[e].n_items_i = (int)items_i.size();
     if ((rc = upload_vec(&p->ep_dev[e].items_i, items_i, p->stream))) return bail(rc);

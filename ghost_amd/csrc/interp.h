@@ -20,8 +20,10 @@
 namespace gcwt {
 
 constexpr int kInterpTaps = 8;       // T
-constexpr int kInterpMaxFactor = 256;   // I = R / q at most: a lane's coefficient set is lane & (I/4 - 1)
-constexpr int kInterpMaxPhases = 16;    // q at most: the columns of one pass of k_synthi (synthi.hip)
+constexpr int kInterpMaxFactor = 1024;  // I = R / q at most: a lane's coefficient set is (4 (wave-task mod 4) .. + lane) & (I/4 - 1),
+                                        // and a wave's wave-tasks stay in one class mod 4 (synthi.hip)
+constexpr int kInterpCols = 16;         // columns (block, scale slot, phase) of one pass of k_synthi (synthi.hip)
+constexpr int kInterpMaxPhases = kInterpCols;   // q at most
 
 inline double interp_sinc(double x) {   // sin(pi x) / (pi x)
   if (std::fabs(x) < 1e-12) return 1.0;

@@ -125,7 +125,8 @@ hipError_t launch_synth7(int mode, int ncol, const Synth7Args& a, int n_items, i
 
 // Interpolating synthesis (synthi.hip): one workgroup = one block of one level, all its scales.
 struct SynthiItem {
-  int32_t level, blk0;
+  int32_t level, blk0;          // first block of the workgroup's group
+  int32_t pass0, n_pass;        // the passes (groups of scale slots) of the level's walk it makes
 };
 struct SynthiLevel {
   int32_t decimation, q, log2q, factor;   // R, phases per (block, scale), I = R / q

@@ -52,7 +52,7 @@ constexpr int kPlaneI = kThreadsI + 1;
 constexpr int kZPad = 4;                         // v2f entries between the slots of the z buffer: their
                                                  // writes fall on different banks
 constexpr int kSlotsMax = kColsI / 4;            // q >= 4
-static_assert(kInterpMaxPhases <= kColsI, "a scale's q phases are columns of one pass");
+static_assert(kColsI == kInterpCols, "the host cuts the passes for this many columns (interp.h)");
 constexpr int kZElems = 256 * kColsI + kSlotsMax * kZPad;     // z buffer
 constexpr int kExElems = kZElems > 16 * kPlaneI ? kZElems : 16 * kPlaneI;   // ... in place of the 16 exchange planes
 constexpr int kGainRowI = 16 * 20;
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   // 20 floats (four conflict-free 16-byte reads per thread), as k_synth7 parks them
   auto stage_slot = [&](int i) { return (i >> 8) * kGainRowI + (i & 15) * 20 + ((i >> 4) & 15); };
   for (int i = tid; i < ns * 256; i += kThreadsI) {
-    const int sb = min(i >> 8, n_scales - 1);
+    const int sb = min(it.pass0 * ns + (i >> 8), n_scales - 1);
     stage[stage_slot(i)] = a.gain[(int64_t)(scales[sb] & kScaleIndexMask) * 256 + (i & 255)];
   }
 
@@ -184,20 +184,23 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   while ((4 << lgi4) < I) ++lgi4;                             // I / 4 = 1 << lgi4
   const int tps = hop * (R >> 2);                             // lane-tasks per (block, scale)
   const int wps = (tps + 63) >> 6;
-  const int sigma = lane & ((1 << lgi4) - 1);                 // which 4 of the I sub-sample positions
-  const float* const coef0 = a.coef + lv.coef_offset + (int64_t)sigma * 4 * kT;
+  // which 4 of the I sub-sample positions a lane-task k covers: k mod (I / 4).  k = 64 wt + lane
+  // and a wave's wave-tasks advance by kWavesI = 4 at a time, so up to I / 4 = 256 the set depends
+  // on the lane and on wt mod 4 only -- constant along a wave's run through a z slot
+  static_assert(kWavesI == 4 && kInterpMaxFactor <= 1024, "a wave's lane-tasks keep their class mod I / 4");
+  const float* const coef_lv = a.coef + lv.coef_offset;
   constexpr int kElem = 1;
   const unsigned ext_bytes = w_len > 0 ? (unsigned)(w_len * (4 * kElem)) : 0u;
   float* const out0 = a.out + ((int64_t)ch * a.n_scales * a.row_len + a.seg.seg_col[seg] + w_lo) * kElem;
   const int s_base = (int)(n_b - w_lo);                       // window-relative sample of the block's first
-  const int n_pass = (n_scales + ns - 1) >> lgns;
-  int cur_par = -1;                       // which coefficient table cf holds: kernels of odd (0) / even (1) length
+  const int pass_end = it.pass0 + it.n_pass;   // of the (n_scales + ns - 1) >> lgns passes of the level's walk
+  int cur_par = -1;                       // which coefficients cf holds: kernels of odd (0) / even (1) length, (wt mod 4 class) << 1
   v2f cf[4][kT / 2];
   __syncthreads();
 
-  for (int pass = 0; pass < n_pass; ++pass) {
+  for (int pass = it.pass0; pass < pass_end; ++pass) {
     const int b0 = pass * ns;
-    const bool has_next = pass + 1 < n_pass;
+    const bool has_next = pass + 1 < pass_end;
     // next pass's gains: loaded now (nothing of this pass is in flight yet), parked after the exchange
     float nxt[4];
     if (has_next) {
@@ -265,15 +268,18 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
         if (b0 + sl >= n_scales || it.blk0 + bl >= lv.nblk) continue;
         const int entry = __builtin_amdgcn_readfirstlane(sc_lds[b0 + sl]);
         const int par = (__builtin_amdgcn_readfirstlane(aux_lds[b0 + sl]) >> 16) & 1;
-        if (par != cur_par) {                                 // at most twice per workgroup: the level's list
-          const float4* const cp = reinterpret_cast<const float4*>(coef0 + (int64_t)par * I * kT);   // is ordered by parity
+        const int wt0 = (wave - zi * wps) & (kWavesI - 1);
+        const int key = par | (lgi4 > 6 ? (wt0 & ((1 << (lgi4 - 6)) - 1)) << 1 : 0);
+        if (key != cur_par) {       // rare: the level's list is ordered by parity; wt0 changes only when I > 256
+          const int sigma = (wt0 * 64 + lane) & ((1 << lgi4) - 1);
+          const float4* const cp = reinterpret_cast<const float4*>(coef_lv + ((int64_t)par * I + sigma * 4) * kT);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float4 u0 = cp[2 * i], u1 = cp[2 * i + 1];
             cf[i][0] = (v2f){u0.x, u0.y}; cf[i][1] = (v2f){u0.z, u0.w};
             cf[i][2] = (v2f){u1.x, u1.y}; cf[i][3] = (v2f){u1.z, u1.w};
           }
-          cur_par = par;
+          cur_par = key;
         }
         // descriptor from provably wave-uniform words (else hipcc waterfalls every store); it spans
         // exactly the samples this launch may write, [w_lo, w_hi) of the segment
@@ -288,7 +294,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
         const int s_blk = s_base + bl * hop * R;              // window-relative sample of this block's first
         // the slot's wave-tasks are dealt round-robin over the waves, continuing where the previous
         // slot stopped
-        for (int wt = (wave - zi * wps) & (kWavesI - 1); wt < wps; wt += kWavesI) {
+        for (int wt = wt0; wt < wps; wt += kWavesI) {
           const int k = wt * 64 + lane;
           const int s_first = s_blk + 256 * wt;               // window-relative sample of the wave-task's first
           const bool whole = wt * 64 + 64 <= tps && s_first >= 0 && (int64_t)s_first + 256 <= w_len;
