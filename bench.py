@@ -402,7 +402,7 @@ def run_rank(args):
             tj = json.load(open(tpath))
             traffic = tj.get("k_synth_hbm_bytes_per_launch")
             traffic_src = "profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
-                          "this command, not measured in this run" % tj.get("round", "r01")
+                          "this command (both synthesis kernels), not measured in this run" % tj.get("round", "r01")
         if cfg5:
             workload = ("config 5: %d ch/GPU x %d samples @ 30 kHz x %d Morse scales 500..1 Hz, %s f32 out, "
                         "streamed in %d time blocks x %d channel groups into a ring of 2 device buffers"

@@ -92,8 +92,9 @@ struct gcwt_plan {
   hipStream_t stream = nullptr;
   hipStream_t aux[2] = {nullptr, nullptr};   // the level passes of a batch run beside each other (run_pipeline)
   bool level_streams = true;  // GHOSTCWT_LEVEL_STREAMS=0: everything on `stream`
-  bool synth_streams = true;  // the interpolating kernel runs beside k_synth7 on aux[0] (its store-bound
-                              // workgroups share the CUs with the arithmetic-bound ones); GHOSTCWT_SYNTH_STREAMS=0: one after the other
+  bool synth_streams = false; // GHOSTCWT_SYNTH_STREAMS=1: the interpolating kernel runs beside k_synth7 on aux[0] (its store-bound
+                              // workgroups share the CUs with the arithmetic-bound ones: measured equal on the headline,
+                              // profiles/r03_synth_study.md); default: one after the other, so that per-kernel times add up
   hipStream_t cur = nullptr;  // the stream the stage in hand is launched on (profiling spans follow it)
   // workspace
   float2* d_x = nullptr;      // [C][max_p]   spectrum (k1-major)
@@ -730,7 +731,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       }
     }
     const EpochDev& dev = p->ep_dev[ep.batch_first];
-    // The interpolating kernel is launched first, on a stream of its own, and k_synth7 beside it:
+    // The interpolating kernel is launched first; with GHOSTCWT_SYNTH_STREAMS=1 on a stream of its own, k_synth7 beside it:
     // the two share the CUs (store-bound workgroups next to arithmetic-bound ones) and each
     // fills the other's tail.  Both only read what the level passes left and write disjoint rows.
     hipStream_t si = st;

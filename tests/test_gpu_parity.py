@@ -806,6 +806,48 @@ def test_config5_regime_streamed_multichannel():
     np.testing.assert_array_equal(whole, out)
 
 
+def test_config5_at_the_shape_the_bench_runs():
+    """BASELINE config 5 at full size for one (channel group, time block), exactly as
+    `bench.py --config 5` executes it: 24 of a GPU's 48 channels x 18e6 samples @ 30 kHz x 200
+    scales 500..1 Hz, the middle time block (both edges are seams between blocks) into an 80 GB
+    ring buffer.  Rows channels {0, 23} x scales {0, 100, 199 = 1 Hz, a 418 430-tap kernel} against
+    the oracle over that block's window (transforms.py:529-597 streaming design, :187-204 numbers)."""
+    import ctypes
+    import importlib.util
+    from ghost_amd.engine import CwtPlan, DeviceBuffer
+    from ghost_amd.synthetic import lfp
+    fs, group, n, S = 30000.0, 24, 18000000, 200
+    f = np.geomspace(500.0, 1.0, S)
+    plan = CwtPlan(n, group, fs, f, output="amplitude")
+    segs = plan.segments()
+    assert len(segs) >= 4 and plan.info["n_spectral"] == S
+    base = lfp(2, n, fs, seed=1234)
+    xb = DeviceBuffer(4 * group * n)
+    for c in range(group):
+        xb.upload(base[c % 2], offset_bytes=4 * c * n)
+    a, b, _ = segs[len(segs) // 2]
+    ring = DeviceBuffer(4 * group * S * (b - a))
+    plan.execute_block_device(xb, ring, a, b - a)
+    om = orc.hz_to_rad(f, fs)
+    lengths = orc.morse_lengths(om)
+    assert lengths[-1] == 418430
+    worst = 0.0
+    for c in (0, group - 1):
+        xc = base[c % 2].astype(np.float64)
+        xc -= xc.mean()                                              # transforms.py:142-143: global mean
+        for sc in (0, S // 2, S - 1):
+            L = int(lengths[sc])
+            psi, _ = orc.morse_kernel(L, om[sc])
+            w0, w1 = max(0, a - L), min(n, b + L)                    # every output needs the input within (L-1)/2
+            ref = np.abs(orc.overlap_add_convolve(xc[w0:w1], psi)[a - w0:b - w0])
+            row = ring.download((b - a,), np.float32, offset_bytes=4 * (c * S + sc) * (b - a))
+            worst = max(worst, float(np.abs(row - ref).max() / ref.max()))
+    print("config 5, block %d..%d: worst %.3g" % (a, b, worst))
+    assert worst < TOL
+    ring.free()
+    xb.free()
+
+
 def test_first_pass_windows_beside_strong_tones(monkeypatch):
     """The synthesis skips, per scale, the first-pass inputs whose bins lie above the scale's
     band (gain below band_eps of the peak there: k_scale_windows).  A recording with tones 20 x

@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage: tools/prof_round.sh r02
+# usage: tools/prof_round.sh r03
 # round-end evidence: bench line, rocprofv3 kernel stats, HBM traffic counters (separate passes,
-# --pmc never combined with the hip/hsa/sys traces).  Then: python tools/traffic.py r02
-R=${1:-r02}
+# --pmc never combined with the hip/hsa/sys traces).  Then: python tools/traffic.py r03
+R=${1:-r03}
 set -x
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$R

@@ -22,26 +22,28 @@ def counter(kind):
 
 
 fetch, write = counter("fetch"), counter("write")
-key = [k for k in fetch if "k_synth7" in k][0]
-f_kb, w_kb = fetch[key]["avg_KB"], write[key]["avg_KB"]
+# the synthesis: k_synth7 (FFT per sample) and k_synthi (interpolating), one launch each per step
+keys = [k for k in fetch if "k_synth7" in k or "k_synthi" in k]
+f_kb = sum(fetch[k]["avg_KB"] for k in keys)
+w_kb = sum(write[k]["avg_KB"] for k in keys)
+steps = max(1, fetch[keys[0]]["calls"])
 out = {
     "round": rnd,
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py 128ch x "
             "1e6 x 100 scales amplitude; values are KB per launch. On gfx950 FETCH_SIZE counts 64 B "
             "per 128 B request for coalesced streams, so fetched bytes = 2 * FETCH_SIZE * 1024 "
-            "(guides/MI355X_MICROARCH.md, HBM section); k_channel_sum confirms it here (250 000 KB "
-            "reported for 512 MB read). WRITE_SIZE is exact for k_synth7's 4 B/lane 256 B/wave "
-            "stores: it reports 5.0e7 KB = 51.2 GB = the amplitude output.",
+            "(guides/MI355X_MICROARCH.md, HBM section); WRITE_SIZE reads the bytes exactly for the "
+            "16-byte-per-lane stores of k_synthi and the 4-byte, 256-B-per-wave stores of k_synth7 "
+            "(with the nt policy it reads about 2 % above the bytes stored). The synthesis is the two "
+            "kernels together: " + ", ".join(keys),
     "k_synth_hbm_bytes_per_launch": int(2 * f_kb * 1024 + w_kb * 1024),
-    "k_synth7_fetch_KB": f_kb, "k_synth7_write_KB": w_kb,
-    "non_synth_hbm_bytes_per_step": int(sum(2 * fetch[k]["avg_KB"] * 1024 * fetch[k]["calls"] for k in fetch if k != key)
-                                        / max(1, fetch[key]["calls"])
-                                        + sum(write[k]["avg_KB"] * 1024 * write[k]["calls"] for k in write if k != key)
-                                        / max(1, write[key]["calls"])),
+    "synthesis_kernels": {k: {"fetch_KB": fetch[k]["avg_KB"], "write_KB": write[k]["avg_KB"]} for k in keys},
+    "non_synth_hbm_bytes_per_step": int(sum(2 * fetch[k]["avg_KB"] * 1024 * fetch[k]["calls"] for k in fetch if k not in keys) / steps
+                                        + sum(write[k]["avg_KB"] * 1024 * write[k]["calls"] for k in write if k not in keys) / steps),
     "counters": {"FETCH_SIZE": fetch, "WRITE_SIZE": write},
 }
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 shutil.copy(newest("stats/*/*kernel_stats.csv"), os.path.join(root, "profiles", rnd + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(root, "profiles", rnd + "_bench.json"))
-print("k_synth7: fetch %.1f MB (x2 corrected) + write %.1f MB = %d bytes per launch" %
-      (2 * f_kb / 1024, w_kb / 1024, out["k_synth_hbm_bytes_per_launch"]))
+print("synthesis (%s): fetch %.1f MB (x2 corrected) + write %.1f MB = %d bytes per step" %
+      (" + ".join(keys), 2 * f_kb / 1024, w_kb / 1024, out["k_synth_hbm_bytes_per_launch"]))
