@@ -95,6 +95,7 @@ def _load():
         "gcwt_comm_broadcast_bank": (C.c_int, [vp, vp, C.c_int]),
         # test-only hooks (include/ghostcwt_debug.h)
         "gcwt_debug_level_count": (C.c_int, [vp]),
+        "gcwt_debug_level_band_shift": (C.c_int, [vp, C.c_int, i32p]),
         "gcwt_debug_batch_of": (C.c_int, [vp, C.c_int, i32p, i32p]),
         "gcwt_debug_level_info": (C.c_int, [vp, C.c_int, C.c_int, i32p, i32p, i32p, i32p, i64p]),
         "gcwt_debug_exact_gain": (C.c_int, [vp, C.c_int, i64p, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
@@ -102,6 +103,7 @@ def _load():
         "gcwt_debug_interp_level": (C.c_int, [vp, C.c_int, i32p, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                             f32p, C.c_int64]),
         "gcwt_debug_scale_demod": (C.c_int, [vp, i32p]),
+        "gcwt_debug_scale_theta_neg": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "gcwt_debug_clock": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "gcwt_debug_bandwidth": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_double)]),
         "gcwt_debug_fetch": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int64]),

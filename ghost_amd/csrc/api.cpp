@@ -63,6 +63,8 @@ struct EpochDev {
   Synth7Item* items7 = nullptr;      // production kernel
   Synth7Level* levels7 = nullptr;
   int n_items7 = 0;
+  Synth7Item* items7w = nullptr;     // ... its wide-halo instantiation (shifted-band levels with halo > 48)
+  int n_items7w = 0;
   SynthiItem* items_i = nullptr;     // interpolating kernel (synthi.hip)
   SynthiLevel* levels_i = nullptr;
   int n_items_i = 0;
@@ -106,6 +108,8 @@ struct gcwt_plan {
   float2* d_psi = nullptr;    // direct kernels
   unsigned long long* d_probe = nullptr;   // GHOSTCWT_CLOCK_PROBE=1: [cycles, 100 MHz ticks] of the synthesis workgroups
   double* d_amps = nullptr;   // kept spectrum samples A_j of every scale (planner.h: amps)
+  float2* d_xs = nullptr;     // [C][xs_stride] shifted slice of the spectrum of the level in hand (levels with a
+  int64_t xs_stride = 0;      //   band shift: heavy-tailed wavelets); xs_stride = the largest such level's M
   float2* d_z = nullptr;      // [C][max_p]   full-band scales: spectrum * response, then its IFFT
   float2* d_hfull = nullptr;  // [max_p]      full-band response of the scale in hand
   float2* d_tw4096 = nullptr; // exp(-2 pi i j/4096), j < 2048
@@ -156,12 +160,12 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
-  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
+  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_xs); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
   p->host_out.release();
-  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.levels7); fr(e.items_i); fr(e.levels_i); }
+  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.items7w); fr(e.levels7); fr(e.items_i); fr(e.levels_i); }
   p->ep_dev.clear();
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
   p->ev_pool.clear();
@@ -187,7 +191,8 @@ enum LevelKernel { LK_SYNTH16 = 0, LK_SYNTH7 = 7, LK_INTERP = 9 };
 inline LevelKernel level_kernel(const gcwt_plan* p, const LevelPlan& lp) {
   if (p->use_synth16) return LK_SYNTH16;
   if (lp.interp_q > 0) return LK_INTERP;
-  return lp.fast ? LK_SYNTH7 : LK_SYNTH16;
+  // (a shifted band is built into k_synth7 and k_synthi only; k_synth7<WIDE> takes its long halos)
+  return lp.fast || (lp.band_shift > 0 && lp.scales.size() <= 256) ? LK_SYNTH7 : LK_SYNTH16;
 }
 
 // RAII-less span helper: begin/end record events on the stage's stream when profiling
@@ -383,6 +388,11 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     if ((rc = dev_alloc(&p->d_x, (size_t)(slots * hp.max_p)))) return bail(rc);
     if ((rc = dev_alloc(&p->d_xr, (size_t)(slots * hp.max_xr)))) return bail(rc);
     if ((rc = dev_alloc(&p->d_xb, (size_t)(slots * hp.max_xb)))) return bail(rc);
+    for (const EpochPlan& ep : hp.epochs)
+      for (size_t l = 0; l < hp.levels.size(); ++l)
+        if (hp.levels[l].band_shift > 0) p->xs_stride = std::max(p->xs_stride, ep.lv[l].m);
+    // one slice buffer per stream the level passes run on (run_pipeline: three streams)
+    if (p->xs_stride > 0 && (rc = dev_alloc(&p->d_xs, (size_t)(3 * slots * p->xs_stride)))) return bail(rc);
     if (hp.n_fullband > 0) {
       if ((rc = dev_alloc(&p->d_z, (size_t)(slots * hp.max_p)))) return bail(rc);
       if ((rc = dev_alloc(&p->d_hfull, (size_t)hp.max_p))) return bail(rc);
@@ -433,7 +443,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   for (int i = 0; i < S; ++i) {
     const ScalePlan& s = hp.scales[i];
     bsc[i] = {s.omega, s.half_delay, s.length, s.amp_offset, s.bin_lo, s.n_bins, s.decimation,
-              s.method == GCWT_SCALE_SPECTRAL ? 1 : 0};
+              s.method == GCWT_SCALE_SPECTRAL ? 1 : 0,
+              s.method == GCWT_SCALE_SPECTRAL ? hp.levels[s.level].band_shift : 0, 0};
     if (s.method == GCWT_SCALE_DIRECT)
       dsc[s.direct_index] = {s.omega, s.length, s.amp_offset, s.direct_offset, i, s.bin_lo, s.n_bins, 0};
   }
@@ -453,7 +464,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     for (int sidx : hp.levels[l].scales)
       if (hp.scales[sidx].half_delay != 0.0) scale_list.push_back(sidx);
     for (int k = 0; k < 256; ++k) {
-      const double a = -M_PI * k / (256.0 * hp.levels[l].decimation);
+      const double a = -M_PI * (k - hp.levels[l].band_shift) / (256.0 * hp.levels[l].decimation);
       half_tw[l * 256 + k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
   }
@@ -481,23 +492,25 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
                ep.lv[l].xb_offset, hp.levels[l].twiddle_offset};
     if ((rc = upload_vec(&p->ep_dev[e].items, items, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels, lv, p->stream))) return bail(rc);
-    std::vector<Synth7Item> items7;
+    std::vector<Synth7Item> items7, items7w;
     std::vector<Synth7Level> lv7(hp.levels.size());
     for (size_t l = 0; l < lv7.size(); ++l) {
       const LevelPlan& lp = hp.levels[l];
       int lg = 0;
       while ((1 << lg) < lp.decimation) ++lg;
       lv7[l] = {lp.decimation, lg, lp.hop, lp.halo, ep.lv[l].nblk, (int32_t)lp.scales.size(),
-                scale_off[l], ep.lv[l].blk_lo, n_plain[l], (int32_t)(l * 256), ep.lv[l].xb_offset,
+                scale_off[l], ep.lv[l].blk_lo, n_plain[l], (int32_t)(l * 256), lp.band_shift, 0, ep.lv[l].xb_offset,
                 lp.twiddle_offset, ep.lv[l].xr_offset, ep.lv[l].m - 1};
       const int bpb = std::max(1, p->synth_cols / lp.decimation);
       const int n_rtiles = std::max(1, lp.decimation / p->synth_cols);
       if (level_kernel(p, lp) != LK_SYNTH7) continue;
       for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
-        for (int rt = 0; rt < n_rtiles; ++rt) items7.push_back({(int32_t)l, b0, rt, 0});
+        for (int rt = 0; rt < n_rtiles; ++rt) (lp.halo > 48 ? items7w : items7).push_back({(int32_t)l, b0, rt, 0});
     }
     p->ep_dev[e].n_items7 = (int)items7.size();
+    p->ep_dev[e].n_items7w = (int)items7w.size();
     if ((rc = upload_vec(&p->ep_dev[e].items7, items7, p->stream))) return bail(rc);
+    if ((rc = upload_vec(&p->ep_dev[e].items7w, items7w, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels7, lv7, p->stream))) return bail(rc);
     // interpolated levels: one workgroup per block, the longest-running (largest R) first
     std::vector<SynthiItem> items_i;
@@ -698,8 +711,19 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         // x_R of this decimation was made for the level that owns it (an earlier one)
       } else if (lp.decimation <= kMaxTwoPassDecimation) {
         const int Q = kRowLen / lp.decimation;
+        const float2* src = p->d_x;
+        int64_t src_row = kRowLen, src_cstride = P;
+        if (lp.band_shift > 0) {
+          // the level's band starts band_shift bins below zero: its M spectrum samples are gathered
+          // (negative frequencies as conjugates) into a slice buffer first, one per stream
+          const int64_t U = (int64_t)lp.band_shift * el.m / hp.block;     // a multiple of P1 (planner: steps of R / 16 bins)
+          if (U % P1 != 0 || U / P1 > Q) return set_err(GCWT_ERR_INVALID, "internal: band shift does not slice the spectrum");
+          float2* xs = p->d_xs + (int64_t)(side ? lp.xr_owner % 3 : 0) * slots * p->xs_stride;
+          RUN(ST_DECIM, launch_shift_gather(p->d_x, xs, P1, Q, (int)(U / P1), kRowLen, P, p->xs_stride, slots, ls));
+          src = xs; src_row = Q; src_cstride = p->xs_stride;
+        }
         // x_R[Q m1 + m2] = sum_{j1} e^{2 pi i j1 m1/P1} e^{2 pi i j1 m2/M} sum_{j2} X~[j1][j2] e^{2 pi i j2 m2/Q}
-        RUN(ST_DECIM, launch_fft_rows(+1, p->d_x, xr, Q, P1, kRowLen, Q, P, hp.max_xr,
+        RUN(ST_DECIM, launch_fft_rows(+1, src, xr, Q, P1, src_row, Q, src_cstride, hp.max_xr,
                                       P1 > 1 ? el.m : 0, p->d_tw4096,
                                       fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, ls));
         if (P1 > 1)
@@ -736,7 +760,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     // fills the other's tail.  Both only read what the level passes left and write disjoint rows.
     hipStream_t si = st;
     if (dev.n_items_i > 0) {
-      const bool beside = p->synth_streams && (dev.n_items7 > 0 || dev.n_items > 0);
+      const bool beside = p->synth_streams && (dev.n_items7 > 0 || dev.n_items7w > 0 || dev.n_items > 0);
       if (beside) {
         hipEvent_t levels_done;
         int rc_ = get_event(p, &levels_done);
@@ -781,13 +805,15 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       a.seg = sout;
       RUN(ST_SYNTH, launch_synth(mode, a, dev.n_items, slots, st));
     }
-    if (dev.n_items7 > 0) {
+    for (int wide = 0; wide < 2; ++wide) {
+      const int n7 = wide ? dev.n_items7w : dev.n_items7;
+      if (n7 == 0) continue;
       Synth7Args a7{};
       a7.xb = p->d_xb;
       a7.bank = p->d_bank;
       a7.tw256 = p->d_tw256;
       a7.level_tw = p->d_level_tw;
-      a7.items = dev.items7;
+      a7.items = wide ? dev.items7w : dev.items7;
       a7.levels = dev.levels7;
       a7.scale_list = p->d_scale_list;
       a7.gain = p->d_gain;
@@ -805,11 +831,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         a7.xb_scale = (float)(1.0 / ((double)hp.block * (double)P));
       }
 #ifdef GCWT_MEASURE
-      if (p->synth_kernel == 8)
-        RUN(ST_SYNTH, launch_synth8(mode, p->synth_cols, a7, dev.n_items7, slots, st));
+      if (p->synth_kernel == 8 && !wide)
+        RUN(ST_SYNTH, launch_synth8(mode, p->synth_cols, a7, n7, slots, st));
       else
 #endif
-        RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, a7, dev.n_items7, slots, st));
+        RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, wide != 0, a7, n7, slots, st));
     }
     if (si != st) {                        // join: the batch is done when both kernels are
       hipEvent_t interp_done;
@@ -1062,6 +1088,13 @@ int gcwt_debug_level_info(const gcwt_plan* p, int epoch, int level, int32_t* dec
   return GCWT_OK;
 }
 
+int gcwt_debug_level_band_shift(const gcwt_plan* p, int level, int32_t* shift) {
+  if (!p || !shift) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  if (level < 0 || level >= (int)p->hp.levels.size()) return set_err(GCWT_ERR_INVALID, "level out of range");
+  *shift = p->hp.levels[level].band_shift;
+  return GCWT_OK;
+}
+
 int gcwt_debug_interp_level(const gcwt_plan* p, int level, int32_t* q, int32_t* factor, double* alpha,
                             double* err_bound, float* coef, int64_t max_floats) {
   if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
@@ -1083,6 +1116,12 @@ int gcwt_debug_interp_level(const gcwt_plan* p, int level, int32_t* q, int32_t* 
 int gcwt_debug_scale_demod(const gcwt_plan* p, int32_t* demod) {
   if (!p || !demod) return set_err(GCWT_ERR_INVALID, "NULL argument");
   for (size_t i = 0; i < p->hp.scales.size(); ++i) demod[i] = p->hp.scales[i].demod_bin;
+  return GCWT_OK;
+}
+
+int gcwt_debug_scale_theta_neg(const gcwt_plan* p, double* theta_neg) {
+  if (!p || !theta_neg) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  for (size_t i = 0; i < p->hp.scales.size(); ++i) theta_neg[i] = p->hp.scales[i].theta_neg;
   return GCWT_OK;
 }
 

@@ -28,6 +28,8 @@ struct BankScale {
   int32_t bin_lo, n_bins;
   int32_t decimation;
   int32_t spectral;
+  int32_t band_shift;  // bank bin k is the frequency (k - band_shift) 2 pi / (256 R): the level's band starts
+  int32_t pad;         // that many bins below zero (planner.h: LevelPlan::band_shift)
 };
 
 struct DirectScale {
@@ -89,6 +91,8 @@ struct Synth7Level {
   int32_t decimation, log2r, hop, halo, nblk, n_scales, scale_offset, blk_base;
   int32_t n_plain;     // the first n_plain scales of the level's list have odd L (real filter);
   int32_t half_offset; // the rest carry the half-sample phase level_half_tw[half_offset + k]
+  int32_t band_shift;  // bins of the level's grid below zero frequency (planner.h; 0 for the default wavelet)
+  int32_t pad1;
   int64_t xb_offset;   // per-channel offset of this level's block spectra (complex elems)
   int64_t tw_offset;   // into level_tw
   int64_t xr_offset;   // per-channel offset of this level's decimated signal x_R (complex elems)
@@ -120,7 +124,8 @@ struct Synth7Args {
   SegOut seg;
 };
 
-hipError_t launch_synth7(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
+// wide_halo: the items' levels have block halos above 48 (k_synth7<.., WIDE>); the other launch takes the rest
+hipError_t launch_synth7(int mode, int ncol, bool wide_halo, const Synth7Args& a, int n_items, int n_channels,
                          hipStream_t st);
 
 // Interpolating synthesis (synthi.hip): one workgroup = one block of one level, all its scales.
@@ -199,6 +204,10 @@ hipError_t launch_fft_rows(int sign, const float2* in, float2* out, int len, int
                            int64_t in_ld, int64_t out_ld, int64_t in_cstride, int64_t out_cstride,
                            int64_t tw_n, const float2* tw4096, const float2* tw256, float scale,
                            int n_channels, hipStream_t st, int out_len = 0, int mirror = 0);
+// shifted band of a level: Xs[k1][j2] = X[k1 + P1 (j2 - u2)] from the positive half of a real signal's
+// k1-major spectrum (kernels.hip: k_shift_gather)
+hipError_t launch_shift_gather(const float2* x, float2* xs, int p1, int q, int u2, int64_t x_row,
+                               int64_t x_cstride, int64_t xs_cstride, int n_channels, hipStream_t st);
 hipError_t launch_block_fft(const float2* xr, float2* xb, int64_t m, int hop, int halo, int blk_lo,
                             int nblk,
                             int64_t xr_cstride, int64_t xb_cstride, const float2* tw256, float scale,

@@ -202,9 +202,10 @@ __global__ void k_build_bank(cf* __restrict__ bank, float* __restrict__ gain,
   float g = 0.f;
   if (p.spectral) {
     const int64_t b = (int64_t)B * p.decimation;
-    const double gd = exact_gain(amps + p.amp_offset, p.bin_lo, p.n_bins, p.length, k, b);
+    const int kk = k - p.band_shift;         // bins are counted from the bottom of the level's band
+    const double gd = exact_gain(amps + p.amp_offset, p.bin_lo, p.n_bins, p.length, kk, b);
     double sn, cs;
-    sincospi(-2.0 * (double)k / (double)b * p.half_delay, &sn, &cs);
+    sincospi(-2.0 * (double)kk / (double)b * p.half_delay, &sn, &cs);
     h = make_float2((float)(gd * cs), (float)(gd * sn));
     g = (float)gd;
   }
@@ -222,7 +223,7 @@ __global__ void k_bank_gain(const cf* __restrict__ bank, float* __restrict__ gai
   const BankScale p = sc[s];
   const cf h = bank[(int64_t)s * 256 + k];
   float sn, cs;
-  sincospif((float)(2.0 * (double)k / (256.0 * (double)p.decimation) * p.half_delay), &sn, &cs);
+  sincospif((float)(2.0 * (double)(k - p.band_shift) / (256.0 * (double)p.decimation) * p.half_delay), &sn, &cs);
   gain[(int64_t)s * 256 + k] = h.x * cs - h.y * sn;
 }
 
@@ -1138,6 +1139,31 @@ __global__ void k_zero_range(float* __restrict__ out, int64_t row_len_floats, in
   if (i < len) out[(int64_t)blockIdx.y * row_len_floats + start + i] = 0.f;
 }
 
+// ---------------------------------------------------------------------------
+// Shifted band of a level (heavy-tailed wavelets: planner.h, LevelPlan::band_shift): the M = P1 q
+// spectrum samples X[k - U], k in [0, M), U = P1 u2 of them below zero frequency, gathered from
+// the k1-major positive-frequency spectrum X~[k1][k2] = X[k1 + P1 k2] of a REAL signal into
+// Xs[k1][j2] = X[k1 + P1 (j2 - u2)]:  j2 >= u2 reads X~[k1][j2 - u2]; below, X[-n] = conj(X[n]) with
+// n = P1 (u2 - j2) - k1 = (P1 - k1) + P1 (u2 - j2 - 1) for k1 > 0.  The level's row and column
+// passes then run on Xs as they do on X~.
+// grid (ceil(q / 256), P1, slots), block 256
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_shift_gather(const cf* __restrict__ x, cf* __restrict__ xs, int p1, int q,
+                                                      int u2, int64_t x_row, int64_t x_cstride, int64_t xs_cstride) {
+  const int j2 = blockIdx.x * 256 + threadIdx.x, k1 = blockIdx.y;
+  if (j2 >= q) return;
+  const cf* xc = x + (int64_t)blockIdx.z * x_cstride;
+  cf v;
+  if (j2 >= u2) {
+    v = xc[(int64_t)k1 * x_row + (j2 - u2)];
+  } else {
+    const int row = k1 == 0 ? 0 : p1 - k1, col = u2 - j2 - (k1 == 0 ? 0 : 1);
+    v = xc[(int64_t)row * x_row + col];
+    v.y = -v.y;
+  }
+  xs[(int64_t)blockIdx.z * xs_cstride + (int64_t)k1 * q + j2] = v;
+}
+
 // ===========================================================================
 // launch wrappers
 // ===========================================================================
@@ -1156,6 +1182,14 @@ hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double*
   hipLaunchKernelGGL(k_channel_sum, dim3(parts, n_channels), dim3(256), 0, st, x, n, sums);
   GCWT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_channel_sum_final, dim3((n_channels + 63) / 64), dim3(64), 0, st, sums, n_channels, parts);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_shift_gather(const cf* x, cf* xs, int p1, int q, int u2, int64_t x_row, int64_t x_cstride,
+                               int64_t xs_cstride, int n_channels, hipStream_t st) {
+  hipLaunchKernelGGL(k_shift_gather, dim3((q + 255) / 256, p1, n_channels), dim3(256), 0, st, x, xs, p1, q, u2,
+                     x_row, x_cstride, xs_cstride);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -131,11 +131,12 @@ static void scale_bins(const HostPlan& hp, ScalePlan* sp, std::vector<double>* a
 }
 
 // Measures, on the exact response G of the reference's kernel (morse_exact.h):
-//  * theta_hi: above it (and all the way round to 2 pi, i.e. through the negative
-//    frequencies) |G| stays below band_tol of the peak.  G is probed where its side lobes
-//    peak, half-way between grid bins: every half-bin of the upper skirt, then geometric
-//    steps out to Nyquist and, from the other end, out from just below 2 pi -- the side
-//    lobes of the L-tap truncation decay like 1/|theta - band|, smoothly, on both sides.
+//  * theta_hi, theta_neg: outside [-theta_neg, theta_hi] |G| stays below band_tol of the peak.
+//    G is probed where its side lobes peak, half-way between grid bins: every half-bin of the
+//    upper skirt, then geometric steps out to Nyquist and, from the other end, down from zero
+//    frequency -- the side lobes of the L-tap truncation decay like 1/|theta - band|, smoothly,
+//    on both sides.  The default wavelet has none below zero (theta_neg = 0); heavy-tailed ones
+//    do, largest just below zero frequency, and take a level band shifted to hold them.
 //  * support: the distance from the kernel's centre beyond which less than support_tol of
 //    its energy (L2) lies.  |psi| is the envelope of an analytic signal, so it is smooth
 //    and sampled on a coarse grid from the kernel's end inwards.
@@ -144,6 +145,7 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
   const int32_t nb = sp->n_bins, j0 = sp->bin_lo;
   sp->band_ok = false;
   sp->theta_hi = 2.0 * M_PI;
+  sp->theta_neg = 0.0;
   sp->support = 0.5 * (double)L;
   if (nb == 0) return;
   double pk = 0.0, energy = 0.0;
@@ -156,24 +158,38 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
   auto env = [&](int64_t m) {   // |G| at half-bin m + 1/2: theta = 2 pi (2m + 1) / (2 L)
     return std::fabs(exact_gain(amp, j0, nb, L, 2 * m + 1, 2 * L));
   };
-  // highest probed half-bin with |G| above the limit
-  int64_t top = -1;
+  // highest probed half-bin with |G| above the limit, on the positive side; on the negative side
+  // (theta = -2 pi (o - 1/2) / L, i.e. half-bin L - o) the largest such offset o.  Beyond the
+  // skirt the probes step geometrically: the extent is taken to the first probe BELOW the limit
+  // after the last one above it.
+  int64_t top = -1, neg = 0;
   const int64_t m_pk = j0 + i_pk, m_skirt = std::min<int64_t>(L - 1, (int64_t)j0 + nb + 2);
   for (int64_t m = m_pk; m <= m_skirt; ++m)
     if (env(m) > lim) top = m;
-  // from the skirt up to Nyquist and from just below 2 pi down to Nyquist, geometric
+  bool pos_to_nyquist = false, neg_to_nyquist = false;
   for (int side = 0; side < 2 && m_skirt < L - 1; ++side) {
     double step = 1.0;
+    bool pending = false;             // the previous probe was above the limit
     for (double off = 1.0; ; off += step, step *= 1.12) {
       const int64_t o = (int64_t)off;
       const int64_t m = side == 0 ? m_skirt + o : L - o;
-      if (side == 0 && m > L / 2) break;
-      if (side == 1 && (m <= L / 2 || m <= m_skirt)) break;
-      if (env(m) > lim) top = std::max(top, m);
+      if (side == 0 && m > L / 2) { if (pending) pos_to_nyquist = true; break; }
+      if (side == 1 && (m <= L / 2 || m <= m_skirt)) { if (pending) neg_to_nyquist = true; break; }
+      const bool above = env(m) > lim;
+      if (side == 0) {
+        if (above) top = std::max(top, m);
+        else if (pending) top = std::max(top, m);   // the edge lies between the two probes
+      } else {
+        if (above || pending) neg = std::max(neg, o);
+      }
+      pending = above;
     }
   }
+  // (a response that still matters at Nyquist wraps round: top >= L / 2 gives theta_hi > pi, no decimation)
+  if (pos_to_nyquist) top = std::max(top, L / 2);
   sp->theta_hi = 2.0 * M_PI * (double)(top + 1) / (double)L;
-  sp->band_ok = sp->theta_hi <= M_PI;
+  sp->theta_neg = neg_to_nyquist ? M_PI : std::min(M_PI, 2.0 * M_PI * (double)neg / (double)L);
+  sp->band_ok = sp->theta_hi + sp->theta_neg <= M_PI;
 
   // |psi(centre + t)|^2 = |(1/L) sum_j A_j e^{i theta_j t}|^2, same on both sides (A real);
   // total energy (1/L) sum A_j^2 (Parseval).  Walk in from t = L/2 until the tails hold
@@ -233,8 +249,8 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
     std::vector<double>& g = gains[n];
     double pk = 0.0;
     for (int k = 0; k < B; ++k) {
-      g[(size_t)k] = std::fabs(exact_gain(hp->amps.data() + sp.amp_offset, sp.bin_lo, sp.n_bins, sp.length, k,
-                                          (int64_t)B * R));
+      g[(size_t)k] = std::fabs(exact_gain(hp->amps.data() + sp.amp_offset, sp.bin_lo, sp.n_bins, sp.length,
+                                          k - lp->band_shift, (int64_t)B * R));
       pk = std::max(pk, g[(size_t)k]);
     }
     if (!(pk > 0.0)) return;
@@ -385,16 +401,74 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     bool moved = false;
     for (ScalePlan& sp : hp->scales) {
       if (sp.method != GCWT_SCALE_SPECTRAL) continue;
-      int r = 2;   // theta_hi <= pi holds here, so R = 2 always fits
-      while (2 * r <= r_cap && sp.theta_hi * (2.0 * r) <= 2.0 * M_PI) r *= 2;
+      const bool two_sided = sp.theta_neg > 0.0;
+      // does the scale's band fit the 2 pi / r of a level of decimation r?  One-sided: [0, theta_hi].
+      // Two-sided: [-theta_neg, theta_hi] inside a band shifted below zero by a whole number of
+      // steps of max(1, r / 16) bins (what the spectrum's k1-major layout can slice), so a step
+      // and a bin of rounding are set aside; only the two-pass level transforms take a shifted slice.
+      auto fits = [&](int r) {
+        if (!two_sided) return sp.theta_hi * (double)r <= 2.0 * M_PI;
+        if (r > kMaxTwoPassDecimation) return false;
+        const int g = std::max(1, r / 16);
+        return (sp.theta_hi + sp.theta_neg) * (double)r + 2.0 * M_PI * (double)(g + 1) / (double)B <= 2.0 * M_PI;
+      };
+      int r = 2;   // one-sided: theta_hi <= pi holds here, so R = 2 always fits
+      while (2 * r <= r_cap && fits(2 * r)) r *= 2;
       sp.decimation = r;
       // decimated samples discarded at each block edge: the kernel's measured support
       int halo = std::max((int)std::ceil(sp.support / (double)r) + halo_margin(), 16);
       if (r == 2) halo += halo & 1;   // keeps halo*R a multiple of 4: 16-byte aligned tile runs
-      if (B - 2 * halo < 32) {        // does not fit the block at the largest decimation it allows
+      if (B - 2 * halo < 32 || (two_sided && !fits(2))) {   // does not fit the block at the largest decimation it allows
         sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
         moved = true;
       }
+    }
+    // Scales with a two-sided band share their level's shift: the bins below zero are the most
+    // any member needs, and every member's upper edge must still fit above them.  Where a
+    // decimation's members do not fit together, the one that asks for the most bins steps
+    // down to the next lower decimation (twice the room) until they do.
+    for (int pass = 0; pass < 64; ++pass) {
+      std::map<int, std::vector<int>> by_r;
+      for (int i = 0; i < prm.n_freqs; ++i)
+        if (hp->scales[i].method == GCWT_SCALE_SPECTRAL) by_r[hp->scales[i].decimation].push_back(i);
+      bool changed = false;
+      for (auto& kv : by_r) {
+        bool any_two_sided = false;
+        for (int i : kv.second) any_two_sided = any_two_sided || hp->scales[i].theta_neg > 0.0;
+        if (!any_two_sided) continue;          // a plain one-sided level: nothing to agree on
+        const int r = kv.first, g = std::max(1, r / 16);
+        const double delta = 2.0 * M_PI / ((double)B * r);
+        int shift = 0, worst = -1;
+        double worst_need = 0.0;
+        for (int i : kv.second) shift = std::max(shift, (int)std::ceil(hp->scales[i].theta_neg / delta));
+        shift = (shift + g - 1) / g * g;
+        for (int i : kv.second) {
+          const double need = std::max(hp->scales[i].theta_hi / delta - (double)(B - shift), 0.0);
+          if (need > 0.0 && need >= worst_need) { worst_need = need; worst = i; }
+        }
+        if (worst < 0) continue;
+        // the member that takes the most room: the widest band of the group
+        int widest = worst;
+        for (int i : kv.second)
+          if (hp->scales[i].theta_neg + hp->scales[i].theta_hi >
+              hp->scales[widest].theta_neg + hp->scales[widest].theta_hi) widest = i;
+        ScalePlan& sp = hp->scales[widest];
+        changed = true;
+        if (r == 2) {
+          sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
+          moved = true;
+        } else {
+          sp.decimation = r / 2;
+          int halo = std::max((int)std::ceil(sp.support / (double)(r / 2)) + halo_margin(), 16);
+          if (r / 2 == 2) halo += halo & 1;
+          if (B - 2 * halo < 32) {
+            sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
+            moved = true;
+          }
+        }
+        break;                       // regroup after every move
+      }
+      if (!changed) break;
     }
     if (!moved) break;
   }
@@ -507,7 +581,10 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     // `support` holds less than support_tol of the kernel's energy), plus two.
     int halo = std::max((int)std::ceil(sp.support / (double)r) + halo_margin(), 16);
     if (r == 2) halo += halo & 1;   // keeps halo*R a multiple of 4: 16-byte aligned tile runs
-    const std::pair<int, int> key(r, split && halo > 16 ? 1 : 0);
+    // Heavy-tailed kernels are long against their band: within one decimation their block halos
+    // range from about 40 to over 100 decimated samples.  Those above 48 form a level of their own
+    // (sharing x_R): the rest keep their longer hop and the production kernel's static row layout.
+    const std::pair<int, int> key(r, sp.theta_neg > 0.0 && halo > 48 ? 2 : (split && halo > 16 ? 1 : 0));
     auto it = level_of.find(key);
     if (it == level_of.end()) {
       LevelPlan lp;
@@ -523,6 +600,31 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     LevelPlan& lp = hp->levels[sp.level];
     lp.scales.push_back(i);
     lp.halo = std::max(lp.halo, halo);
+  }
+  // Band shift of every decimation (the levels of one decimation share x_R, so they share the
+  // shift): the bins below zero frequency its scales need, in steps of max(1, R / 16) bins.  A
+  // member whose upper edge no longer fits (cannot happen for bands that scale with the
+  // frequency, as a wavelet family's do) would be a planning error.
+  {
+    std::map<int, int> shift_of_r;
+    for (const LevelPlan& lp : hp->levels) {
+      const double delta = 2.0 * M_PI / ((double)B * lp.decimation);
+      int& shift = shift_of_r[lp.decimation];
+      for (int i : lp.scales)
+        if (hp->scales[i].theta_neg > 0.0)
+          shift = std::max(shift, (int)std::ceil(hp->scales[i].theta_neg / delta));
+    }
+    for (LevelPlan& lp : hp->levels) {
+      const double delta = 2.0 * M_PI / ((double)B * lp.decimation);
+      const int g = std::max(1, lp.decimation / 16);
+      const int shift = (shift_of_r[lp.decimation] + g - 1) / g * g;
+      lp.band_shift = shift;
+      for (int i : lp.scales)
+        if (hp->scales[i].theta_hi > (double)(B - shift) * delta * (1.0 + 1e-12))
+          return fail(GCWT_ERR_UNSUPPORTED, "internal: a scale's band does not fit its level's shifted band");
+      if (shift > 0 && lp.scales.size() > 256)
+        return fail(GCWT_ERR_UNSUPPORTED, "more than 256 heavy-tailed scales in one decimation level");
+    }
   }
   for (LevelPlan& lp : hp->levels) {
     lp.hop = B - 2 * lp.halo;

@@ -42,10 +42,12 @@ struct ScalePlan {
   int32_t bin_lo = 0, n_bins = 0;
   int64_t amp_offset = 0;
   // measured on the exact response (planner.cpp: analyse_scale)
-  double theta_hi = 0;             // |G| <= band_tol * peak for theta in [theta_hi, 2 pi)
+  double theta_hi = 0;             // |G| <= band_tol * peak for theta in [theta_hi, 2 pi - theta_neg]
+  double theta_neg = 0;            // ... : how far below zero frequency the response still matters (the side
+                                   // lobes of the L-tap truncation; 0 for the default wavelet)
   double support = 0;              // samples either side of the centre that hold all but
                                    // support_tol of the kernel's energy (L2)
-  bool band_ok = false;            // theta_hi <= pi: some decimation R >= 2 is exact to band_tol
+  bool band_ok = false;            // theta_hi + theta_neg <= pi: some decimation R >= 2 is exact to band_tol
   int demod_bin = 0;               // interpolated levels: bin of the level's 256-point grid the scale's
                                    // oversampled output is demodulated by (its band centre; a multiple of q)
 };
@@ -59,6 +61,9 @@ struct LevelPlan {
   int xr_owner = -1;               // first level with this decimation: its x_R is shared (a
                                    // decimation's scales are split by halo into up to two levels)
   int64_t twiddle_offset = 0;      // offset into the level twiddle table (complex elems)
+  int band_shift = 0;              // bins of the level's 256-point grid that lie BELOW zero frequency: the level's
+                                   // band is [-band_shift, 256 - band_shift) * 2 pi / (256 R); x_R is made from that
+                                   // slice of the spectrum (heavy-tailed wavelets; 0 for the default one)
   // Interpolating synthesis (synthi.hip, interp.h; amplitude and power only): the level's scales
   // are made at q x the level's rate and brought to the full rate by a T-tap polyphase FIR.
   int interp_q = 0;                // phases of the 256-point inverse FFT per (block, scale); 0: not interpolated

@@ -36,7 +36,23 @@ namespace gcwt {
 // LDS: 16 x 513 complex + 256 complex + 8 x 320 gains + 256 indices = 77 KB -> two
 // workgroups per CU.  128 VGPRs.
 // ---------------------------------------------------------------------------
-template <int MODE, int NCOL>
+// exp(-2 pi i shift r / (256 R)): what phase r of a level whose band starts `shift` bins below zero
+// carries (shift r < 2^24: exact in float before the division by a power of two)
+__device__ __forceinline__ v2f phase_carrier(int shift, int r, int R) {
+  float sn, cs;
+  sincospif(-2.0f * (float)(shift * r) / (256.0f * (float)R), &sn, &cs);
+  return (v2f){cs, sn};
+}
+
+// WIDE: block halo above 48 (the long, heavy-tailed kernels of a level with a shifted band):
+// every row's place in the block is tested, rows 0 and 15 included in the walk.
+// Levels whose band starts band_shift bins below zero frequency (planner.h): bins are counted
+// from the bottom of the band, so the sample the transform makes at block position m and
+// phase r carries the carrier exp(-2 pi i shift (R (m_b + m) + r) / (256 R)) -- the block's
+// constant goes into its spectrum, the phase's into P, and the position's into the W256
+// twiddles and the order of the exchange planes (the same device as synthi.hip's
+// demodulation): nothing is added to the scale loop.
+template <int MODE, int NCOL, bool WIDE>
 __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   constexpr int kThreads = 16 * NCOL;
   constexpr int kPlane = kThreads + 1;
@@ -54,7 +70,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   const Synth7Level lv = a.levels[it.level];
   const int c = blockIdx.y;               // workspace slot: segment * n_channels + channel
   const int seg = c / a.seg.n_channels, ch = c - seg * a.seg.n_channels;
-  const int R = lv.decimation, lg = lv.log2r, hop = lv.hop, halo = lv.halo;
+  const int R = lv.decimation, lg = lv.log2r, hop = lv.hop, halo = lv.halo, sh = lv.band_shift;
   {
     // The level grids are the union over the batch's segments: leave at once if this
     // group of blocks keeps no sample inside this segment's window (workgroup-uniform).
@@ -76,8 +92,8 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   for (int i = tid; i < lv.n_scales; i += kThreads) sc_lds[i] = scales[i];
 
   if (tid < 256) {
-    // W256^(t j) stored [j][t]: the 16 lanes of a column read consecutive entries
-    const float2 w = a.tw256[((tid & 15) * (tid >> 4)) & 255];
+    // W256^((t - shift) j) stored [j][t]: the 16 lanes of a column read consecutive entries
+    const float2 w = a.tw256[(((tid & 15) - sh) * (tid >> 4)) & 255];
     twl[tid] = (v2f){w.x, w.y};
   }
   // The filter enters as its real gain |H_s[k]|; the half-sample phase that even kernel
@@ -129,16 +145,21 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) v[k1] = fx[colw * 256 + k1 * 16 + (t ^ k1)];
       idft16v(v);
+      // the block's carrier: exp(-2 pi i shift m_b / 256), m_b the block's first decimated sample
+      const int blkx = min(it.blk0 + colw, lv.nblk - 1);
+      const float2 cb = a.tw256[(-(int64_t)sh * ((int64_t)(lv.blk_base + blkx) * hop - halo)) & 255];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const v2f z = v[dft16_pos(j)];
-        xbs[colw * 256 + t + 16 * j] = (v2f){z.x * a.xb_scale, -z.y * a.xb_scale};
+        const v2f xb = (v2f){z.x * a.xb_scale, -z.y * a.xb_scale};
+        xbs[colw * 256 + t + 16 * j] = sh ? cmulv(xb, (v2f){cb.x, cb.y}) : xb;
       }
     }
     __syncthreads();
     const float2* ltw = a.level_tw + lv.tw_offset;
     const float2 b0 = ltw[t * r], st = ltw[16 * r];
     v2f wcur = (v2f){b0.x, b0.y};
+    if (sh) wcur = cmulv(wcur, phase_carrier(sh, r, R));
     const v2f wstep = (v2f){st.x, st.y};
     const v2f* const mine = xbs + blk_l * 256 + t;
 #pragma unroll
@@ -154,6 +175,10 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     const float2* ltw = a.level_tw + lv.tw_offset;
     const float2 b0 = ltw[t * r], st = ltw[16 * r];
     v2f wcur = (v2f){b0.x, b0.y};
+    if (sh) {   // the phase's and the block's carriers (the XB pass knows nothing of the shift)
+      const float2 cb = a.tw256[(-(int64_t)sh * ((int64_t)(lv.blk_base + blk) * hop - halo)) & 255];
+      wcur = cmulv(cmulv(wcur, phase_carrier(sh, r, R)), (v2f){cb.x, cb.y});
+    }
     const v2f wstep = (v2f){st.x, st.y};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -163,7 +188,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     }
   }
   const int sstride = wide ? NCOL : R;
-  v2f* const exw = ex + t * kPlane + (wide ? colw : (blk_l << (4 + lg)) + r);
+  v2f* const exw = ex + ((t - sh) & 15) * kPlane + (wide ? colw : (blk_l << (4 + lg)) + r);
   const int blk_l2 = wide ? 0 : (tid >> (4 + lg));
   const int rem = wide ? tid : (tid & ((16 << lg) - 1));
   const int m2 = wide ? (tid >> kLgN) : (rem >> lg);
@@ -177,6 +202,12 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   const bool deep = halo > 32;
   const bool keep1 = !deep && m2 >= halo - 16, keep14 = !deep && m2 < 32 - halo;
   const bool keep2 = !deep || m2 >= halo - 32, keep13 = !deep || m2 < 48 - halo;
+  // WIDE (halo > 48): row m1 is kept when halo <= 16 m1 + m2 < 256 - halo: bit m1 of `keep_rows`
+  unsigned keep_rows = 0;
+  if (WIDE) {
+#pragma unroll
+    for (int m1 = 0; m1 < 16; ++m1) keep_rows |= (16 * m1 + m2 >= halo && 16 * m1 + m2 < 256 - halo) ? 1u << m1 : 0u;
+  }
 
   // Stores go through a buffer descriptor that covers exactly the samples this launch
   // may write, [w_lo, w_hi) of the segment: anything else -- halo rows (negative offsets
@@ -236,9 +267,10 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         dst, 0, __builtin_amdgcn_readfirstlane(ext_bytes), 0x00020000);
 #pragma unroll
-    for (int m1 = 1; m1 < 15; ++m1) {
+    for (int m1 = 1; m1 < 15; ++m1) {     // (rows 0 and 15 are never kept: halo >= 16)
       const v2f z = v[dft16_pos(m1)];
-      const bool keep = m1 == 1 ? keep1 : m1 == 2 ? keep2 : m1 == 13 ? keep13 : m1 == 14 ? keep14 : true;
+      const bool keep = WIDE ? (keep_rows >> m1) & 1u
+                             : m1 == 1 ? keep1 : m1 == 2 ? keep2 : m1 == 13 ? keep13 : m1 == 14 ? keep14 : true;
       const unsigned vo = voff0 + (unsigned)m1 * vstep;
       if (MODE == GCWT_OUT_COMPLEX_C64) {
         typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -256,7 +288,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   }
 }
 
-template <int NCOL>
+template <int NCOL, bool WIDE>
 static hipError_t launch_synth7_n(int mode, const Synth7Args& a, int n_items, int n_channels,
                                   hipStream_t st) {
   constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 8 * 320 * 4 + 256 * 4;
@@ -265,32 +297,35 @@ static hipError_t launch_synth7_n(int mode, const Synth7Args& a, int n_items, in
   (void)hipGetDevice(&dev_);
   bool& attr_set = attr_done[dev_ & 63];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_AMPLITUDE_F32, NCOL>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_AMPLITUDE_F32, NCOL, WIDE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_POWER_F32, NCOL>,
+    e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_POWER_F32, NCOL, WIDE>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_COMPLEX_C64, NCOL>,
+    e = hipFuncSetAttribute((const void*)k_synth7<GCWT_OUT_COMPLEX_C64, NCOL, WIDE>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid(n_items, n_channels), block(16 * NCOL);
   if (mode == GCWT_OUT_AMPLITUDE_F32)
-    hipLaunchKernelGGL((k_synth7<GCWT_OUT_AMPLITUDE_F32, NCOL>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((k_synth7<GCWT_OUT_AMPLITUDE_F32, NCOL, WIDE>), grid, block, lds, st, a);
   else if (mode == GCWT_OUT_POWER_F32)
-    hipLaunchKernelGGL((k_synth7<GCWT_OUT_POWER_F32, NCOL>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((k_synth7<GCWT_OUT_POWER_F32, NCOL, WIDE>), grid, block, lds, st, a);
   else
-    hipLaunchKernelGGL((k_synth7<GCWT_OUT_COMPLEX_C64, NCOL>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((k_synth7<GCWT_OUT_COMPLEX_C64, NCOL, WIDE>), grid, block, lds, st, a);
   return hipGetLastError();
 }
 
-hipError_t launch_synth7(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
+hipError_t launch_synth7(int mode, int ncol, bool wide_halo, const Synth7Args& a, int n_items, int n_channels,
                          hipStream_t st) {
   if (n_items == 0) return hipSuccess;
-  return ncol == 16 ? launch_synth7_n<16>(mode, a, n_items, n_channels, st)
-                    : launch_synth7_n<32>(mode, a, n_items, n_channels, st);
+  if (wide_halo)
+    return ncol == 16 ? launch_synth7_n<16, true>(mode, a, n_items, n_channels, st)
+                      : launch_synth7_n<32, true>(mode, a, n_items, n_channels, st);
+  return ncol == 16 ? launch_synth7_n<16, false>(mode, a, n_items, n_channels, st)
+                    : launch_synth7_n<32, false>(mode, a, n_items, n_channels, st);
 }
 
 }  // namespace gcwt

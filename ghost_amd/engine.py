@@ -142,8 +142,10 @@ class CwtPlan:
         f64p = C.POINTER(C.c_double)
         check(lib.gcwt_plan_scale_support(self._handle, theta_hi.ctypes.data_as(f64p),
                                           support.ctypes.data_as(f64p), n_bins.ctypes.data_as(i32p)))
+        theta_neg = np.zeros(s, np.float64)
+        check(lib.gcwt_debug_scale_theta_neg(self._handle, theta_neg.ctypes.data_as(f64p)))
         return {"method": method, "decimation": dec, "halo": halo, "hop": hop, "length": length,
-                "theta_hi": theta_hi, "support": support, "n_bins": n_bins}
+                "theta_hi": theta_hi, "theta_neg": theta_neg, "support": support, "n_bins": n_bins}
 
     # -- device -----------------------------------------------------------
     def upload(self):
@@ -231,8 +233,10 @@ class CwtPlan:
             m = C.c_int64()
             check(lib.gcwt_debug_level_info(self._handle, epoch, l, C.byref(d), C.byref(h),
                                             C.byref(hp), C.byref(nb), C.byref(m)))
+            sh = C.c_int32()
+            check(lib.gcwt_debug_level_band_shift(self._handle, l, C.byref(sh)))
             res.append({"decimation": d.value, "halo": h.value, "hop": hp.value,
-                        "nblk": nb.value, "m": m.value})
+                        "nblk": nb.value, "m": m.value, "band_shift": sh.value})
         return res
 
     def debug_interp(self):

@@ -19,6 +19,9 @@ enum {
 int gcwt_debug_level_count(const gcwt_plan* plan);
 int gcwt_debug_level_info(const gcwt_plan* plan, int epoch, int level, int32_t* decimation,
                           int32_t* halo, int32_t* hop, int32_t* nblk, int64_t* m);
+/* Bins of a level's 256-point grid that lie below zero frequency (heavy-tailed wavelets: the level's
+ * band is [-shift, 256 - shift) * 2 pi / (256 R); 0 for the default wavelet). */
+int gcwt_debug_level_band_shift(const gcwt_plan* plan, int level, int32_t* shift);
 /* Segments of equal FFT length are launched together: first segment and size of the batch
  * that `segment` belongs to. */
 int gcwt_debug_batch_of(const gcwt_plan* plan, int segment, int32_t* first, int32_t* count);
@@ -39,6 +42,9 @@ int gcwt_debug_exact_gain(const gcwt_plan* plan, int scale, const int64_t* a, in
 int gcwt_debug_interp_level(const gcwt_plan* plan, int level, int32_t* q, int32_t* factor,
                             double* alpha, double* err_bound, float* coef, int64_t max_floats);
 int gcwt_debug_scale_demod(const gcwt_plan* plan, int32_t* demod);
+/* Per scale: how far below zero frequency (radians per sample) the response of its kernel still
+ * exceeds band_eps of the peak (planner.h: ScalePlan::theta_neg; 0 for the default wavelet). */
+int gcwt_debug_scale_theta_neg(const gcwt_plan* plan, double* theta_neg);
 /* 1 in libghostcwt_measure.so (`make -C ghost_amd/csrc measure`: -DGCWT_MEASURE), the build that
  * carries the measurement hooks -- stores dropped / barriers removed (GHOSTCWT_SYNTH_DROP_STORES,
  * results WRONG), the in-kernel clock probe, the slower k_synth8 (GHOSTCWT_SYNTH_KERNEL=8);

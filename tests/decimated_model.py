@@ -3,7 +3,10 @@
 Per scale the engine's planner picks one of three evaluations of the SAME quantity, the
 convolution with the reference's L-tap kernel:
 
-  spectral   X = FFT_P(x - mean, zero padded); x_R = IFFT_{P/R}(X[0:P/R]) / R;
+  spectral   X = FFT_P(x - mean, zero padded); x_R = IFFT_{P/R}(X[0:P/R]) / R  -- for a level whose
+             band starts `shift` bins of its 256-point grid below zero frequency (heavy-tailed
+             wavelets), IFFT_{P/R}(X[-U : P/R - U]) with U = shift (P/R)/256 and every bin k
+             below standing for the frequency k - shift;
              XB_b = FFT_B(x_R[b*hop - Lh : b*hop - Lh + B]) (circular index);
              y[R*m + r] = IFFT_B(XB_b * H_s(2 pi k/(B R)) * exp(2 pi i k r/(B R)))[m],
              kept for Lh <= m < B - Lh
@@ -74,6 +77,7 @@ def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=25
         plan = CwtPlan(n, 1, fs, freqs_hz, gamma=gamma, beta=beta, epoch_bounds=epoch_bounds,
                        normalization=normalization, order=order)
     si = plan.scale_info()
+    shift_of = {lv["decimation"]: lv["band_shift"] for lv in plan.debug_levels()}
     omegas = orc.hz_to_rad(freqs_hz, fs)
     lengths = orc.morse_lengths(omegas, gamma, beta)
     assert np.array_equal(lengths, si["length"])
@@ -98,18 +102,22 @@ def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=25
                 continue
             R, lh, hop = int(si["decimation"][i]), int(si["halo"][i]), int(si["hop"][i])
             M = p_big // R
+            shift = shift_of[R]
             if R not in xr_cache:
-                xr_cache[R] = ifft(X[:M]) / R
+                U = shift * M // B
+                xr_cache[R] = ifft(X[(np.arange(M) - U) % p_big]) / R      # the engine's x_R: bin u is frequency u - U
             xr = xr_cache[R]
             k = np.arange(B)
-            H = exact_response(2 * np.pi * k / (B * R), om, L, gamma, beta, normalization, order)
-            tw = np.exp(2j * np.pi * np.outer(k, np.arange(R)) / (B * R))
+            H = exact_response(2 * np.pi * (k - shift) / (B * R), om, L, gamma, beta, normalization, order)
+            tw = np.exp(2j * np.pi * np.outer(k - shift, np.arange(R)) / (B * R))
             nblk = int(math.ceil(math.ceil((lead + ne) / R) / hop))
             y = np.zeros(R * nblk * hop, dtype=np.complex128)
             for b in range(nblk):
                 idx = (b * hop - lh + np.arange(B)) % M
                 XB = fft(xr[idx])
                 blk = ifft((XB * H)[:, None] * tw, axis=0)        # [m, r]
+                if shift:   # the carrier of the shifted band: block position and sample within the block
+                    blk = blk * np.exp(-2j * np.pi * shift * ((b * hop - lh) + np.arange(B)) / B)[:, None]
                 y[R * b * hop: R * (b + 1) * hop] = blk[lh:lh + hop].reshape(-1)
             out[i, start:stop] = y[lead:lead + ne]
     return out
@@ -131,6 +139,7 @@ def amplitude_interpolated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=2
     out = np.abs(cwt_decimated(x, fs, freqs_hz, epoch_bounds, gamma, beta, B, plan=plan))
     si, di, levels = plan.scale_info(), plan.debug_interp(), plan.debug_levels()
     by_r = {lv["decimation"]: d for lv, d in zip(levels, di["levels"])}
+    shift_of = {lv["decimation"]: lv["band_shift"] for lv in levels}
     omegas = orc.hz_to_rad(freqs_hz, fs)
     xc = x - x.mean()
     fft_len = {(a, b): p for (a, b, p) in plan.segments()}
@@ -150,9 +159,10 @@ def amplitude_interpolated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=2
             kc = int(di["demod"][i])
             assert kc % q == 0
             M = p_big // R
-            xr = ifft(X[:M]) / R
+            shift = shift_of[R]
+            xr = ifft(X[(np.arange(M) - shift * M // B) % p_big]) / R
             k = np.arange(B)
-            G = exact_gain(2 * np.pi * k / (B * R), om, int(L), gamma, beta)
+            G = exact_gain(2 * np.pi * (k - shift) / (B * R), om, int(L), gamma, beta)
             tw = np.exp(2j * np.pi * np.outer(k, np.arange(q)) / (B * q))            # phase p of bin k
             demod = np.exp(-2j * np.pi * kc * np.arange(B * q) / (B * q))           # bins counted from k_c
             nblk = int(math.ceil(math.ceil((lead + ne) / R) / hop))

@@ -404,8 +404,12 @@ def test_other_family_members_on_the_host(golden):
 def test_planner_measures_each_wavelet():
     """What the planner decides from the measured support of the kernel's response:
     the default wavelet keeps the fast path with hop >= 206 (212, and 206 for the level
-    that takes in the three scales of the thin top decimation); heavy-tailed wavelets
-    (side lobes of the L-tap truncation above band_eps everywhere) leave it entirely."""
+    that takes in the three scales of the thin top decimation).  Heavy-tailed wavelets, whose
+    L-tap truncation leaves side lobes above band_eps below zero frequency: where those die out
+    within a few omega ((3,4), (2,8)) the scale keeps a decimated level whose band is shifted
+    below zero to hold them -- at a lower decimation and a longer block halo than the default
+    wavelet's -- and only the short kernels at the top go to the time domain; where they reach
+    Nyquist ((3,2), (1,5)) the scale leaves the decimated path entirely."""
     fs, f = 1000.0, np.geomspace(200.0, 2.0, 100)
     p = CwtPlan(1000000, 128, fs, f)
     si, info = p.scale_info(), p.info
@@ -420,8 +424,25 @@ def test_planner_measures_each_wavelet():
     for gamma, beta in GB_PAIRS:
         q = CwtPlan(65536, 1, fs, f2, gamma=gamma, beta=beta)
         m, ln = q.scale_info()["method"], q.scale_info()["length"]
+        si2, lv = q.scale_info(), q.debug_levels()
         if (gamma, beta) in ((3, 8), (4, 30)):
             assert (m == _lib.SCALE_SPECTRAL).sum() >= 36, (gamma, beta)
+            assert not si2["theta_neg"][m == _lib.SCALE_SPECTRAL].any() and all(l["band_shift"] == 0 for l in lv)
+        elif (gamma, beta) in ((3, 4), (2, 8)):
+            spec = m == _lib.SCALE_SPECTRAL
+            assert spec.sum() >= 23 and np.all(m[~spec] == _lib.SCALE_DIRECT) and ln[~spec].max() <= 256
+            assert np.all(si2["theta_neg"][spec] > 0) and all(l["band_shift"] > 0 for l in lv)
+            # the band fits the level: [-theta_neg, theta_hi] inside [-shift, 256 - shift) bins
+            for l in lv:
+                mine = spec & (si2["decimation"] == l["decimation"])
+                delta = 2 * np.pi / (256 * l["decimation"])
+                assert np.all(si2["theta_neg"][mine] <= l["band_shift"] * delta * (1 + 1e-12))
+                assert np.all(si2["theta_hi"][mine] <= (256 - l["band_shift"]) * delta * (1 + 1e-12))
+                assert l["band_shift"] % max(1, l["decimation"] // 16) == 0
+            # levels of one decimation share x_R, hence the shift
+            by_r = {}
+            for l in lv:
+                assert by_r.setdefault(l["decimation"], l["band_shift"]) == l["band_shift"]
         else:
             assert not (m == _lib.SCALE_SPECTRAL).any(), (gamma, beta)
             assert np.all(m[ln <= 256] == _lib.SCALE_DIRECT)
