@@ -22,7 +22,10 @@ namespace gcwt {
 constexpr int kInterpTaps = 8;       // T
 constexpr int kInterpMaxFactor = 1024;  // I = R / q at most: a lane's coefficient set is (4 (wave-task mod 4) .. + lane) & (I/4 - 1),
                                         // and a wave's wave-tasks stay in one class mod 4 (synthi.hip)
-constexpr int kInterpCols = 16;         // columns (block, scale slot, phase) of one pass of k_synthi (synthi.hip)
+#ifndef GCWT_SYNTHI_COLS
+#define GCWT_SYNTHI_COLS 16             // (8 and 32 are measurement builds: profiles/r03_synth_study.md)
+#endif
+constexpr int kInterpCols = GCWT_SYNTHI_COLS;   // columns (block, scale slot, phase) of one pass of k_synthi (synthi.hip)
 constexpr int kInterpMaxPhases = kInterpCols;   // q at most
 
 inline double interp_sinc(double x) {   // sin(pi x) / (pi x)

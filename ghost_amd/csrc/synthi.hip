@@ -41,10 +41,7 @@ static_assert(kT == 8, "the FIR loop below is written for 8 taps");
 // Columns per pass.  16 (256 threads, three workgroups and 12 waves per CU, up to 168 VGPRs: the
 // persistent operand, the FIR coefficients and both transforms' working sets fit without spills)
 // or 32 (512 threads, two workgroups and 16 waves per CU, 128 VGPRs).
-#ifndef GCWT_SYNTHI_COLS
-#define GCWT_SYNTHI_COLS 16
-#endif
-constexpr int kColsI = GCWT_SYNTHI_COLS;
+constexpr int kColsI = kInterpCols;
 constexpr int kLgColsI = kColsI == 32 ? 5 : kColsI == 16 ? 4 : 3;
 constexpr int kThreadsI = 16 * kColsI;
 constexpr int kWavesI = kThreadsI / 64;
@@ -187,7 +184,8 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   // which 4 of the I sub-sample positions a lane-task k covers: k mod (I / 4).  k = 64 wt + lane
   // and a wave's wave-tasks advance by kWavesI = 4 at a time, so up to I / 4 = 256 the set depends
   // on the lane and on wt mod 4 only -- constant along a wave's run through a z slot
-  static_assert(kWavesI == 4 && kInterpMaxFactor <= 1024, "a wave's lane-tasks keep their class mod I / 4");
+  static_assert(GCWT_SYNTHI_COLS != 16 || (kWavesI == 4 && kInterpMaxFactor <= 1024),
+                "a wave's lane-tasks keep their class mod I / 4 (the 8- and 32-column measurement builds: I <= 256 only)");
   const float* const coef_lv = a.coef + lv.coef_offset;
   constexpr int kElem = 1;
   const unsigned ext_bytes = w_len > 0 ? (unsigned)(w_len * (4 * kElem)) : 0u;
