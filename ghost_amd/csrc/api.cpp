@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -111,7 +112,11 @@ struct gcwt_plan {
   float2* d_xs = nullptr;     // [C][xs_stride] shifted slice of the spectrum of the level in hand (levels with a
   int64_t xs_stride = 0;      //   band shift: heavy-tailed wavelets); xs_stride = the largest such level's M
   float2* d_z = nullptr;      // [C][max_p]   full-band scales: spectrum * response, then its IFFT
-  float2* d_hfull = nullptr;  // [max_p]      full-band response of the scale in hand
+  float2* d_hfull = nullptr;  // [max_p]      full-band response of the scale in hand (when the cache below is full)
+  // Full-band responses are an O(n_bins P) fp64 evaluation each: computed once per (scale, FFT
+  // length) and kept on the device while they fit 4 GiB, reused by every later batch and execute.
+  std::map<std::pair<int, int>, float2*> hfull_cache;
+  int64_t hfull_cache_bytes = 0;
   float2* d_tw4096 = nullptr; // exp(-2 pi i j/4096), j < 2048
   float2* d_tw256 = nullptr;  // exp(+2 pi i q/256)
   float2* d_level_tw = nullptr;
@@ -164,6 +169,9 @@ void free_dev(gcwt_plan* p) {
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
+  for (auto& kv : p->hfull_cache) (void)hipFree(kv.second);
+  p->hfull_cache.clear();
+  p->hfull_cache_bytes = 0;
   p->host_out.release();
   for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.items7w); fr(e.levels7); fr(e.items_i); fr(e.levels_i); }
   p->ep_dev.clear();
@@ -849,8 +857,27 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     // full-band scales: W = IFFT_P(X H_s), one scale at a time for every slot of the batch
     for (int i = 0; i < S && hp.n_fullband > 0; ++i) {
       if (hp.scales[i].method != GCWT_SCALE_FULLBAND) continue;
-      RUN(ST_FULLBAND, launch_fullband_filter(p->d_hfull, p->d_bank_sc, i, p->d_amps, P1, st));
-      RUN(ST_FULLBAND, launch_fullband_mul(p->d_x, p->d_hfull, p->d_z, P, slots, st));
+      const float2* h = nullptr;
+      const auto cached = p->hfull_cache.find({i, P1});
+      if (cached != p->hfull_cache.end()) {
+        h = cached->second;
+      } else {
+        float2* dst = p->d_hfull;
+        const int64_t bytes = (int64_t)sizeof(float2) * P;
+        if (p->hfull_cache_bytes + bytes <= ((int64_t)4 << 30)) {
+          float2* keep = nullptr;
+          if (hipMalloc((void**)&keep, (size_t)bytes) == hipSuccess) {
+            p->hfull_cache[{i, P1}] = keep;
+            p->hfull_cache_bytes += bytes;
+            dst = keep;
+          } else {
+            (void)hipGetLastError();           // no room: compute into the scratch row as before
+          }
+        }
+        RUN(ST_FULLBAND, launch_fullband_filter(dst, p->d_bank_sc, i, p->d_amps, P1, st));
+        h = dst;
+      }
+      RUN(ST_FULLBAND, launch_fullband_mul(p->d_x, h, p->d_z, P, slots, st));
       // inverse: rows over k2 with the W_P^(k1 n2) twiddle, then columns over k1 -> natural order
       RUN(ST_FULLBAND, launch_fft_rows(+1, p->d_z, p->d_z, kRowLen, P1, kRowLen, kRowLen, P, P,
                                        P1 > 1 ? P : 0, p->d_tw4096, p->d_tw256, 1.0f, slots, st));

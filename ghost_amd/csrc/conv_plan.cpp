@@ -86,8 +86,10 @@ int gcwt_conv_plan_create(gcwt_conv_plan** out, int64_t n, int64_t m, int32_t n_
   if (fft_log2 != 0 && (fft_log2 < 12 || fft_log2 > 22)) return fail(GCWT_ERR_INVALID, "fft_log2 must be 0 or 12..22");
   int64_t P = kRowLen;
   if (fft_log2 == 0) {
-    // one FFT when the whole convolution fits 2^22 points, else overlap-save chunks of 2^22
-    while (P < n + m - 1 && P < ((int64_t)1 << 22)) P <<= 1;
+    // One FFT when the whole convolution fits: chunk 0 of the overlap-save layout starts with
+    // m - 1 zeros of history, so a single chunk needs n + 2 (m - 1) points (with only n + m - 1 the
+    // work would be two full-size chunks).  Else overlap-save chunks of 2^22.
+    while (P < n + 2 * (m - 1) && P < ((int64_t)1 << 22)) P <<= 1;
   } else {
     P = (int64_t)1 << fft_log2;
   }

@@ -164,8 +164,11 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
   // after the last one above it.
   int64_t top = -1, neg = 0;
   const int64_t m_pk = j0 + i_pk, m_skirt = std::min<int64_t>(L - 1, (int64_t)j0 + nb + 2);
-  for (int64_t m = m_pk; m <= m_skirt; ++m)
-    if (env(m) > lim) top = m;
+  // (every half-bin of the skirt -- unless the kernel keeps thousands of bins ('energy' members with
+  // very long kernels: each probe costs n_bins evaluations), then about a thousand of them)
+  const int64_t skirt_step = std::max<int64_t>(1, (int64_t)nb / 1024);
+  for (int64_t m = m_pk; m <= m_skirt; m += skirt_step)
+    if (env(m) > lim) top = std::min<int64_t>(m + skirt_step - 1, m_skirt);
   bool pos_to_nyquist = false, neg_to_nyquist = false;
   for (int side = 0; side < 2 && m_skirt < L - 1; ++side) {
     double step = 1.0;

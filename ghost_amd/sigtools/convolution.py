@@ -44,16 +44,18 @@ def _check_mode(mode, n, m):
 class ConvPlan:
     """Convolution of ``n_channels`` real signals of ``n_samples`` with one kernel of
     ``kernel_len`` taps.  ``fft_length``: None (the smallest power of two that holds the
-    whole convolution, at most 2^22; longer signals are chunked) or a power of two
-    4096 .. 2^22, the reference's ``fft_length`` (chunks of ``fft_length - kernel_len + 1``)."""
+    whole convolution as one overlap-save chunk, ``n + 2 (m - 1)`` points, at most 2^22; longer
+    signals are chunked) or the reference's ``fft_length`` (chunks of ``fft_length - kernel_len + 1``):
+    any value up to 2^22 is taken and rounded UP to a power of two of at least 4096 (the
+    reference accepts any length; the result does not depend on it)."""
 
     def __init__(self, n_samples, kernel_len, n_channels=1, *, fft_length=None, device=-1):
         self._handle = _vp()
         log2 = 0
         if fft_length is not None:
-            log2 = int(fft_length).bit_length() - 1
-            if (1 << log2) != int(fft_length) or not 12 <= log2 <= 22:
-                raise ValueError("fft_length must be a power of two between 4096 and 2**22")
+            if int(fft_length) < 1 or int(fft_length) > (1 << 22):
+                raise ValueError("fft_length must be between 1 and 2**22")
+            log2 = max(12, (int(fft_length) - 1).bit_length())      # rounded up to a power of two >= 4096
         check(lib.gcwt_conv_plan_create(C.byref(self._handle), int(n_samples), int(kernel_len),
                                         int(n_channels), log2, int(device)))
         self.n_samples, self.kernel_len, self.n_channels = int(n_samples), int(kernel_len), int(n_channels)
@@ -96,6 +98,11 @@ class ConvPlan:
         if np.iscomplexobj(x):
             raise TypeError("signal must be real")
         one = x.ndim == 1
+        want = (self.n_samples,) if one else (self.n_channels, self.n_samples)
+        if x.shape != want or (one and self.n_channels != 1):
+            raise ValueError("signals must have shape (%d, %d)%s, got %s"
+                             % (self.n_channels, self.n_samples,
+                                " or (%d,)" % self.n_samples if self.n_channels == 1 else "", x.shape))
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.n_channels, self.n_samples)
         out = np.empty((self.n_channels, self.count(mode)), dtype=np.complex64)
         check(lib.gcwt_conv_plan_execute(self._handle, x.ctypes.data_as(_vp), _MODES[mode],

@@ -205,7 +205,8 @@ int gcwt_get_timings(const gcwt_plan* plan, gcwt_timings* t);
  * reused: it owns its stream, FFT tables, the kernel's spectrum and the workspace.  Signals
  * longer than one FFT run as overlap-save chunks (the reference's chunked overlap-add,
  * convolution.py:68-77); chunks and channels are batched.  fft_log2: 0 = the smallest
- * 2^k >= n + m - 1, at most 2^22; or 12..22 to fix the FFT length F = 2^fft_log2 (the
+ * 2^k >= n + 2 (m - 1) -- one overlap-save chunk (m - 1 samples of history, then the signal and
+ * its tail) holds the whole convolution -- at most 2^22; or 12..22 to fix the FFT length F = 2^fft_log2 (the
  * reference's fft_length: chunks of F - m + 1 samples, convolution.py:70). */
 typedef struct gcwt_conv_plan gcwt_conv_plan;
 int gcwt_conv_plan_create(gcwt_conv_plan** out, int64_t n, int64_t m, int32_t n_channels,

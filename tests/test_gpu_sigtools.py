@@ -96,10 +96,21 @@ def test_conv_plan_is_a_reusable_batched_operator():
     from oracle import ghost_oracle as orc
     ref = orc.overlap_add_convolve(x2, k2, mode="same").real
     assert got.shape == (n2,) and np.abs(got - ref).max() <= 5e-6 * np.abs(ref).max()
-    with pytest.raises(ValueError):
-        ConvPlan(100, 10, fft_length=3000)
+    # any fft_length the reference accepts is taken (rounded up to a power of two >= 4096: the
+    # result does not depend on it); one shorter than the kernel is refused as the reference does
+    odd = ConvPlan(n, m, C, fft_length=3000).set_kernel(k)
+    assert odd.fft_length == 4096 and _close(odd.execute(x, mode="same")[0], convolve(x[0], k, mode="same"))
+    assert ConvPlan(n, m, C, fft_length=5000).fft_length == 8192
     with pytest.raises(ValueError):
         fastconv_hip(x[0], k, fft_length=512)
+    # one chunk holds the whole convolution whenever n + 2 (m - 1) fits the FFT
+    tight = ConvPlan(65000, 500, 1)
+    assert tight.fft_length == 131072 and tight.n_chunks == 1
+    # shapes are checked before anything is reshaped
+    with pytest.raises(ValueError, match="signals must have shape"):
+        plan.execute(x[0])
+    with pytest.raises(ValueError, match="signals must have shape"):
+        plan.execute(x[:, :100])
 
 
 def test_chirpz_dft():
