@@ -285,6 +285,10 @@ def run_rank(args):
                          "(GHOSTCWT_ALLOW_SHARED_GPU=1 to rehearse on one)" % (world, ndev))
     dev = local % ndev
     check(lib.gcwt_set_device(dev))
+    numa, n_pinned = (None, 0)
+    if world > 1:                                    # each rank beside its own GPU (best effort)
+        from ghost_amd.dist import pin_to_device_numa
+        numa, n_pinned = pin_to_device_numa(dev)
 
     cfg5 = args.config == 5
     fs = 30000.0 if cfg5 else 1000.0
@@ -386,6 +390,7 @@ def run_rank(args):
             sustained["steps"], sustained["seconds"] = n_s, round(time.perf_counter() - t_s, 2)
     per_rank = comm.allgather(own / args.steps * 1e3)
     devices = comm.allgather(dev)
+    numas = comm.allgather(-1 if numa is None else numa)
 
     if rank == 0:
         units = world * C * N * args.steps
@@ -490,7 +495,9 @@ def run_rank(args):
             slow = int(np.argmax(per_rank))
             line["ranks"] = {"ms_per_step": [round(v, 4) for v in per_rank],
                              "min": round(min(per_rank), 4), "max": round(max(per_rank), 4), "rank_of_max": slow,
-                             "devices": [int(d) for d in devices]}
+                             "devices": [int(d) for d in devices],
+                             "numa_nodes": [int(v) for v in numas],   # -1: not pinned (sysfs silent or outside the affinity)
+                             "pinned_cpus_rank0": n_pinned}
         if cfg5 and not args.no_check:
             line["checked"], line["check"] = check_config5(plan, xbuf, ring[0], base, distinct, fs, freqs, N, S,
                                                            group, segs)

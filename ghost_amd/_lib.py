@@ -63,6 +63,7 @@ def _load():
         "gcwt_last_error": (C.c_char_p, []),
         "gcwt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
         "gcwt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+        "gcwt_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
         "gcwt_set_device": (C.c_int, [C.c_int]),
         "gcwt_device_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
         "gcwt_device_free": (C.c_int, [vp]),

@@ -253,6 +253,12 @@ int gcwt_device_name(int device, char* buf, size_t buflen) {
   return GCWT_OK;
 }
 
+int gcwt_device_pci_bus_id(int device, char* buf, size_t buflen) {
+  if (!buf || buflen < 16) return set_err(GCWT_ERR_INVALID, "buffer of at least 16 bytes needed");
+  HIP_TRY(hipDeviceGetPCIBusId(buf, (int)buflen, device));
+  return GCWT_OK;
+}
+
 int gcwt_set_device(int device) { HIP_TRY(hipSetDevice(device)); return GCWT_OK; }
 
 int gcwt_device_memory(size_t* free_bytes, size_t* total_bytes) {

@@ -14,7 +14,7 @@ import os
 import tempfile
 import time
 
-__all__ = ["Comm", "shard_channels", "shard_time_blocks", "env_rank"]
+__all__ = ["Comm", "shard_channels", "shard_time_blocks", "env_rank", "parse_cpulist", "pin_to_device_numa"]
 
 
 def env_rank():
@@ -51,6 +51,41 @@ def shard_time_blocks(segments, rank, world):
     if not mine:
         return lo_t, lo_t
     return mine[0][0], mine[-1][1]
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist) -> {0, 1, 2, 3, 8, 10, 11}."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_device_numa(device, sysfs="/sys"):
+    """Keeps this process's threads on the host cores of the GPU's NUMA node (multi-rank runs:
+    the rank's launch thread and its staging copies stay beside its device).  Best effort:
+    returns (numa_node, n_cpus) or (None, 0) when sysfs does not say or the node's cores are
+    outside the process's current affinity (a container's CPU share is never widened)."""
+    try:
+        from ._lib import lib, check
+        buf = C.create_string_buffer(64)
+        check(lib.gcwt_device_pci_bus_id(int(device), buf, 64))
+        bus = buf.value.decode().lower()
+        with open(os.path.join(sysfs, "bus/pci/devices", bus, "numa_node")) as fh:
+            node = int(fh.read().strip())
+        if node < 0:
+            return None, 0
+        with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)) as fh:
+            cpus = parse_cpulist(fh.read()) & set(os.sched_getaffinity(0))
+        if not cpus:
+            return None, 0
+        os.sched_setaffinity(0, cpus)
+        return node, len(cpus)
+    except Exception:
+        return None, 0
 
 
 def _launcher_start():

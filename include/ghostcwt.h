@@ -128,6 +128,9 @@ int gcwt_abi_version(void);
 const char* gcwt_last_error(void);
 int gcwt_device_count(int* count);
 int gcwt_device_name(int device, char* buf, size_t buflen);
+/* PCI bus id of a device ("0000:c1:00.0"): a launcher looks its NUMA node up in sysfs to pin the
+ * rank's host threads beside its GPU. */
+int gcwt_device_pci_bus_id(int device, char* buf, size_t buflen);
 int gcwt_set_device(int device);
 int gcwt_device_malloc(void** ptr, size_t bytes);
 int gcwt_device_free(void* ptr);

@@ -97,6 +97,15 @@ def test_time_block_shards_tile_the_recording():
     assert shard_time_blocks([], 0, 2) == (0, 0)
 
 
+def test_cpulist_parser_and_pinning_is_best_effort(tmp_path):
+    from ghost_amd.dist import parse_cpulist, pin_to_device_numa
+    assert parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert parse_cpulist("5") == {5} and parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    assert pin_to_device_numa(0, sysfs=str(tmp_path)) == (None, 0)     # no GPU / no sysfs entry: nothing changes
+    assert os.sched_getaffinity(0) == before
+
+
 def test_single_rank_comm_is_a_noop():
     c = Comm(0, 1)
     assert c.backend == "single"
