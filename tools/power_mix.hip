@@ -2,7 +2,8 @@
 // chip-wide (2 x 512 threads per CU, 4 waves per SIMD) for a few seconds so that
 // `rocm-smi --showpower --showclocks` can be sampled beside it (tools/power_mix.sh), and
 // prints the rate it reached.  Modes: pk_fma, pk_add, sqrt, lds_w64, lds_r64, lds_r128, exchange
-// (16 w64 + barrier + 16 r64 + barrier), store (nt dword stores, 256 B per wave), mix (the
+// (16 w64 + barrier + 16 r64 + barrier), dpp_xpose (the same 16 x 16 transpose over the lanes of a DPP
+// row, no LDS), store (nt dword stores, 256 B per wave), mix (the
 // kernel's per-scale mix without stores), mixstore (with 14 stores per scale).
 //   hipcc -O3 --offload-arch=gfx950 tools/power_mix.hip -o /tmp/pmix && /tmp/pmix pk_fma 5
 #include <hip/hip_runtime.h>
@@ -15,8 +16,8 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-enum { PK_FMA, PK_ADD, SQRT, LDS_W64, LDS_R64, LDS_R128, EXCHANGE, STORE, MIX, MIXSTORE, STORE_DEF, STORE4, STORE4_DEF, STORE2, DPP_ADD, ADD, N_MODES };
-static const char* kNames[N_MODES] = {"pk_fma", "pk_add", "sqrt", "lds_w64", "lds_r64", "lds_r128", "exchange", "store", "mix", "mixstore", "store_def", "store4", "store4_def", "store2", "dpp_add", "add"};
+enum { PK_FMA, PK_ADD, SQRT, LDS_W64, LDS_R64, LDS_R128, EXCHANGE, STORE, MIX, MIXSTORE, STORE_DEF, STORE4, STORE4_DEF, STORE2, DPP_ADD, ADD, DPP_XPOSE, N_MODES };
+static const char* kNames[N_MODES] = {"pk_fma", "pk_add", "sqrt", "lds_w64", "lds_r64", "lds_r128", "exchange", "store", "mix", "mixstore", "store_def", "store4", "store4_def", "store2", "dpp_add", "add", "dpp_xpose"};
 
 constexpr int kPlane = 513;
 
@@ -57,6 +58,38 @@ __global__ void __launch_bounds__(512) k_run(float* out, float* sink, int iters,
           asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(a[(i + 1) & 15].x));
           asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(a[i].y) : "v"(a[(i + 1) & 15].y));
         }
+    }
+    if (MODE == DPP_XPOSE) {
+      // The 16 x 16 transpose of k_synth7's exchange (thread t of a column holds 16 complex values,
+      // wants element t of every other thread's) WITHOUT LDS: four butterfly stages over the 16
+      // lanes of a DPP row, lane bit s against register-index bit s.  Per stage and register pair:
+      // pick what goes (v_cndmask), move it to the partner lane t ^ (1 << s) (quad_perm for s = 0, 1;
+      // row_shl:4 / row_shr:4 under complementary bank masks for s = 2; row_ror:8 for s = 3), put
+      // what came into the right register (2 v_cndmask) -- per 32-bit half of the complex value.
+#define XP_HALF(X, Y, MOVS)                                                                        \
+      { float snd, rcv;                                                                             \
+        asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(snd) : "v"(Y), "v"(X), "s"(hi));         \
+        MOVS                                                                                        \
+        asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(X) : "v"(rcv), "s"(hi));                 \
+        asm volatile("v_cndmask_b32 %0, %1, %0, %2" : "+v"(Y) : "v"(rcv), "s"(hi)); }
+#define XP_Q(PERM) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:" PERM " row_mask:0xf bank_mask:0xf" : "=v"(rcv) : "v"(snd));
+#define XP_4 asm volatile("v_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(rcv) : "v"(snd)); \
+             asm volatile("v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(rcv) : "v"(snd));
+#define XP_8 asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(rcv) : "v"(snd));
+#pragma unroll
+      for (int sbit = 0; sbit < 4; ++sbit) {
+        const unsigned long long hi = __builtin_amdgcn_ballot_w64((tid >> sbit) & 1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (j & (1 << sbit)) continue;
+          v2f& X = a[j];
+          v2f& Y = a[j | (1 << sbit)];
+          if (sbit == 0) { XP_HALF(X.x, Y.x, XP_Q("[1,0,3,2]")) XP_HALF(X.y, Y.y, XP_Q("[1,0,3,2]")) }
+          else if (sbit == 1) { XP_HALF(X.x, Y.x, XP_Q("[2,3,0,1]")) XP_HALF(X.y, Y.y, XP_Q("[2,3,0,1]")) }
+          else if (sbit == 2) { XP_HALF(X.x, Y.x, rcv = 0.f; XP_4) XP_HALF(X.y, Y.y, rcv = 0.f; XP_4) }
+          else { XP_HALF(X.x, Y.x, XP_8) XP_HALF(X.y, Y.y, XP_8) }
+        }
+      }
     }
     if (MODE == ADD) {                   // plain f32 add, 2 per pair
 #pragma unroll
@@ -164,7 +197,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&sink, (size_t)2048 * grid * 512 * 4));   // 2 GiB: 2048 rows of one float per thread
   if (!strcmp(mode, "idle")) { printf("idle\n"); fflush(stdout); std::this_thread::sleep_for(std::chrono::duration<double>(seconds)); return 0; }
 #define CASE(M) if (!strcmp(mode, kNames[M])) { drive<M>(seconds, out, sink, clk, grid); return 0; }
-  CASE(PK_FMA) CASE(PK_ADD) CASE(SQRT) CASE(LDS_W64) CASE(LDS_R64) CASE(LDS_R128) CASE(EXCHANGE) CASE(STORE) CASE(MIX) CASE(MIXSTORE) CASE(STORE_DEF) CASE(STORE4) CASE(STORE4_DEF) CASE(STORE2) CASE(DPP_ADD) CASE(ADD)
+  CASE(PK_FMA) CASE(PK_ADD) CASE(SQRT) CASE(LDS_W64) CASE(LDS_R64) CASE(LDS_R128) CASE(EXCHANGE) CASE(STORE) CASE(MIX) CASE(MIXSTORE) CASE(STORE_DEF) CASE(STORE4) CASE(STORE4_DEF) CASE(STORE2) CASE(DPP_ADD) CASE(ADD) CASE(DPP_XPOSE)
   printf("unknown mode %s\n", mode);
   return 1;
 }
