@@ -47,3 +47,13 @@ shutil.copy(newest("stats/*/*kernel_stats.csv"), os.path.join(root, "profiles", 
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(root, "profiles", rnd + "_bench.json"))
 print("synthesis (%s): fetch %.1f MB (x2 corrected) + write %.1f MB = %d bytes per step" %
       (" + ".join(keys), 2 * f_kb / 1024, w_kb / 1024, out["k_synth_hbm_bytes_per_launch"]))
+
+# config 5: the line and the kernel stats of the same command
+import glob as _g
+c5 = os.path.join(src, "bench_config5.json")
+if os.path.exists(c5) and os.path.getsize(c5) > 0:
+    shutil.copy(c5, os.path.join(root, "profiles", rnd + "_bench_config5.json"))
+    st5 = _g.glob(os.path.join(src, "stats5/*/*kernel_stats.csv"))
+    if st5:
+        shutil.copy(max(st5, key=os.path.getmtime), os.path.join(root, "profiles", rnd + "_config5_kernel_stats.csv"))
+    print("config 5 line and kernel stats copied")
