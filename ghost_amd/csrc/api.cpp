@@ -547,7 +547,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       if (const char* e = getenv("GHOSTCWT_INTERP_LGNB")) lgnb = std::min(std::max(atoi(e), 0), 2);   // (A/B runs; read at upload)
       while (lgnb > 0 && (lp.interp_q << lgnb) > kInterpMaxPhases) --lgnb;
       // what k_synthi's indexing assumes (synthi.hip); the planner guarantees it
-      if (lp.interp_q < 4 || lp.interp_q > kInterpMaxPhases || (lp.interp_q & (lp.interp_q - 1)) ||
+      if (lp.interp_q < 2 || lp.interp_q > kInterpMaxPhases || (lp.interp_q & (lp.interp_q - 1)) ||
           lp.interp_factor * lp.interp_q != lp.decimation || lp.interp_factor < 4 ||
           lp.interp_factor > kInterpMaxFactor || lp.scales.size() > 256 || lp.halo < 16 ||
           lp.hop != hp.block - 2 * lp.halo || lp.hop < 1 || hp.block != 256)

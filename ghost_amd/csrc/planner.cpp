@@ -219,26 +219,26 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
 
 // Decides whether a level is made by the interpolating synthesis and, if so, designs it: the
 // demodulation bin of every scale (the centre of the bins where its gain exceeds 1e-4 of the
-// peak, a multiple of q), the design band (the widest such half-band of the level), the
-// coefficient tables of both kernel-length parities, and -- from the scales' own gains -- a bound
-// on the error the interpolation adds: max over bins of |G_s[k]| / peak times the interpolator's
-// error at that bin's distance from the demodulation centre.  A level whose bound exceeds
-// interp_tol stays on the FFT-per-sample kernels.
+// peak, a multiple of q), the envelope of the level's gains against the distance from that
+// centre, the coefficient tables of both kernel-length parities fitted under that envelope
+// (interp.h: design_interp_weighted), and -- from the scales' own gains -- a bound on the error
+// the interpolation adds: max over bins of |G_s[k]| / peak times the interpolator's error at that
+// bin's distance from the demodulation centre.  A level whose bound exceeds interp_tol stays on
+// the FFT-per-sample kernels.
 static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
   constexpr int T = kInterpTaps;
   const int B = hp->block, R = lp->decimation;
   lp->interp_q = 0;
   if (hp->prm.out_mode == GCWT_OUT_COMPLEX_C64) return;   // the demodulation would have to be undone per sample
-  // Below R = 16 the q = 4 phases through the block transform are half or more of the
-  // FFT-per-sample work and the interpolation does not pay (at R = 16 it breaks even per level
-  // and wins 2 % on the headline mix: profiles/r03_synth_study.md); GHOSTCWT_INTERP_MIN_R moves
-  // the line (A/B runs).
-  int min_r = 16;
-  if (const char* e = getenv("GHOSTCWT_INTERP_MIN_R")) min_r = std::max(16, atoi(e));
-  if (R < min_r || lp->scales.empty()) return;
-  int q = 4;
+  // Below R = 16 the q = 2 phases through the block transform are a quarter or more of the
+  // FFT-per-sample work and the interpolation does not pay (profiles/r03_synth_study.md);
+  // GHOSTCWT_INTERP_MIN_R moves the line, GHOSTCWT_INTERP_Q sets the phases per scale (A/B runs).
+  int min_r = 16, q = 2;
+  if (const char* e = getenv("GHOSTCWT_INTERP_MIN_R")) min_r = std::max(8, atoi(e));
+  if (const char* e = getenv("GHOSTCWT_INTERP_Q")) q = atoi(e) == 4 ? 4 : 2;
+  if (R < min_r || R < 4 * q || lp->scales.empty()) return;     // I = R / q >= 4: a lane makes 4 samples of one interval
   while (R / q > kInterpMaxFactor) q *= 2;
-  if (q > kInterpMaxPhases) return;                        // a pass of the kernel has 16 columns (R <= 4096)
+  if (q > kInterpMaxPhases) return;                        // a pass of the kernel has 16 columns
   if (lp->scales.size() > 256) return;                     // the kernel parks a level's scale list in LDS
   const int I = R / q;
   for (int sidx : lp->scales)
@@ -246,7 +246,7 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
                                                            // probes below would take seconds
   // gains on the level's grid, band edges and demodulation bins
   std::vector<std::vector<double>> gains(lp->scales.size(), std::vector<double>((size_t)B));
-  double hw_max = 1.0;
+  std::vector<double> genv((size_t)2 * B, 0.0);            // envelope against the distance d from the centre: index d + B
   for (size_t n = 0; n < lp->scales.size(); ++n) {
     ScalePlan& sp = hp->scales[lp->scales[n]];
     std::vector<double>& g = gains[n];
@@ -265,15 +265,24 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
     int kc = ((klo + khi + q) / (2 * q)) * q;              // nearest multiple of q to the middle
     kc = std::min(std::max(kc, 0), B - q);
     sp.demod_bin = kc;
-    hw_max = std::max(hw_max, (double)std::max(khi - kc, kc - klo) + 1.0);
+    for (int k = 0; k < B; ++k) genv[(size_t)(k - kc + B)] = std::max(genv[(size_t)(k - kc + B)], g[(size_t)k]);
   }
-  const double alpha = hw_max / (0.5 * B) / (double)q;
-  if (alpha > 0.45) return;
+  for (int d = 1; d < B; ++d) {                            // real coefficients: the error is even in d
+    const double m = std::max(genv[(size_t)(B + d)], genv[(size_t)(B - d)]);
+    genv[(size_t)(B + d)] = genv[(size_t)(B - d)] = m;
+  }
+  double hw = 0.0;
+  for (int d = 0; d < B; ++d)
+    if (genv[(size_t)(B + d)] > 1e-4) hw = (double)d + 1.0;
+  const double alpha = hw / (0.5 * B) / (double)q;
+  if (alpha > 0.9) return;
   std::vector<double> c((size_t)2 * I * T);
-  design_interp(T, I, alpha, 0.0, c.data());
-  design_interp(T, I, alpha, 0.5, c.data() + (size_t)I * T);
-  // interpolator error against the distance d (bins of the level's grid) from the demodulation
-  // centre, worst over a few sub-sample positions of both parities
+  design_interp_weighted(T, I, q, B, genv.data(), 0.0, c.data());
+  design_interp_weighted(T, I, q, B, genv.data(), 0.5, c.data() + (size_t)I * T);
+  // the tables the kernel uses are float32: bound the error with what it will multiply by
+  for (double& v : c) v = (double)(float)v;
+  // interpolator error against the distance d from the demodulation centre, worst over a few
+  // sub-sample positions of both parities
   std::vector<double> err((size_t)2 * B, 0.0);             // d = -B .. B-1 at index d + B
   const int n_probe = std::min(I, 8);
   for (int par = 0; par < 2; ++par)
@@ -282,8 +291,8 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
       const double tau = ((double)rho - 0.5 * par) / (double)I;
       const double* cr = c.data() + ((size_t)par * I + rho) * T;
       for (int d = -B; d < B; ++d) {
-        double th = 2.0 * M_PI * (double)d / ((double)B * q);
-        th = std::remainder(th, 2.0 * M_PI);
+        if (!(genv[(size_t)(d + B)] > 0.0)) continue;
+        const double th = std::remainder(2.0 * M_PI * (double)d / ((double)B * q), 2.0 * M_PI);
         err[(size_t)(d + B)] = std::max(err[(size_t)(d + B)], interp_error_at(T, cr, tau, th));
       }
     }

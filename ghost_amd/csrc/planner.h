@@ -127,7 +127,7 @@ struct HostPlan {
   int64_t level_twiddle_total = 0;
   int64_t max_p = 0, max_xr = 0, max_xb = 0;
   std::vector<float> interp_coef;  // interpolator coefficients of every interpolated level
-  double interp_tol = 1.5e-7;      // largest interp_err a level may have and still be interpolated
+  double interp_tol = 2e-7;        // largest interp_err a level may have and still be interpolated
   int max_fft_log2 = 22;
   int max_batch = 1;               // largest batch_count in the plan: workspace slots per channel
   size_t out_elem_bytes = 4;

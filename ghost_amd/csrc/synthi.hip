@@ -48,7 +48,7 @@ constexpr int kWavesI = kThreadsI / 64;
 constexpr int kPlaneI = kThreadsI + 1;
 constexpr int kZPad = 4;                         // v2f entries between the slots of the z buffer: their
                                                  // writes fall on different banks
-constexpr int kSlotsMax = kColsI / 4;            // q >= 4
+constexpr int kSlotsMax = kColsI / 2;            // z slots and scale slots of a pass: q >= 2
 static_assert(kColsI == kInterpCols, "the host cuts the passes for this many columns (interp.h)");
 constexpr int kZElems = 256 * kColsI + kSlotsMax * kZPad;     // z buffer
 constexpr int kExElems = kZElems > 16 * kPlaneI ? kZElems : 16 * kPlaneI;   // ... in place of the 16 exchange planes
@@ -200,10 +200,10 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
     const int b0 = pass * ns;
     const bool has_next = pass + 1 < pass_end;
     // next pass's gains: loaded now (nothing of this pass is in flight yet), parked after the exchange
-    float nxt[4];
+    float nxt[kSlotsMax];
     if (has_next) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kSlotsMax; ++u) {
         const int i = tid + kThreadsI * u;
         if (i < ns * 256) {
           const int sb = min(b0 + ns + (i >> 8), n_scales - 1);
@@ -218,9 +218,16 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
       const int kc = aux_lds[bs] & 0xffff;
       const float4* const hs = reinterpret_cast<const float4*>(stage + slot * kGainRowI + t * 20);
       v2f v[16];
-      // (16 - j_hi) in the entry's top byte: first-pass inputs j >= j_hi are left out (kernels.h);
-      // a wave's four columns belong to one slot (q >= 4), so the choice is wave-uniform
-      switch ((unsigned)__builtin_amdgcn_readfirstlane(entry) >> 24) {
+      // (16 - j_hi) in the entry's top byte: first-pass inputs j >= j_hi are left out (kernels.h).
+      // A wave's four columns belong to one scale slot (q >= 4) or two (q = 2): the smaller window
+      // cut of the two, so that the choice is wave-uniform
+      unsigned cut = (unsigned)__builtin_amdgcn_readfirstlane(entry) >> 24;
+      if (q == 2) {
+        const int other = sc_lds[min(b0 + (((colw ^ 2) >> lgq) & (ns - 1)), n_scales - 1)];
+        cut = min(cut, (unsigned)__builtin_amdgcn_readfirstlane(min((unsigned)entry >> 24, (unsigned)other >> 24)));
+        cut = (unsigned)__builtin_amdgcn_readfirstlane(cut);
+      }
+      switch (cut) {
 #define GCWT_WINDOW(hi) case 16 - (hi): gain_first_layer<hi>(v, pw, hs); break;
         GCWT_WINDOW(15) GCWT_WINDOW(14) GCWT_WINDOW(13) GCWT_WINDOW(12) GCWT_WINDOW(11) GCWT_WINDOW(10) GCWT_WINDOW(9)
 #undef GCWT_WINDOW
@@ -243,7 +250,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
     __syncthreads();
     if (has_next) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kSlotsMax; ++u) {
         const int i = tid + kThreadsI * u;
         if (i < ns * 256) stage[stage_slot(i)] = nxt[u];
       }

@@ -157,7 +157,7 @@ def amplitude_interpolated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=2
             q, I, lh, hop = d["q"], d["factor"], int(si["halo"][i]), int(si["hop"][i])
             coef = d["coef"][1 if int(L) % 2 == 0 else 0].astype(np.float64)   # [I][8]
             kc = int(di["demod"][i])
-            assert kc % q == 0
+            assert kc % q == 0, (kc, q)
             M = p_big // R
             shift = shift_of[R]
             xr = ifft(X[(np.arange(M) - shift * M // B) % p_big]) / R
