@@ -169,7 +169,7 @@ class PowerSampler:
     thread that only reads sysfs (hwmon power1_average / power1_input, freq1_input; no HIP call,
     no subprocess of a GPU tool)."""
 
-    def __init__(self, period=0.02):
+    def __init__(self, period=0.02, pci_bus_id=None):
         import glob
         self.period, self.rows, self._stop, self._th = period, [], False, None
         self.cards = []
@@ -178,7 +178,13 @@ class PowerSampler:
             if pw:
                 self.cards.append({"hw": hw, "power": os.path.join(hw, pw[0]),
                                    "sclk": os.path.join(hw, "freq1_input"),
-                                   "cap": os.path.join(hw, "power1_cap")})
+                                   "cap": os.path.join(hw, "power1_cap"),
+                                   "pci": os.path.basename(os.path.realpath(os.path.join(hw, "..", ".."))).lower()})
+        # this rank's own GPU when sysfs names it (a host has eight); else the busiest card is reported
+        mine = [c for c in self.cards if pci_bus_id and c["pci"] == pci_bus_id.lower()]
+        self.matched = bool(mine)
+        if mine:
+            self.cards = mine
 
     @staticmethod
     def _read(path):
@@ -218,7 +224,8 @@ class PowerSampler:
                         "power_cap_w": round(cap / 1e6, 1) if cap else None,
                         "sclk_ghz": round(sum(ck) / len(ck) / 1e9, 3) if ck else None,
                         "sclk_ghz_min": round(min(ck) / 1e9, 3) if ck else None,
-                        "samples": len(pw), "source": c["hw"]}
+                        "samples": len(pw), "source": c["hw"],
+                        "card": "the rank's device (PCI %s)" % c["pci"] if self.matched else "busiest card seen"}
         return best
 
 
@@ -357,7 +364,14 @@ def run_rank(args):
     for _ in range(args.warmup):
         step({})
     check(lib.gcwt_device_synchronize())
-    sampler = PowerSampler() if rank == 0 else None
+    bus = None
+    try:
+        buf = ctypes.create_string_buffer(64)
+        check(lib.gcwt_device_pci_bus_id(dev, buf, 64))
+        bus = buf.value.decode()
+    except Exception:
+        pass
+    sampler = PowerSampler(pci_bus_id=bus) if rank == 0 else None
     comm.barrier()
     stats = {}
     if sampler:
@@ -375,7 +389,7 @@ def run_rank(args):
     if rank == 0 and world == 1 and power and args.sustain > 0:
         # hwmon's power reading is a moving average that lags a 0.1 s burst: the same step is run
         # for `--sustain` seconds more, AFTER and OUTSIDE the timed region, and sampled again
-        s2 = PowerSampler()
+        s2 = PowerSampler(pci_bus_id=bus)
         t_s = time.perf_counter()
         time.sleep(0.0)
         n_s = 0
