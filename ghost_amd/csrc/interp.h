@@ -89,39 +89,45 @@ struct TallQR {
 // unweighted fit on a band this buys two taps or a factor two in oversampling:
 //   q = 4: 6 taps 5e-8 .. 7e-8 (8 taps unweighted: 4e-8);  q = 2: 8 taps 9e-8 .. 1.3e-7.
 inline void design_interp_weighted(int T, int I, int q, int B, const double* genv, double shift, double* c) {
+  // every second bin: the envelope is smooth on that scale and the demodulation centres are even
   std::vector<double> th, ge;
-  for (int d = -B; d < B; ++d) {
-    if (!(genv[d + B] > 1e-12)) continue;
+  for (int d = -B; d < B; d += 2) {
+    const double g = std::max(genv[d + B], d + 1 < B ? genv[d + 1 + B] : 0.0);
+    if (!(g > 1e-12)) continue;
     th.push_back(std::remainder(2.0 * M_PI * (double)d / ((double)B * q), 2.0 * M_PI));
-    ge.push_back(genv[d + B]);
+    ge.push_back(g);
   }
   const int n = (int)th.size();
   if (n == 0) { for (int i = 0; i < I * T; ++i) c[i] = 0.0; return; }
   std::vector<double> w = ge, mat((size_t)2 * n * T), rhs((size_t)2 * n), x((size_t)T);
+  std::vector<double> cs((size_t)n * T), sn((size_t)n * T);   // e^{i theta (j - T/2 + 1)}: the same in every pass
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < T; ++j) {
+      const double ph = th[(size_t)i] * (double)(j - (T / 2 - 1));
+      cs[(size_t)i * T + j] = std::cos(ph);
+      sn[(size_t)i * T + j] = std::sin(ph);
+    }
   TallQR qr;
   auto build = [&]() {
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < T; ++j) {
-        const double ph = th[(size_t)i] * (double)(j - (T / 2 - 1));
-        mat[(size_t)i * T + j] = w[(size_t)i] * std::cos(ph);
-        mat[(size_t)(n + i) * T + j] = w[(size_t)i] * std::sin(ph);
+        mat[(size_t)i * T + j] = w[(size_t)i] * cs[(size_t)i * T + j];
+        mat[(size_t)(n + i) * T + j] = w[(size_t)i] * sn[(size_t)i * T + j];
       }
     qr.factor(mat, 2 * n, T);
   };
-  auto solve_tau = [&](double tau, double* out) {
-    for (int i = 0; i < n; ++i) {
-      rhs[(size_t)i] = w[(size_t)i] * std::cos(th[(size_t)i] * tau);
-      rhs[(size_t)(n + i)] = w[(size_t)i] * std::sin(th[(size_t)i] * tau);
-    }
-    qr.solve(rhs, out);
-  };
-  for (int it = 0; it < 30; ++it) {            // Lawson: weights towards the minimax fit at tau = 1/2
+  std::vector<double> half_c((size_t)n), half_s((size_t)n);
+  for (int i = 0; i < n; ++i) { half_c[(size_t)i] = std::cos(0.5 * th[(size_t)i]); half_s[(size_t)i] = std::sin(0.5 * th[(size_t)i]); }
+  for (int it = 0; it < 16; ++it) {            // Lawson: weights towards the minimax fit at tau = 1/2
     build();
-    solve_tau(0.5, x.data());
+    for (int i = 0; i < n; ++i) { rhs[(size_t)i] = w[(size_t)i] * half_c[(size_t)i]; rhs[(size_t)(n + i)] = w[(size_t)i] * half_s[(size_t)i]; }
+    qr.solve(rhs, x.data());
     double emax = 0.0;
     std::vector<double> e((size_t)n);
     for (int i = 0; i < n; ++i) {
-      e[(size_t)i] = ge[(size_t)i] * interp_error_at_fwd(T, x.data(), 0.5, th[(size_t)i]);
+      double re = -half_c[(size_t)i], im = -half_s[(size_t)i];
+      for (int j = 0; j < T; ++j) { re += x[(size_t)j] * cs[(size_t)i * T + j]; im += x[(size_t)j] * sn[(size_t)i * T + j]; }
+      e[(size_t)i] = ge[(size_t)i] * std::sqrt(re * re + im * im);
       emax = std::max(emax, e[(size_t)i]);
     }
     if (!(emax > 0.0)) break;
@@ -133,7 +139,24 @@ inline void design_interp_weighted(int T, int I, int q, int B, const double* gen
     for (int i = 0; i < n; ++i) w[(size_t)i] /= wmax;
   }
   build();
-  for (int rho = 0; rho < I; ++rho) solve_tau(((double)rho - shift) / (double)I, c + (size_t)rho * T);
+  // e^{i theta tau} for tau = (rho - shift) / I by rotation from one sub-sample position to the next
+  std::vector<double> pc((size_t)n), ps((size_t)n), dc((size_t)n), ds((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    pc[(size_t)i] = std::cos(-th[(size_t)i] * shift / (double)I);
+    ps[(size_t)i] = std::sin(-th[(size_t)i] * shift / (double)I);
+    dc[(size_t)i] = std::cos(th[(size_t)i] / (double)I);
+    ds[(size_t)i] = std::sin(th[(size_t)i] / (double)I);
+  }
+  for (int rho = 0; rho < I; ++rho) {
+    for (int i = 0; i < n; ++i) {
+      rhs[(size_t)i] = w[(size_t)i] * pc[(size_t)i];
+      rhs[(size_t)(n + i)] = w[(size_t)i] * ps[(size_t)i];
+      const double nc = pc[(size_t)i] * dc[(size_t)i] - ps[(size_t)i] * ds[(size_t)i];
+      ps[(size_t)i] = pc[(size_t)i] * ds[(size_t)i] + ps[(size_t)i] * dc[(size_t)i];
+      pc[(size_t)i] = nc;
+    }
+    qr.solve(rhs, c + (size_t)rho * T);
+  }
 }
 
 // |sum_j c_j e^{i theta (j - T/2 + 1)} - e^{i theta tau}| : what the interpolator does to a

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <map>
+#include <mutex>
 
 namespace gcwt {
 
@@ -251,9 +252,16 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
     ScalePlan& sp = hp->scales[lp->scales[n]];
     std::vector<double>& g = gains[n];
     double pk = 0.0;
+    // (where the kept spectrum samples are more than a few bins of the L-point grid away the response
+    // is side lobes of the truncation, below 1e-6 of the peak for every wavelet that is decimated at
+    // all: zero for the purposes of this design, and two thirds of the evaluations saved)
+    const double bin_per_k = (double)sp.length / ((double)B * R);        // L-grid bins per level bin
+    const double lo_k = ((double)sp.bin_lo - 6.0) / bin_per_k + lp->band_shift;
+    const double hi_k = ((double)(sp.bin_lo + sp.n_bins) + 6.0) / bin_per_k + lp->band_shift;
     for (int k = 0; k < B; ++k) {
-      g[(size_t)k] = std::fabs(exact_gain(hp->amps.data() + sp.amp_offset, sp.bin_lo, sp.n_bins, sp.length,
-                                          k - lp->band_shift, (int64_t)B * R));
+      g[(size_t)k] = ((double)k < lo_k || (double)k > hi_k) ? 0.0
+                     : std::fabs(exact_gain(hp->amps.data() + sp.amp_offset, sp.bin_lo, sp.n_bins, sp.length,
+                                            k - lp->band_shift, (int64_t)B * R));
       pk = std::max(pk, g[(size_t)k]);
     }
     if (!(pk > 0.0)) return;
@@ -276,9 +284,26 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
     if (genv[(size_t)(B + d)] > 1e-4) hw = (double)d + 1.0;
   const double alpha = hw / (0.5 * B) / (double)q;
   if (alpha > 0.9) return;
+  // The same level geometry comes back with every plan of a recording (one transform() per call):
+  // a small process-wide cache keyed by what the design depends on -- the envelope, to float
+  // precision -- saves the fit (the bound below is recomputed: it depends on the scales).
   std::vector<double> c((size_t)2 * I * T);
-  design_interp_weighted(T, I, q, B, genv.data(), 0.0, c.data());
-  design_interp_weighted(T, I, q, B, genv.data(), 0.5, c.data() + (size_t)I * T);
+  {
+    static std::mutex mu;
+    static std::map<std::vector<float>, std::vector<double>> cache;
+    std::vector<float> key{(float)T, (float)I, (float)q, (float)B};
+    for (double v : genv) key.push_back((float)v);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+      design_interp_weighted(T, I, q, B, genv.data(), 0.0, c.data());
+      design_interp_weighted(T, I, q, B, genv.data(), 0.5, c.data() + (size_t)I * T);
+      if (cache.size() >= 64) cache.clear();
+      cache.emplace(std::move(key), c);
+    } else {
+      c = it->second;
+    }
+  }
   // the tables the kernel uses are float32: bound the error with what it will multiply by
   for (double& v : c) v = (double)(float)v;
   // interpolator error against the distance d from the demodulation centre, worst over a few
