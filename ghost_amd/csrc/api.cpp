@@ -421,7 +421,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   if ((rc = dev_alloc(&p->d_bank, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_gain, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_psi, (size_t)hp.direct_total))) return bail(rc);
-  {   // every kernel is followed by zero taps up to a multiple of 8 (+8): k_direct reads whole groups
+  {   // zero taps in front of every kernel and behind it up to a multiple of 8 (+8): k_direct reads whole groups
     hipError_t hz = hipMemsetAsync(p->d_psi, 0, sizeof(float2) * (size_t)std::max<int64_t>(1, hp.direct_total), p->stream);
     if (hz != hipSuccess) return bail(hip_err(hz, "psi reset"));
   }
@@ -460,7 +460,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
               s.method == GCWT_SCALE_SPECTRAL ? 1 : 0,
               s.method == GCWT_SCALE_SPECTRAL ? hp.levels[s.level].band_shift : 0, 0};
     if (s.method == GCWT_SCALE_DIRECT)
-      dsc[s.direct_index] = {s.omega, s.length, s.amp_offset, s.direct_offset, i, s.bin_lo, s.n_bins, 0};
+      dsc[s.direct_index] = {s.omega, s.length, s.amp_offset, s.direct_offset, i, s.bin_lo, s.n_bins,
+                              direct_front_pad(s.length)};
   }
   if ((rc = upload_vec(&p->d_bank_sc, bsc, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_direct_sc, dsc, p->stream))) return bail(rc);
@@ -1069,7 +1070,7 @@ int gcwt_direct_kernel(gcwt_plan* p, int scale, float* psi) {
   if (s.method != GCWT_SCALE_DIRECT) return set_err(GCWT_ERR_INVALID, "not a direct scale");
   int rc = gcwt_plan_upload(p);
   if (rc) return rc;
-  HIP_TRY(hipMemcpy(psi, p->d_psi + s.direct_offset, sizeof(float2) * (size_t)s.length,
+  HIP_TRY(hipMemcpy(psi, p->d_psi + s.direct_offset + direct_front_pad(s.length), sizeof(float2) * (size_t)s.length,
                     hipMemcpyDeviceToHost));
   return GCWT_OK;
 }

@@ -38,8 +38,12 @@ struct DirectScale {
   int64_t amp_offset;   // kept spectrum samples A_j: amps[amp_offset .. + n_bins), bins bin_lo ..
   int64_t offset;       // into the psi buffer
   int32_t scale;        // output row
-  int32_t bin_lo, n_bins, pad;
+  int32_t bin_lo, n_bins;
+  int32_t front;        // zero taps in front of the kernel in the psi buffer (direct_front_pad)
 };
+
+// k_direct wants (L-1)/2 + front = 7 (mod 8): see the kernel's header
+inline int direct_front_pad(int64_t length) { return (int)((7 - (length - 1) / 2) & 7); }
 
 // Segments launched together (planner.h: batches).  blockIdx.y = segment * n_channels +
 // channel; every workspace array simply has n_channels * n_segments "channels", only the

@@ -17,6 +17,7 @@
 
 #include "kernels.h"
 #include "morse_exact.h"
+#include "synth_math.h"
 
 namespace gcwt {
 
@@ -278,7 +279,7 @@ __global__ void k_build_direct(cf* __restrict__ psi, const DirectScale* __restri
     re += a * cs;
     im += a * sn;
   }
-  psi[p.offset + n] = make_float2((float)(re / (double)L), (float)(im / (double)L));
+  psi[p.offset + p.front + n] = make_float2((float)(re / (double)L), (float)(im / (double)L));
 }
 
 // ---------------------------------------------------------------------------
@@ -936,21 +937,58 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
 // ---------------------------------------------------------------------------
 // Direct scales: W[n] = sum_j (x[n + (L-1)/2 - j] - mean) psi[j] inside the epoch
 // (convolution.py:68-87 'same' crop; transforms.py:202-204), for kernels of up to
-// kDirectTaps taps.
+// kDirectMaxLen taps.
 //
 // One workgroup owns kDirectTile consecutive output samples of one (epoch, channel): it
 // parks the samples those outputs need (tile + half the longest kernel on either side,
 // mean removed, zero outside the epoch) in LDS once and walks over ALL direct scales.
-// A thread computes 8 consecutive outputs; taps go in groups of 8, so the 15 samples a
-// group needs sit in registers with static indices (64 complex-by-real FMAs per 8 LDS
-// reads), and the taps themselves are wave-uniform: scalar loads, SGPR operands.  LDS
-// element i lives at i + i/8, which spreads the lanes' stride-8 reads over all banks.
-// psi of a scale is padded with zeros to a multiple of 8 taps (+8).
+// A thread computes 8 consecutive outputs as 8 (re, im) accumulator pairs; taps go in groups
+// of 8, and a group needs the 15 samples x[b .. b+14], b = first output + top - 8 g - 7.
+// The kernel of a scale is stored behind `front` = (7 - top) mod 8 zero taps
+// (direct_front_pad), which makes b a multiple of 8 for every thread and group: the window is
+// two aligned 8-sample chunks, the lower one new in each group (two ds_read_b128 with no
+// address arithmetic; chunks sit 12 words apart, so the 16 lanes of a b128 access hit
+// distinct banks) and the upper one the previous group's lower chunk (two groups per trip,
+// roles swapped, no copies).  A tap is wave-uniform -- an SGPR pair from a scalar load -- and
+// one v_pk_fma_f32 adds sample * (re, im) to an accumulator pair, the sample broadcast to
+// both halves by op_sel: 64 packed FMAs per 8 taps and nothing else on the vector pipe.
+// Results leave through a wave-private LDS transposition, so that a wave stores 1 KB runs
+// (dwordx4 per lane, or 256 B runs of dwords when the row is not 16-byte aligned there)
+// instead of 32-byte pieces per lane.
+// psi of a scale: front zeros + L taps + zeros up to a multiple of 8 (+8).
 // grid (ceil(longest range / kDirectTile), 1, n_epochs * C): up to 16 epochs per launch
 // ---------------------------------------------------------------------------
 constexpr int kDirectTile = 2048;     // outputs per workgroup: 256 threads x 8
 
-__device__ __forceinline__ int direct_pad(int i) { return i + (i >> 3); }
+__device__ __forceinline__ int direct_chunk(int c) { return 12 * c; }   // word offset of chunk c
+__device__ __forceinline__ int direct_stage(int f) { return f + ((f >> 6) << 2); }
+
+template <int HI>   // acc += w[HI] * k, w = one of the two samples of the register pair
+__device__ __forceinline__ void direct_fma(v2f& acc, v2f w, v2f k) {
+  if constexpr (HI == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "s"(k));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "s"(k));
+}
+
+// 8 taps x 8 outputs: window element i (0..14) is lo[i] for i < 8, hi[i - 8] above
+__device__ __forceinline__ void direct_group(v2f (&acc)[8], const v4f& l0, const v4f& l1, const v4f& h0,
+                                             const v4f& h1, const cf* __restrict__ taps) {
+  const v2f wp[8] = {{l0.x, l0.y}, {l0.z, l0.w}, {l1.x, l1.y}, {l1.z, l1.w},
+                     {h0.x, h0.y}, {h0.z, h0.w}, {h1.x, h1.y}, {h1.z, h1.w}};
+  v2f k[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { const cf t = taps[u]; k[u] = v2f{t.x, t.y}; }   // wave-uniform: scalar loads
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int i = 7 - u + o;
+      if ((i & 1) == 0) direct_fma<0>(acc[o], wp[i >> 1], k[u]);
+      else direct_fma<1>(acc[o], wp[i >> 1], k[u]);
+    }
+  }
+}
 
 template <int MODE>
 __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, float* __restrict__ out,
@@ -961,8 +999,9 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
                                                 const DirectEpochs eps, int64_t col0,
                                                 int64_t row_len, int halo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* const tile = reinterpret_cast<float*>(smem);
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
+  constexpr int kStageWave = 512 * kElem + 32 * kElem;        // floats of one wave's transposition area
+  float* const tile = reinterpret_cast<float*>(smem);
   const int e = blockIdx.z / eps.n_channels, c = blockIdx.z - e * eps.n_channels;
   const int64_t epoch_start = eps.epoch_start[e], epoch_len = eps.epoch_len[e];
   const int64_t g0 = eps.g_lo[e] + (int64_t)blockIdx.x * kDirectTile;   // first output, recording index
@@ -970,53 +1009,80 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
   const int64_t base = g0 - epoch_start;                               // epoch-local index of output 0
   const double mean = sums[c] * inv_n;      // subtracted in fp64
   const float* xe = x + (int64_t)c * n_samples + epoch_start;
-  // tile[i] = sample base - halo + i of the epoch
+  // sample base - halo + i of the epoch is element i & 7 of chunk i >> 3
   const int n_tile = kDirectTile + 2 * halo;
   for (int i = threadIdx.x; i < n_tile; i += 256) {
     const int64_t m = base - halo + i;
-    tile[direct_pad(i)] = m >= 0 && m < epoch_len ? (float)((double)xe[m] - mean) : 0.f;
+    tile[direct_chunk(i >> 3) + (i & 7)] = m >= 0 && m < epoch_len ? (float)((double)xe[m] - mean) : 0.f;
   }
   __syncthreads();
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const stage = tile + direct_chunk(n_tile >> 3) + wave * kStageWave;
+  const int64_t wave_left = (eps.g_hi[e] - g0 - 512 * wave) * kElem;    // floats of this wave inside the range
   for (int d = 0; d < n_direct; ++d) {
     const DirectScale p = sc[d];
-    const cf* const taps = psi + p.offset;
-    const int top = (int)((p.length - 1) / 2);
-    // output o of this thread reads tile[q0 + o - j] for tap j
-    const int q0 = 8 * tid + top + halo;
-    float ar[8], ai[8], w[15];
+    const cf* taps = psi + p.offset;
+    const int top = (int)((p.length - 1) / 2) + p.front;            // = 7 (mod 8)
+    const int n_groups = (int)((p.length + p.front + 7) >> 3);
+    // output o of this thread reads sample q0 + o - j of the tile for tap j; q0 + 1 starts a chunk
+    const float* w_ptr = tile + direct_chunk((8 * tid + top + halo + 1) >> 3);
+    v2f acc[8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) ar[o] = ai[o] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) w[i + 8] = tile[direct_pad(q0 + 1 + i)];   // indices q0+1 .. q0+7
-    const int n_groups = (int)((p.length + 7) >> 3);
-    for (int g = 0; g < n_groups; ++g) {
-      const int jg = 8 * g;
-      // w[i] = tile[q0 - jg - 7 + i], i < 15: the upper 7 come from the previous group
-#pragma unroll
-      for (int i = 0; i < 7; ++i) w[i + 8] = g == 0 ? w[i + 8] : w[i];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) w[i] = tile[direct_pad(q0 - jg - 7 + i)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const cf k = taps[jg + u];                // wave-uniform: scalar load
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-          ar[o] = fmaf(w[7 - u + o], k.x, ar[o]);
-          ai[o] = fmaf(w[7 - u + o], k.y, ai[o]);
-        }
+    for (int o = 0; o < 8; ++o) acc[o] = v2f{0.f, 0.f};
+    v4f a0, a1;
+    v4f b0 = *reinterpret_cast<const v4f*>(w_ptr), b1 = *reinterpret_cast<const v4f*>(w_ptr + 4);
+    for (int g = 0; g < n_groups; g += 2) {
+      w_ptr -= 12;
+      a0 = *reinterpret_cast<const v4f*>(w_ptr);
+      a1 = *reinterpret_cast<const v4f*>(w_ptr + 4);
+      direct_group(acc, a0, a1, b0, b1, taps);
+      if (g + 1 < n_groups) {
+        w_ptr -= 12;
+        b0 = *reinterpret_cast<const v4f*>(w_ptr);
+        b1 = *reinterpret_cast<const v4f*>(w_ptr + 4);
+        direct_group(acc, b0, b1, a0, a1, taps + 8);
       }
+      taps += 16;
     }
-    float* o_row = out + (((int64_t)c * n_scales + p.scale) * row_len + (g0 - col0) + 8 * tid) * kElem;
-    const int64_t left = eps.g_hi[e] - g0 - 8 * tid;     // outputs of this thread inside the range
+    // this thread's 8 * kElem floats, then the wave's 512 * kElem floats in runs of 4 per lane
+    float v[8 * kElem];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-      if (o < left) {
-        if (MODE == GCWT_OUT_AMPLITUDE_F32) o_row[o] = sqrtf(ar[o] * ar[o] + ai[o] * ai[o]);
-        else if (MODE == GCWT_OUT_POWER_F32) o_row[o] = ar[o] * ar[o] + ai[o] * ai[o];
-        else { o_row[2 * o] = ar[o]; o_row[2 * o + 1] = ai[o]; }
+      if (MODE == GCWT_OUT_AMPLITUDE_F32) v[o] = sqrtf(acc[o].x * acc[o].x + acc[o].y * acc[o].y);
+      else if (MODE == GCWT_OUT_POWER_F32) v[o] = acc[o].x * acc[o].x + acc[o].y * acc[o].y;
+      else { v[2 * o] = acc[o].x; v[2 * o + 1] = acc[o].y; }
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * kElem; ++i)
+      *reinterpret_cast<v4f*>(stage + direct_stage(lane * 8 * kElem + 4 * i)) =
+          v4f{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* const o_row = out + (((int64_t)c * n_scales + p.scale) * row_len + (g0 - col0) + 512 * wave) * kElem;
+    const bool aligned = (reinterpret_cast<uintptr_t>(o_row) & 15) == 0;     // wave-uniform
+    if (aligned) {
+#pragma unroll
+      for (int i = 0; i < 2 * kElem; ++i) {
+        const int f = 256 * i + 4 * lane;
+        const v4f r = *reinterpret_cast<const v4f*>(stage + direct_stage(f));
+        if (f + 4 <= wave_left) __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(o_row + f));
+        else {
+          if (f < wave_left) o_row[f] = r.x;
+          if (f + 1 < wave_left) o_row[f + 1] = r.y;
+          if (f + 2 < wave_left) o_row[f + 2] = r.z;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8 * kElem; ++i) {
+        const int f = 64 * i + lane;
+        const float r = stage[direct_stage(f)];
+        if (f < wave_left) __builtin_nontemporal_store(r, o_row + f);
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1388,8 +1454,10 @@ hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, co
   if (n_direct == 0 || n_epochs == 0 || longest <= 0) return hipSuccess;
   // samples either side of a tile that its outputs reach: half the longest kernel, and the
   // zero-padded tail of the last group of 8 taps
-  const int halo = (int)(((max_len / 2 + 1 + 8) + 7) & ~7);
-  const size_t lds = sizeof(float) * (size_t)((kDirectTile + 2 * halo) * 9 / 8 + 16);
+  // (front zeros included: top + front + 1 <= halo and L - top + 6 <= halo)
+  const int halo = (int)(((max_len / 2 + 9) + 7) & ~7);
+  const int elem = mode == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
+  const size_t lds = sizeof(float) * (size_t)((kDirectTile + 2 * halo) / 8 * 12 + 4 * 544 * elem);
   dim3 grid((unsigned)((longest + kDirectTile - 1) / kDirectTile), 1, eps.n_channels * n_epochs), block(256);
 #define GCWT_DIRECT(M)                                                                       \
   hipLaunchKernelGGL((k_direct<M>), grid, block, lds, st, x, out, psi, sc, n_direct, sums,   \

@@ -556,7 +556,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     if (sp.method == GCWT_SCALE_DIRECT) {
       sp.direct_index = hp->n_direct++;
       sp.direct_offset = hp->direct_total;
-      hp->direct_total += ((sp.length + 7) & ~(int64_t)7) + 8;   // zero-padded to whole groups of 8 taps
+      hp->direct_total += ((sp.length + 7 + 7) & ~(int64_t)7) + 8;   // up to 7 zero taps in front, whole groups of 8
     } else if (sp.method == GCWT_SCALE_FULLBAND) {
       sp.fullband_index = hp->n_fullband++;
     }

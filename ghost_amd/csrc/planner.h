@@ -25,7 +25,7 @@ constexpr int kMaxTwoPassDecimation = 256;   // above it the level IFFT uses the
 constexpr int kSynthCols = 16;     // columns (block, r) per batch of the 16-column kernel
 constexpr int kSynthWide = 32;      // columns per batch of the production kernel
 constexpr int kDirectMaxLen = 256;  // longest kernel the time-domain path takes (beyond it one FFT
-                                    // convolution per scale is cheaper: ~9 us per tap vs ~2 ms per scale at 128 ch x 1e6)
+                                    // convolution per scale is cheaper: ~6.5 us per tap vs ~2 ms per scale at 128 ch x 1e6)
 
 struct ScalePlan {
   double freq_hz = 0, omega = 0;   // omega = f / (fs/2) * pi   (transforms.py:408-410)

@@ -998,3 +998,43 @@ def test_split_levels_option(monkeypatch):
     assert (np.abs(got - ref) / scale).max() < 2e-6
     oracle = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f) for c in range(2)])
     assert rel_err(got, oracle).max() < TOL
+
+
+def test_time_domain_kernel_every_alignment_and_edge():
+    """The time-domain kernel stores a scale's taps behind (7 - (L-1)//2) mod 8 zeros and works
+    in groups of 8 taps, two groups per trip (csrc/kernels.hip: k_direct): lengths covering
+    every residue and both parities of the group count, kernels up to the longest it takes,
+    all output modes, tiles that end inside the range, and block requests whose first column
+    is not a multiple of four samples (the store path without 16-byte alignment)."""
+    from ghost_amd.engine import CwtPlan
+    fs, n = 1000.0, 6200                           # three tiles of 2048 outputs + a ragged tail
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((3, n)) + np.array([[0.7], [-2.0], [0.0]])).astype(np.float32)
+    # Morse(3, 20): one frequency per kernel length 33 .. 48 (highest frequency of each length)
+    grid = np.linspace(0.30 * fs, 0.46 * fs, 4001)
+    lens = orc.morse_lengths(orc.hz_to_rad(grid, fs))
+    f_short = np.array([grid[lens == L].max() for L in range(33, 49) if np.any(lens == L)])[::-1]
+    assert len(f_short) >= 14
+    for gamma, beta, freqs in [(3.0, 20.0, f_short), (2.0, 2.0, np.array([330.0, 97.0, 60.0, 40.0, 26.0, 15.0]))]:
+        eb = np.array([[0, 2501], [2503, n]])
+        ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, freqs, eb, gamma=gamma, beta=beta)
+                        for c in range(3)])
+        scale = np.abs(ref).max(axis=2, keepdims=True)
+        for output in ("complex", "amplitude", "power"):
+            p = CwtPlan(n, 3, fs, freqs, gamma=gamma, beta=beta, epoch_bounds=eb, output=output)
+            si = p.scale_info()
+            direct = si["method"] == 1
+            assert direct.sum() >= 3, (beta, si["method"])
+            if beta == 20.0:
+                assert len({int((L - 1) // 2) % 8 for L in si["length"][direct]}) == 8
+            else:
+                assert si["length"][direct].max() > 230 and si["length"][direct].min() < 16
+            want = ref if output == "complex" else np.abs(ref) if output == "amplitude" else np.abs(ref) ** 2
+            sc = scale if output != "power" else scale ** 2
+            tol = 2 * TOL if output == "power" else TOL
+            got = p.execute(x)
+            assert (np.abs(got - want) / sc)[:, direct].max() < tol, (beta, output)
+            assert np.all(got[:, :, 2501:2503] == 0)
+            for start, length in [(1, 2047), (2049, 2050), (2502, 3698), (3, 1)]:
+                blk = p.execute_block(x, start, length)
+                np.testing.assert_array_equal(blk, got[:, :, start:start + length])

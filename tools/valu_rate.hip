@@ -11,10 +11,12 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-enum { PK_ADD, PK_MUL, PK_FMA, PK_ADD_MOD, ADD, FMA, MUL, SQRT, MIX_PK, MIX_SC, N_OPS };
+enum { PK_ADD, PK_MUL, PK_FMA, PK_ADD_MOD, ADD, FMA, MUL, SQRT, MIX_PK, MIX_SC, PK_FMA_BC, PK_FMA_S2, PK_FMA_S1, FMA_S, N_OPS };
 static const char* kNames[] = {"v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32", "v_pk_add_f32 op_sel/neg",
                                "v_add_f32", "v_fma_f32", "v_mul_f32", "v_sqrt_f32",
-                               "cmul packed (pk_mul+pk_fma)", "cmul scalar (2 mul + 2 fma)"};
+                               "cmul packed (pk_mul+pk_fma)", "cmul scalar (2 mul + 2 fma)",
+                               "v_pk_fma_f32 src0 broadcast", "v_pk_fma_f32 src1 = SGPR pair (both)",
+                               "v_pk_fma_f32 src1 = SGPR (one dword)", "v_fma_f32 src1 = SGPR"};
 
 template <int OP>
 __global__ void __launch_bounds__(512) k_rate(float* out, long long* cyc, int iters) {
@@ -22,6 +24,7 @@ __global__ void __launch_bounds__(512) k_rate(float* out, long long* cyc, int it
   const v2f w = {1.0001f + threadIdx.x * 1e-7f, 0.9999f};
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = (v2f){1.f + i, 2.f + threadIdx.x * 1e-3f};
+  const v2f ws = {1e-9f * iters, 1e-9f};     // wave-uniform: lives in SGPRs
   const long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -36,6 +39,10 @@ __global__ void __launch_bounds__(512) k_rate(float* out, long long* cyc, int it
         else if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i].x) : "v"(w.x));
         else if (OP == MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(w.x));
         else if (OP == SQRT) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i].x));
+        else if (OP == PK_FMA_BC) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(w));
+        else if (OP == PK_FMA_S2) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "s"(ws));
+        else if (OP == PK_FMA_S1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "s"(ws));
+        else if (OP == FMA_S) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].x) : "v"(a[(i + 1) & 7].y), "s"(ws.x));
         else if (OP == MIX_PK) {
           v2f t;
           asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a[i]), "v"(w));
@@ -87,6 +94,8 @@ int main() {
     run<PK_ADD_MOD>(thr, bpc, out, cyc, h); run<ADD>(thr, bpc, out, cyc, h); run<FMA>(thr, bpc, out, cyc, h);
     run<MUL>(thr, bpc, out, cyc, h); run<SQRT>(thr, bpc, out, cyc, h); run<MIX_PK>(thr, bpc, out, cyc, h);
     run<MIX_SC>(thr, bpc, out, cyc, h);
+    run<PK_FMA_BC>(thr, bpc, out, cyc, h); run<PK_FMA_S2>(thr, bpc, out, cyc, h); run<PK_FMA_S1>(thr, bpc, out, cyc, h);
+    run<FMA_S>(thr, bpc, out, cyc, h);
   }
   return 0;
 }
