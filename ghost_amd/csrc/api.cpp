@@ -105,6 +105,7 @@ struct gcwt_plan {
   float2* d_xb = nullptr;     // [C][max_xb]  block spectra, all levels
   float2* d_bank = nullptr;   // [S][B]
   float* d_gain = nullptr;    // [S][B] |H|
+  float* d_gain_lv = nullptr; // the same rows in level-list order, transposed for k_synth7 (+8 zero rows)
   float2* d_half_tw = nullptr; // [levels][256] exp(-i pi k/(256 R))
   float2* d_psi = nullptr;    // direct kernels
   unsigned long long* d_probe = nullptr;   // GHOSTCWT_CLOCK_PROBE=1: [cycles, 100 MHz ticks] of the synthesis workgroups
@@ -165,7 +166,7 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
-  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_xs); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
+  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_xs); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_gain_lv); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
@@ -414,8 +415,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   }
   if ((rc = upload_vec(&p->d_amps, hp.amps, p->stream))) return bail(rc);
   if (p->clock_probe) {
-    if ((rc = dev_alloc(&p->d_probe, 2))) return bail(rc);
-    hipError_t he0 = hipMemsetAsync(p->d_probe, 0, 16, p->stream);
+    if ((rc = dev_alloc(&p->d_probe, 8))) return bail(rc);
+    hipError_t he0 = hipMemsetAsync(p->d_probe, 0, 64, p->stream);
     if (he0 != hipSuccess) return bail(hip_err(he0, "probe reset"));
   }
   if ((rc = dev_alloc(&p->d_bank, (size_t)S * B))) return bail(rc);
@@ -490,6 +491,12 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   if ((rc = upload_vec(&p->d_scale_aux, scale_aux, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_interp_coef, hp.interp_coef, p->stream))) return bail(rc);
   p->n_listed = (int)scale_list.size();
+  {   // k_synth7 reads whole chunks of 8 rows: 8 rows of zeros behind the last level's
+    const size_t n = ((size_t)p->n_listed + 8) * 256;
+    if ((rc = dev_alloc(&p->d_gain_lv, n))) return bail(rc);
+    hipError_t hz = hipMemsetAsync(p->d_gain_lv, 0, sizeof(float) * n, p->stream);
+    if (hz != hipSuccess) return bail(hip_err(hz, "gain rows reset"));
+  }
   p->ep_dev.resize(hp.epochs.size());
   for (size_t e = 0; e < hp.epochs.size(); ++e) {
     const EpochPlan& ep = hp.epochs[e];
@@ -589,8 +596,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
 
   hipError_t he = launch_build_bank(p->d_bank, p->d_gain, p->d_bank_sc, p->d_amps, S, B, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_bank"));
-  he = launch_scale_windows(p->d_gain, p->d_scale_list, p->prune_inputs ? p->n_listed : 0,
-                            (float)hp.band_tol, p->stream);
+  he = launch_scale_windows(p->d_gain, p->d_scale_list, p->n_listed, (float)hp.band_tol, p->d_gain_lv,
+                            p->prune_inputs, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "scale_windows"));
   he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, p->d_amps, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_direct"));
@@ -832,6 +839,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       a7.levels = dev.levels7;
       a7.scale_list = p->d_scale_list;
       a7.gain = p->d_gain;
+      a7.gain_lv = p->d_gain_lv;
       a7.level_half_tw = p->d_half_tw;
       a7.out = dout;
       a7.xb_cstride = hp.max_xb;
@@ -1184,11 +1192,14 @@ int gcwt_debug_clock(gcwt_plan* p, double* ghz, double* workgroup_seconds) {
   if (!p->d_probe)
     return set_err(GCWT_ERR_INVALID, kMeasureBuild ? "plan was not created with GHOSTCWT_CLOCK_PROBE=1"
                                                    : "the clock probe exists only in libghostcwt_measure.so (make measure)");
-  unsigned long long v[2] = {0, 0};
+  unsigned long long v[8] = {};
   HIP_TRY(hipMemcpy(v, p->d_probe, sizeof(v), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(p->d_probe, 0, sizeof(v)));
   *ghz = v[1] ? (double)v[0] / (double)v[1] * 0.1 : 0.0;
   if (workgroup_seconds) *workgroup_seconds = (double)v[1] * 1e-8;
+  if (getenv("GHOSTCWT_CLOCK_PHASES") && v[6])   // mean microseconds into a k_synth7 workgroup's life at its marks
+    fprintf(stderr, "k_synth7 workgroups %llu: loads parked %.2f us, spectra exchanged %.2f, spectra done %.2f, loop starts %.2f, ends %.2f\n",
+            v[6], v[2] * 0.01 / v[6], v[3] * 0.01 / v[6], v[4] * 0.01 / v[6], v[5] * 0.01 / v[6], v[1] * 0.01 / v[6]);
   return GCWT_OK;
 }
 
@@ -1230,8 +1241,8 @@ int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, 
 int gcwt_internal_refresh_bank(gcwt_plan* p) {   // derived tables follow a (broadcast) bank
   hipError_t he = launch_bank_gain(p->d_bank, p->d_gain, p->d_bank_sc, p->hp.prm.n_freqs, p->stream);
   if (he != hipSuccess) return hip_err(he, "bank_gain");
-  he = launch_scale_windows(p->d_gain, p->d_scale_list, p->prune_inputs ? p->n_listed : 0,
-                            (float)p->hp.band_tol, p->stream);
+  he = launch_scale_windows(p->d_gain, p->d_scale_list, p->n_listed, (float)p->hp.band_tol, p->d_gain_lv,
+                            p->prune_inputs, p->stream);
   if (he != hipSuccess) return hip_err(he, "scale_windows");
   return GCWT_OK;
 }

@@ -112,6 +112,7 @@ struct Synth7Args {
   const Synth7Level* levels;
   const int32_t* scale_list;   // scale indices grouped by level, odd kernel lengths first
   const float* gain;           // |H_s[k]|, [S][256]
+  const float* gain_lv;        // the same rows in list order, [entry][t][16 j] (k_scale_windows)
   const float2* level_half_tw; // exp(-i pi k/(256 R)), 256 per level
   float* out;
   int64_t xb_cstride;
@@ -181,7 +182,7 @@ hipError_t launch_build_bank(float2* bank, float* gain, const BankScale* sc, con
 // (k_scale_windows).
 constexpr int kScaleIndexMask = 0x00FFFFFF;
 hipError_t launch_scale_windows(const float* gain, int32_t* scale_list, int n_listed, float tol,
-                                hipStream_t st);
+                                float* gain_lv, bool prune, hipStream_t st);
 hipError_t launch_bank_gain(const float2* bank, float* gain, const BankScale* sc, int n_scales,
                             hipStream_t st);
 // full-band scales (exact.hip): H[k] / P on the k1-major grid of a P-point spectrum, the

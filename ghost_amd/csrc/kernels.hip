@@ -235,13 +235,20 @@ __global__ void k_bank_gain(const cf* __restrict__ bank, float* __restrict__ gai
 // scale's entry in its level's list.  (Nothing is skipped below the band: the L-tap
 // truncation's side lobes stay near 1e-8 of the peak down to zero frequency, and recordings
 // carry most of their power there.)
+// The kernel also lays the level's gains out the way k_synth7 parks them in LDS -- row =
+// position in the level lists, lane t's sixteen gains (bins t + 16 j) side by side -- so that a
+// workgroup's refill is one 16-byte load per thread at an address it knows without reading the
+// scale list first (gain_lv: n_listed + 8 rows of 256 floats).  prune = 0: windows left whole.
 // grid (n_listed), block (256)
-__global__ void k_scale_windows(const float* __restrict__ gain, int32_t* __restrict__ scale_list, float tol) {
+__global__ void k_scale_windows(const float* __restrict__ gain, int32_t* __restrict__ scale_list, float tol,
+                                float* __restrict__ gain_lv, int prune) {
   __shared__ float red[4];
   __shared__ int last;
   const int k = threadIdx.x;
   const int s = scale_list[blockIdx.x] & kScaleIndexMask;
-  const float g = fabsf(gain[(int64_t)s * 256 + k]);
+  const float g_signed = gain[(int64_t)s * 256 + k];
+  gain_lv[(int64_t)blockIdx.x * 256 + (k & 15) * 16 + (k >> 4)] = g_signed;
+  const float g = fabsf(g_signed);
   float m = g;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
@@ -252,7 +259,7 @@ __global__ void k_scale_windows(const float* __restrict__ gain, int32_t* __restr
   if (g > tol * peak) atomicMax(&last, k);
   __syncthreads();
   if (k == 0) {
-    const int j_hi = min(16, max(9, (last + 16) >> 4));       // ceil((last + 1) / 16), inputs 0..8 always kept
+    const int j_hi = prune ? min(16, max(9, (last + 16) >> 4)) : 16;   // ceil((last + 1) / 16), inputs 0..8 always kept
     scale_list[blockIdx.x] = s | ((16 - j_hi) << 24);
   }
 }
@@ -1275,9 +1282,10 @@ hipError_t launch_bank_gain(const cf* bank, float* gain, const BankScale* sc, in
 }
 
 hipError_t launch_scale_windows(const float* gain, int32_t* scale_list, int n_listed, float tol,
-                                hipStream_t st) {
+                                float* gain_lv, bool prune, hipStream_t st) {
   if (n_listed <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_scale_windows, dim3(n_listed), dim3(256), 0, st, gain, scale_list, tol);
+  hipLaunchKernelGGL(k_scale_windows, dim3(n_listed), dim3(256), 0, st, gain, scale_list, tol, gain_lv,
+                     prune ? 1 : 0);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -33,8 +33,8 @@ namespace gcwt {
 //   DFT16, |.|, 14 stores of 4 B per lane: 256 contiguous bytes per wave store, nt
 // With 16 <= halo <= 32 rows 0 and 15 of a thread's 16 outputs are always halo,
 // rows 2..13 are always kept and rows 1 / 14 are kept lane-wise.
-// LDS: 16 x 513 complex + 256 complex + 8 x 320 gains + 256 indices = 77 KB -> two
-// workgroups per CU.  128 VGPRs.
+// LDS: 16 x 513 complex + 256 complex + 8 x 320 gains + 256 indices + 256 half-sample factors
+// = 79 KB -> two workgroups per CU.  128 VGPRs.
 // ---------------------------------------------------------------------------
 // exp(-2 pi i shift r / (256 R)): what phase r of a level whose band starts `shift` bins below zero
 // carries (shift r < 2^24: exact in float before the division by a power of two)
@@ -53,7 +53,7 @@ __device__ __forceinline__ v2f phase_carrier(int shift, int r, int R) {
 // twiddles and the order of the exchange planes (the same device as synthi.hip's
 // demodulation): nothing is added to the scale loop.
 template <int MODE, int NCOL, bool WIDE>
-__global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
+__global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const Synth7Args a) {
   constexpr int kThreads = 16 * NCOL;
   constexpr int kPlane = kThreads + 1;
   constexpr int kLgN = NCOL == 32 ? 5 : 4;
@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   v2f* const twl = ex + 16 * kPlane;
   float* const stage = reinterpret_cast<float*>(twl + 256);       // gains of kChunk scales
   int* const sc_lds = reinterpret_cast<int*>(stage + 8 * kGainRow);   // this level's scale indices
+  v2f* const half_lds = reinterpret_cast<v2f*>(sc_lds + 256);         // the level's half-sample factors
 
   const Synth7Item it = a.items[blockIdx.x];
   const Synth7Level lv = a.levels[it.level];
@@ -80,36 +81,47 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     if (last <= a.seg.w_lo[seg] || first >= a.seg.w_hi[seg]) return;
   }
   const int tid = threadIdx.x;
-  long long probe_c0 = 0, probe_t0 = 0;
+  long long probe_c0 = 0, probe_t0 = 0, probe_ph[4] = {0, 0, 0, 0};
   if (kMeasureBuild && a.clock_probe) { probe_c0 = __builtin_amdgcn_s_memtime(); probe_t0 = __builtin_amdgcn_s_memrealtime(); }
   const int colw = tid >> 4, t = tid & 15;
   const bool wide = R > NCOL;
   const int blk_l = wide ? 0 : (colw >> lg);
   const int r = wide ? it.rtile * NCOL + colw : (colw & (R - 1));
   const int* const scales = a.scale_list + lv.scale_offset;
-  // scale indices are read from LDS inside the loop: a global load there would have to
-  // wait for vmcnt(0), i.e. for every store still in flight
-  for (int i = tid; i < lv.n_scales; i += kThreads) sc_lds[i] = scales[i];
-
-  if (tid < 256) {
-    // W256^((t - shift) j) stored [j][t]: the 16 lanes of a column read consecutive entries
-    const float2 w = a.tw256[(((tid & 15) - sh) * (tid >> 4)) & 255];
-    twl[tid] = (v2f){w.x, w.y};
-  }
+  constexpr int kChunk = 8;
+  // ---- every global load of the prologue is issued here, before anything waits for one: the
+  // workgroup pays one trip to memory, not one per table ----
+  // this level's scale entries (read from LDS inside the loop: a global load there would have to
+  // wait for vmcnt(0), i.e. for every store still in flight); at most 256 per level
+  const int sc_v = tid < lv.n_scales ? scales[tid] : 0;
+  // W256^((t - shift) j) stored [j][t]: the 16 lanes of a column read consecutive entries
+  const float2 tw_v = tid < 256 ? a.tw256[(((tid & 15) - sh) * (tid >> 4)) & 255] : make_float2(0.f, 0.f);
   // The filter enters as its real gain |H_s[k]|; the half-sample phase that even kernel
   // lengths carry is folded into P when the walk reaches those scales (they come last in
-  // the level's list).  Gains of kChunk scales at a time are parked in LDS (10 KB): a
-  // refill is one global load per thread per kChunk batches, so its vmcnt(0) drain of
-  // the outstanding stores is paid once per kChunk batches, not per batch.
-  constexpr int kChunk = 8;
-  auto fill_stage = [&](int b0) {
-    for (int i = tid; i < kChunk * 256; i += kThreads) {
-      const int sb = min(b0 + (i >> 8), lv.n_scales - 1);
-      stage[(i >> 8) * kGainRow + (i & 15) * 20 + ((i >> 4) & 15)] =
-          a.gain[(int64_t)(scales[sb] & kScaleIndexMask) * 256 + (i & 255)];
+  // the level's list; its 256 factors wait in LDS).  Gains of kChunk scales at a time are
+  // parked in LDS (10 KB), lane t's sixteen side by side; gain_lv holds them in that order
+  // (k_scale_windows), one 16-byte load per thread and chunk, the next chunk's issued as soon as
+  // the current one is parked.
+  constexpr int kGainLoads = kChunk * 64 / kThreads;     // float4 per thread and chunk: 1 (2 for 16 columns)
+  static_assert(kGainLoads * kThreads == kChunk * 64, "one chunk = a whole number of loads per thread");
+  const float4* const gain_rows = reinterpret_cast<const float4*>(a.gain_lv + (int64_t)lv.scale_offset * 256);
+  float4 g_v[kGainLoads];
+  auto load_gains = [&](int b0) {
+#pragma unroll
+    for (int i = 0; i < kGainLoads; ++i) g_v[i] = gain_rows[b0 * 64 + i * kThreads + tid];
+  };
+  auto park_gains = [&]() {
+#pragma unroll
+    for (int i = 0; i < kGainLoads; ++i) {
+      const int f = i * kThreads + tid;                  // float4 f of the chunk: scale f >> 6, lane (f >> 2) & 15
+      *reinterpret_cast<float4*>(stage + (f >> 6) * kGainRow + ((f >> 2) & 15) * 20 + (f & 3) * 4) = g_v[i];
     }
   };
-  fill_stage(0);
+  load_gains(0);
+  const bool has_half = lv.n_plain < lv.n_scales;        // workgroup-uniform
+  const float2 half_v = has_half && tid < 256 ? a.level_half_tw[lv.half_offset + tid] : make_float2(1.f, 0.f);
+  const float2* ltw = a.level_tw + lv.tw_offset;
+  const float2 b0 = ltw[t * r], st = ltw[16 * r];
   v2f pw[16];
   if (a.xr) {
     // Block spectra made here: XB_b = FFT_256(x_R[(b hop - halo + n) mod M]) / (256 P) for the
@@ -124,30 +136,46 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     v2f* const xbs = ex + (NCOL / 2) * 256;
     static_assert(NCOL * 256 <= 16 * (16 * NCOL + 1), "prologue buffers must fit the exchange planes");
     v2f v[16];
+    const int blkx = min(it.blk0 + colw, lv.nblk - 1);
+    const int64_t m_b = (int64_t)(lv.blk_base + blkx) * hop - halo;       // the block's first decimated sample
+    // the block's carrier: exp(-2 pi i shift m_b / 256)
+    float2 cb = make_float2(1.f, 0.f);
     if (colw < nblk_wg) {
-      const int blkx = min(it.blk0 + colw, lv.nblk - 1);
-      const int64_t base = (int64_t)(lv.blk_base + blkx) * hop - halo + t;
+      if (sh) cb = a.tw256[(-(int64_t)sh * m_b) & 255];
       const float2* xr = a.xr + (int64_t)c * a.xr_cstride + lv.xr_offset;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float2 q = xr[(base + 16 * j) & lv.m_mask];
+        const float2 q = xr[(m_b + t + 16 * j) & lv.m_mask];
         v[j] = (v2f){q.x, -q.y};
       }
+    }
+    // the small tables first (they were asked for first), the samples stay in flight meanwhile
+    if (tid < lv.n_scales) sc_lds[tid] = sc_v;
+    if (tid < 256) { twl[tid] = (v2f){tw_v.x, tw_v.y}; half_lds[tid] = (v2f){half_v.x, half_v.y}; }
+    park_gains();
+    if (lv.n_scales > kChunk) load_gains(kChunk);
+    if (kMeasureBuild && a.clock_probe) { __builtin_amdgcn_s_waitcnt(0); probe_ph[0] = __builtin_amdgcn_s_memrealtime(); }
+    if (colw < nblk_wg) {
       idft16v(v);
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const float2 w = a.tw256[(t * m) & 255];            // exp(+2 pi i t m / 256)
-        fx[colw * 256 + t * 16 + (m ^ t)] = cmulv(v[dft16_pos(m)], (v2f){w.x, w.y});
-      }
+      for (int m = 0; m < 16; ++m) fx[colw * 256 + t * 16 + (m ^ t)] = v[dft16_pos(m)];
     }
     __syncthreads();
+    if (kMeasureBuild && a.clock_probe) probe_ph[1] = __builtin_amdgcn_s_memrealtime();
     if (colw < nblk_wg) {
+      // element (writer k1, index t) arrives without its twiddle exp(+2 pi i k1 t / 256): with no
+      // band shift that is twl[16 k1 + t], just parked
 #pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) v[k1] = fx[colw * 256 + k1 * 16 + (t ^ k1)];
+      for (int k1 = 0; k1 < 16; ++k1) {
+        const v2f z = fx[colw * 256 + k1 * 16 + (t ^ k1)];
+        if (sh) {
+          const float2 w = a.tw256[(t * k1) & 255];
+          v[k1] = cmulv(z, (v2f){w.x, w.y});
+        } else {
+          v[k1] = k1 == 0 ? z : cmulv(z, twl[16 * k1 + t]);
+        }
+      }
       idft16v(v);
-      // the block's carrier: exp(-2 pi i shift m_b / 256), m_b the block's first decimated sample
-      const int blkx = min(it.blk0 + colw, lv.nblk - 1);
-      const float2 cb = a.tw256[(-(int64_t)sh * ((int64_t)(lv.blk_base + blkx) * hop - halo)) & 255];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const v2f z = v[dft16_pos(j)];
@@ -156,8 +184,7 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
       }
     }
     __syncthreads();
-    const float2* ltw = a.level_tw + lv.tw_offset;
-    const float2 b0 = ltw[t * r], st = ltw[16 * r];
+    if (kMeasureBuild && a.clock_probe) probe_ph[2] = __builtin_amdgcn_s_memrealtime();
     v2f wcur = (v2f){b0.x, b0.y};
     if (sh) wcur = cmulv(wcur, phase_carrier(sh, r, R));
     const v2f wstep = (v2f){st.x, st.y};
@@ -172,8 +199,6 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
     // the last block reuse it and are never stored
     const int blk = min(it.blk0 + blk_l, lv.nblk - 1);
     const float2* xb = a.xb + (int64_t)c * a.xb_cstride + lv.xb_offset + (int64_t)blk * 256 + t;
-    const float2* ltw = a.level_tw + lv.tw_offset;
-    const float2 b0 = ltw[t * r], st = ltw[16 * r];
     v2f wcur = (v2f){b0.x, b0.y};
     if (sh) {   // the phase's and the block's carriers (the XB pass knows nothing of the shift)
       const float2 cb = a.tw256[(-(int64_t)sh * ((int64_t)(lv.blk_base + blk) * hop - halo)) & 255];
@@ -186,6 +211,10 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
       pw[j] = cmulv((v2f){q.x, q.y}, wcur);
       wcur = cmulv(wcur, wstep);
     }
+    if (tid < lv.n_scales) sc_lds[tid] = sc_v;
+    if (tid < 256) { twl[tid] = (v2f){tw_v.x, tw_v.y}; half_lds[tid] = (v2f){half_v.x, half_v.y}; }
+    park_gains();
+    if (lv.n_scales > kChunk) load_gains(kChunk);
   }
   const int sstride = wide ? NCOL : R;
   v2f* const exw = ex + ((t - sh) & 15) * kPlane + (wide ? colw : (blk_l << (4 + lg)) + r);
@@ -223,20 +252,18 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   const unsigned vstep = (unsigned)(m1step * (4 * kElem));
   const float* const st_rd = stage + t * 20;
   __syncthreads();
+  if (kMeasureBuild && a.clock_probe) probe_ph[3] = __builtin_amdgcn_s_memrealtime();
 
   for (int b = 0; b < lv.n_scales; ++b) {
     if (b > 0 && (b & (kChunk - 1)) == 0) {    // wave-uniform
       __syncthreads();                         // everyone is done with the previous chunk
-      fill_stage(b);
+      park_gains();                            // asked for eight scales ago
+      if (b + kChunk < lv.n_scales) load_gains(b + kChunk);
       __syncthreads();
     }
     if (b == lv.n_plain) {                     // wave-uniform; at most once per workgroup
-      const float2* hp = a.level_half_tw + lv.half_offset + t;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float2 q = hp[16 * j];
-        pw[j] = cmulv(pw[j], (v2f){q.x, q.y});
-      }
+      for (int j = 0; j < 16; ++j) pw[j] = cmulv(pw[j], half_lds[t + 16 * j]);
     }
     const float4* const hs = reinterpret_cast<const float4*>(st_rd + (b & (kChunk - 1)) * kGainRow);
     // the entry's top byte: 16 - j_hi, first-pass inputs j >= j_hi are left out for this scale (kernels.h)
@@ -285,13 +312,15 @@ __global__ void __launch_bounds__(16 * NCOL, 4) k_synth7(const Synth7Args a) {
   if (kMeasureBuild && a.clock_probe && tid == 0) {
     atomicAdd(a.clock_probe, (unsigned long long)(__builtin_amdgcn_s_memtime() - probe_c0));
     atomicAdd(a.clock_probe + 1, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - probe_t0));
+    for (int i = 0; i < 4; ++i) atomicAdd(a.clock_probe + 2 + i, (unsigned long long)(probe_ph[i] - probe_t0));
+    atomicAdd(a.clock_probe + 6, 1ull);
   }
 }
 
 template <int NCOL, bool WIDE>
 static hipError_t launch_synth7_n(int mode, const Synth7Args& a, int n_items, int n_channels,
                                   hipStream_t st) {
-  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 8 * 320 * 4 + 256 * 4;
+  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 8 * 320 * 4 + 256 * 4 + 256 * 8;
   static bool attr_done[64] = {};            // per device: one process may drive several
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
