@@ -166,21 +166,31 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
       // element (writer k1, index t) arrives without its twiddle exp(+2 pi i k1 t / 256): with no
       // band shift that is twl[16 k1 + t], just parked
 #pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) {
-        const v2f z = fx[colw * 256 + k1 * 16 + (t ^ k1)];
-        if (sh) {
+      for (int k1 = 0; k1 < 16; ++k1) v[k1] = fx[colw * 256 + k1 * 16 + (t ^ k1)];
+      if (sh) {                              // workgroup-uniform
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) {
           const float2 w = a.tw256[(t * k1) & 255];
-          v[k1] = cmulv(z, (v2f){w.x, w.y});
-        } else {
-          v[k1] = k1 == 0 ? z : cmulv(z, twl[16 * k1 + t]);
+          v[k1] = cmulv(v[k1], (v2f){w.x, w.y});
         }
+      } else {
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmulv(v[k1], twl[16 * k1 + t]);
       }
       idft16v(v);
+      const float xs = a.xb_scale;
+      if (sh) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const v2f z = v[dft16_pos(j)];
-        const v2f xb = (v2f){z.x * a.xb_scale, -z.y * a.xb_scale};
-        xbs[colw * 256 + t + 16 * j] = sh ? cmulv(xb, (v2f){cb.x, cb.y}) : xb;
+        for (int j = 0; j < 16; ++j) {
+          const v2f z = v[dft16_pos(j)];
+          xbs[colw * 256 + t + 16 * j] = cmulv((v2f){z.x * xs, -z.y * xs}, (v2f){cb.x, cb.y});
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const v2f z = v[dft16_pos(j)];
+          xbs[colw * 256 + t + 16 * j] = (v2f){z.x * xs, -z.y * xs};
+        }
       }
     }
     __syncthreads();
@@ -250,6 +260,12 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
   float* const out0 = a.out + ((int64_t)ch * a.n_scales * a.row_len + a.seg.seg_col[seg] + w_lo) * kElem;
   const unsigned voff0 = (unsigned)(((int)(n_b - w_lo) + off0) * (4 * kElem));
   const unsigned vstep = (unsigned)(m1step * (4 * kElem));
+  // R = 2 (amplitude / power): rows leave in pairs, see the store loop
+  const bool pair_rows = !wide && lg == 1;
+  const bool upper = (tid & 32) != 0;
+  const bool keep_p0 = upper ? keep2 : keep1, keep_p6 = upper ? keep14 : keep13;
+  const unsigned voff_pair = voff0 - (upper ? (unsigned)((2 * hop - 32) * 4) : 0u);   // the wave's first block, lane-linear
+  const unsigned pair_step = (unsigned)(2 * hop * 4);                              // its second block
   const float* const st_rd = stage + t * 20;
   __syncthreads();
   if (kMeasureBuild && a.clock_probe) probe_ph[3] = __builtin_amdgcn_s_memrealtime();
@@ -293,6 +309,28 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
     float* const dst = reinterpret_cast<float*>(((uint64_t)dst_hi << 32) | dst_lo);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         dst, 0, __builtin_amdgcn_readfirstlane(ext_bytes), 0x00020000);
+    if (MODE != GCWT_OUT_COMPLEX_C64 && !WIDE && pair_rows) {      // R = 2; workgroup-uniform
+      // A wave holds two blocks x 32 samples of every row: 128-byte pieces.  Swapping the upper
+      // half of row m1 with the lower half of row m1 + 1 (v_permlane32_swap) leaves one register
+      // with 64 consecutive samples of the first block and one with the second block's: 256
+      // contiguous bytes per store like every other level.
+#pragma unroll
+      for (int m1 = 1; m1 < 15; m1 += 2) {
+        const v2f z0 = v[dft16_pos(m1)], z1 = v[dft16_pos(m1 + 1)];
+        const float p0 = __builtin_fmaf(z0.y, z0.y, z0.x * z0.x), p1 = __builtin_fmaf(z1.y, z1.y, z1.x * z1.x);
+        const float a0 = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p0) : p0;
+        const float a1 = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p1) : p1;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0),
+                                                         __builtin_bit_cast(unsigned, a1), false, false);
+        const bool keep = m1 == 1 ? keep_p0 : m1 == 13 ? keep_p6 : true;   // this lane's row: m1 + (lane >= 32)
+        const unsigned vo = voff_pair + (unsigned)m1 * vstep;
+        if (keep) {
+          __builtin_amdgcn_raw_buffer_store_b32(sw[0], rsrc, vo, 0, GCWT_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b32(sw[1], rsrc, vo + pair_step, 0, GCWT_STORE_AUX);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int m1 = 1; m1 < 15; ++m1) {     // (rows 0 and 15 are never kept: halo >= 16)
       const v2f z = v[dft16_pos(m1)];
