@@ -2,6 +2,7 @@
 // workspace, and the orchestration of one transform.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -702,10 +703,25 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     const bool fused_blocks = p->fuse_blocks && p->synth_kernel == 7 && !p->use_synth16;
     // The levels are independent once the spectrum is there (rows pass -> column pass per
     // level, disjoint x_R); run one after the other they leave 10 us between launches and the
-    // small ones (R >= 16: grids that do not fill the chip) cost 0.2 ms.  Three streams take
-    // them in turn -- level l on stream l mod 3, the plan's own stream being one of them --
-    // and join before the synthesis.
+    // small ones (R >= 16: grids that do not fill the chip) cost 0.2 ms.  Three streams, the
+    // plan's own being one of them, share them by size (x_R of level R is P/R samples: the
+    // largest level alone is half of all the work, so it keeps a stream to itself and the
+    // small ones queue behind the second and third largest) and join before the synthesis.
     const bool side = p->level_streams && hp.levels.size() > 2;
+    std::vector<int> stream_of(hp.levels.size(), 0);
+    if (side) {
+      double load[3] = {0.0, 0.0, 0.0};
+      std::vector<size_t> order;
+      for (size_t l = 0; l < hp.levels.size(); ++l)
+        if (hp.levels[l].xr_owner == (int)l) order.push_back(l);
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return ep.lv[a].m > ep.lv[b].m; });
+      for (size_t l : order) {
+        const int k = (int)(std::min_element(load, load + 3) - load);
+        stream_of[l] = k;
+        load[k] += (double)ep.lv[l].m;
+      }
+      for (size_t l = 0; l < hp.levels.size(); ++l) stream_of[l] = stream_of[hp.levels[l].xr_owner];
+    }
     bool forked[2] = {false, false};
     hipEvent_t spectrum_ready = nullptr;
     if (side) {
@@ -720,7 +736,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       float2* xr = p->d_xr + el.xr_offset;
       hipStream_t ls = st;
       if (side) {                          // level (and whoever shares its x_R) -> its own stream
-        const int k = lp.xr_owner % 3;
+        const int k = stream_of[l];
         ls = k == 0 ? st : p->aux[k - 1];
         if (k > 0 && !forked[k - 1]) {
           he = hipStreamWaitEvent(ls, spectrum_ready, 0);
@@ -740,7 +756,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
           // (negative frequencies as conjugates) into a slice buffer first, one per stream
           const int64_t U = (int64_t)lp.band_shift * el.m / hp.block;     // a multiple of P1 (planner: steps of R / 16 bins)
           if (U % P1 != 0 || U / P1 > Q) return set_err(GCWT_ERR_INVALID, "internal: band shift does not slice the spectrum");
-          float2* xs = p->d_xs + (int64_t)(side ? lp.xr_owner % 3 : 0) * slots * p->xs_stride;
+          float2* xs = p->d_xs + (int64_t)stream_of[l] * slots * p->xs_stride;
           RUN(ST_DECIM, launch_shift_gather(p->d_x, xs, P1, Q, (int)(U / P1), kRowLen, P, p->xs_stride, slots, ls));
           src = xs; src_row = Q; src_cstride = p->xs_stride;
         }
