@@ -11,6 +11,7 @@
 //   modes: fir8   T = 8, 8 outputs per lane, two 16-byte stores at a lane stride of 32 B
 //          fir8c  T = 8, 4 outputs per lane, one 16-byte store, 1 KB contiguous per wave store
 //          fir6   T = 6, 8 outputs per lane
+//          fir6c / fir4c  fir8c with T = 6 / 4
 //          fir8ns / fir6ns  the same without stores
 //          st32   only the stores of fir8;  st16  only the stores of fir8c
 //   hipcc -O3 --offload-arch=gfx950 tools/interp_mix.hip -o /tmp/imix && /tmp/imix fir8 5
@@ -24,8 +25,8 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-enum { FIR8, FIR8C, FIR6, FIR8NS, FIR6NS, ST32, ST16, N_MODES };
-static const char* kNames[N_MODES] = {"fir8", "fir8c", "fir6", "fir8ns", "fir6ns", "st32", "st16"};
+enum { FIR8, FIR8C, FIR6, FIR8NS, FIR6NS, ST32, ST16, FIR6C, FIR4C, N_MODES };
+static const char* kNames[N_MODES] = {"fir8", "fir8c", "fir6", "fir8ns", "fir6ns", "st32", "st16", "fir6c", "fir4c"};
 
 // acc += z * c.x  /  acc += z * c.y   (complex z, real coefficient broadcast to both halves)
 __device__ __forceinline__ void fma_lo(v2f& acc, v2f z, v2f c) {
@@ -44,8 +45,8 @@ constexpr int kZ = 8192;   // complex samples of the coarse signal parked in LDS
 
 template <int MODE>
 __global__ void __launch_bounds__(512, 4) k_run(float* out, float* sink, int iters, long long* clk) {
-  constexpr int T = (MODE == FIR6 || MODE == FIR6NS) ? 6 : 8;
-  constexpr int NOUT = MODE == FIR8C || MODE == ST16 ? 4 : 8;
+  constexpr int T = (MODE == FIR6 || MODE == FIR6NS || MODE == FIR6C) ? 6 : MODE == FIR4C ? 4 : 8;
+  constexpr int NOUT = MODE == FIR8C || MODE == ST16 || MODE == FIR6C || MODE == FIR4C ? 4 : 8;
   constexpr bool kStore = !(MODE == FIR8NS || MODE == FIR6NS);
   constexpr bool kFir = !(MODE == ST32 || MODE == ST16);
   __shared__ __attribute__((aligned(16))) v2f z[kZ + 16];
@@ -137,7 +138,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&sink, (size_t)grid * (4u << 20)));
   if (!strcmp(mode, "idle")) { printf("idle\n"); fflush(stdout); std::this_thread::sleep_for(std::chrono::duration<double>(seconds)); return 0; }
 #define CASE(M) if (!strcmp(mode, kNames[M])) { drive<M>(seconds, out, sink, clk, grid); return 0; }
-  CASE(FIR8) CASE(FIR8C) CASE(FIR6) CASE(FIR8NS) CASE(FIR6NS) CASE(ST32) CASE(ST16)
+  CASE(FIR8) CASE(FIR8C) CASE(FIR6) CASE(FIR8NS) CASE(FIR6NS) CASE(ST32) CASE(ST16) CASE(FIR6C) CASE(FIR4C)
   printf("unknown mode %s\n", mode);
   return 1;
 }
