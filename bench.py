@@ -457,8 +457,10 @@ def run_rank(args):
         rl = line["roofline"]
         if info["n_interp"]:
             # the two synthesis kernels apart: rows x samples x 4 B each wrote, over its own launch time
-            b_i = C * N * info["n_interp"] * b_out
-            b_7 = C * N * (S - info["n_interp"]) * b_out
+            # (per launch, like kernel_ms: config 5 makes several launches per step)
+            rows_launch = C * N * b_out * args.steps / launches        # bytes of one scale's rows per launch
+            b_i = rows_launch * info["n_interp"]
+            b_7 = rows_launch * (S - info["n_interp"])
             k7_ms = max(1e-9, k_ms - ki_ms)
             rl["kernels"] = {
                 "k_synthi": {"ms": round(ki_ms, 4), "scales": info["n_interp"],

@@ -44,7 +44,15 @@ out = {
 }
 json.dump(out, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 shutil.copy(newest("stats/*/*kernel_stats.csv"), os.path.join(root, "profiles", rnd + "_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "bench.json"), os.path.join(root, "profiles", rnd + "_bench.json"))
+# the tracked line carries the traffic of THIS round's counter passes (bench.py itself can only read the
+# traffic.json that was in the tree when it ran, i.e. the previous collection)
+line = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+if isinstance(line.get("roofline"), dict):
+    line["roofline"]["traffic"] = out["k_synth_hbm_bytes_per_launch"]
+    line["roofline"]["traffic_source"] = ("profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                          "command in the same gpurun call as this line (tools/prof_round.sh), both synthesis "
+                                          "kernels; filled in by tools/traffic.py" % rnd)
+open(os.path.join(root, "profiles", rnd + "_bench.json"), "w").write(json.dumps(line) + "\n")
 print("synthesis (%s): fetch %.1f MB (x2 corrected) + write %.1f MB = %d bytes per step" %
       (" + ".join(keys), 2 * f_kb / 1024, w_kb / 1024, out["k_synth_hbm_bytes_per_launch"]))
 
