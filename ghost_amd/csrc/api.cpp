@@ -704,9 +704,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     // The levels are independent once the spectrum is there (rows pass -> column pass per
     // level, disjoint x_R); run one after the other they leave 10 us between launches and the
     // small ones (R >= 16: grids that do not fill the chip) cost 0.2 ms.  Three streams, the
-    // plan's own being one of them, share them by size (x_R of level R is P/R samples: the
-    // largest level alone is half of all the work, so it keeps a stream to itself and the
-    // small ones queue behind the second and third largest) and join before the synthesis.
+    // plan's own being one of them, share them by estimated time -- two passes over the level's
+    // P/R samples per slot at the rate such passes reach, plus what two launches cost however
+    // small they are (config 5's levels are all of the second kind and end up three per stream;
+    // the headline's R = 2 level is half of all the work and keeps a stream to itself) -- and
+    // join before the synthesis.
     const bool side = p->level_streams && hp.levels.size() > 2;
     std::vector<int> stream_of(hp.levels.size(), 0);
     if (side) {
@@ -718,7 +720,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       for (size_t l : order) {
         const int k = (int)(std::min_element(load, load + 3) - load);
         stream_of[l] = k;
-        load[k] += (double)ep.lv[l].m;
+        load[k] += 40e-6 + 32.0 * (double)ep.lv[l].m * (double)slots / 4.5e12;   // seconds
       }
       for (size_t l = 0; l < hp.levels.size(); ++l) stream_of[l] = stream_of[hp.levels[l].xr_owner];
     }

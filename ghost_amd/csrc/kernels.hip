@@ -737,6 +737,93 @@ __global__ void __launch_bounds__(256, 2) k_fft_colsq(const void* __restrict__ i
   }
 }
 
+// Forward column pass for REAL input and len = 256 q (q = 2, 4): the q interleaved subsequences of
+// a column are real, so two of them share one FFT256 -- z = x_{2p} + i x_{2p+1}, split again with
+// Z[kb] +- conj(Z[256 - kb]) -- before the W_len^(a kb) twiddles and the DFT_q: half the transforms
+// of k_fft_colsq<-1, true, LQ>.  A thread keeps its own Z[kb] in registers and reads the partner
+// rows from a [kb][column] tile in LDS (the last pair's tile aliases the exchange planes).
+// grid (ld/16, slots); 39 KB (q = 2) or 74 KB (q = 4) of LDS
+template <int LQ>
+__global__ void __launch_bounds__(256, 2) k_fft_colsq_real2(const float* __restrict__ in, cf* __restrict__ out,
+                                                         int ld, int64_t in_cstride, int64_t out_cstride,
+                                                         int64_t tw_n, const cf* __restrict__ tw4096,
+                                                         const cf* __restrict__ tw256,
+                                                         const double* __restrict__ sums, double inv_n,
+                                                         const SegIn segs, int rows_out) {
+  constexpr int q = 1 << LQ, len = 256 * q, np = q / 2;
+  static_assert(q == 2 || q == 4, "two or four subsequences");
+  __shared__ __attribute__((aligned(16))) cf planes[16 * kExColD];       // exchange planes / last pair's tile
+  __shared__ cf tile0[np > 1 ? 256 * 17 : 1];                           // first pair's tile (q = 4)
+  __shared__ cf twl[256];                 // W256^(-t j) at [j][t]
+  float* const ex_re = reinterpret_cast<float*>(planes);
+  float* const ex_im = ex_re + 16 * kExColD;
+  const int c = blockIdx.y, col0 = blockIdx.x * 16, tid = threadIdx.x;   // c: workspace slot
+  const int s = tid & 15, t = tid >> 4;
+  {
+    const cf w = tw256[((tid & 15) * (tid >> 4)) & 255];
+    twl[tid] = make_float2(w.x, -w.y);
+  }
+  const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
+  const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+  const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
+  const double mean = sums[ch] * inv_n;     // subtracted in fp64
+  cf v[16], u[np > 1 ? 16 : 1];
+#pragma unroll
+  for (int p = 0; p < np; ++p) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t na = (int64_t)(q * (t + 16 * j) + 2 * p) * ld + col0 + s, nb = na + ld;
+      const float xa = x[min(max(na, n_lead), n_valid - 1)], xb = x[min(max(nb, n_lead), n_valid - 1)];   // clamped
+      v[j] = make_float2(na >= n_lead && na < n_valid ? (float)((double)xa - mean) : 0.f,
+                         nb >= n_lead && nb < n_valid ? (float)((double)xb - mean) : 0.f);
+    }
+    __syncthreads();                      // twiddle table written / previous exchange read
+    fft256_16t_ldstw<-1>(v, twl + t, ex_re + s * kExColD, ex_im + s * kExColD, t);
+    if (p < np - 1) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { tile0[(t + 16 * j) * 17 + s] = v[j]; u[j] = v[j]; }
+    }
+  }
+  __syncthreads();                        // the last pair's tile aliases the planes
+#pragma unroll
+  for (int j = 0; j < 16; ++j) planes[(t + 16 * j) * 17 + s] = v[j];
+  __syncthreads();
+  cf* o = out + (int64_t)c * out_cstride + col0 + s;
+  cf stq = make_float2(1.f, 0.f), st16 = stq, wj = stq;
+  if (tw_n > 0) {
+    stq = unit_phase((int64_t)(col0 + s) * 256, tw_n, -1);
+    st16 = unit_phase((int64_t)(col0 + s) * 16, tw_n, -1);
+    wj = unit_phase((int64_t)(col0 + s) * t, tw_n, -1);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int kb = t + 16 * j, km = (256 - kb) & 255;
+    cf w[q];
+#pragma unroll
+    for (int p = 0; p < np; ++p) {
+      const cf zk = p < np - 1 ? u[j] : v[j];
+      const cf zm = p < np - 1 ? tile0[km * 17 + s] : planes[km * 17 + s];
+      const cf xa = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+      const cf xb = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+      w[2 * p] = p == 0 ? xa : cmul(xa, tw4096_at<-1>(tw4096, 2 * p * kb * (kRowLenDev / len)));
+      w[2 * p + 1] = cmul(xb, tw4096_at<-1>(tw4096, (2 * p + 1) * kb * (kRowLenDev / len)));
+    }
+    dft_small<-1, q>(w);
+    cf ph = wj;
+#pragma unroll
+    for (int ka = 0; ka < q; ++ka) {
+      const int k = kb + 256 * ka;
+      if (k < rows_out) {
+        cf val = w[ka];
+        if (tw_n > 0) val = cmul(val, ph);
+        o[(int64_t)k * ld] = val;
+      }
+      if (tw_n > 0) ph = cmul(ph, stq);
+    }
+    if (tw_n > 0) wj = cmul(wj, st16);
+  }
+}
+
 // Forward column pass for REAL input, two columns per FFT: z = x[.., 2m] + i x[.., 2m+1]
 // goes through one FFT256 and is split again with Z[k] +- conj(Z[256-k]); only rows
 // k = 0 .. 128 exist afterwards (the mirrored rows are reflected by the row pass).
@@ -1354,7 +1441,17 @@ static hipError_t launch_fft_cols_segs(int sign, bool real_in, const void* in, c
   if ((len == 512 || len == 1024) && tw256 && tw4096 && !(sign > 0 && real_in)) {
     const bool big = len == 1024;
     hipError_t e;
-    if (sign < 0 && real_in)
+    if (sign < 0 && real_in && all_valid) {      // two real subsequences per FFT256
+      if (big)
+        hipLaunchKernelGGL(k_fft_colsq_real2<2>, dim3(ld / 16, n_channels), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(in), out, ld, in_cstride, out_cstride, tw_n, tw4096,
+                           tw256, sums, inv_n, segs, rows_out);
+      else
+        hipLaunchKernelGGL(k_fft_colsq_real2<1>, dim3(ld / 16, n_channels), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(in), out, ld, in_cstride, out_cstride, tw_n, tw4096,
+                           tw256, sums, inv_n, segs, rows_out);
+      e = hipGetLastError();
+    } else if (sign < 0 && real_in)
       e = big ? launch_colsq<-1, true, 2>(in, out, ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, n_channels, rows_out, st)
               : launch_colsq<-1, true, 1>(in, out, ld, in_cstride, out_cstride, tw_n, tw4096, tw256, sums, inv_n, segs, n_channels, rows_out, st);
     else if (sign < 0)
