@@ -44,6 +44,19 @@ __device__ __forceinline__ v2f phase_carrier(int shift, int r, int R) {
   return (v2f){cs, sn};
 }
 
+// One column's sixteen first-stage outputs times W256^(t j) (tw: this lane's sixteen, two per 16-byte
+// read; j = 0 is 1) into the exchange planes, STRIDE elements apart (0: run-time stride).
+template <int STRIDE>
+__device__ __forceinline__ void twiddle_to_planes(v2f* exw, const v2f (&v)[16], const v2f* tw, int stride = STRIDE) {
+  const int st = STRIDE ? STRIDE : stride;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const v4f w2 = *reinterpret_cast<const v4f*>(tw + 2 * jj);
+    exw[(2 * jj) * st] = jj == 0 ? v[0] : cmulv(v[dft16_pos(2 * jj)], (v2f){w2.x, w2.y});
+    exw[(2 * jj + 1) * st] = cmulv(v[dft16_pos(2 * jj + 1)], (v2f){w2.z, w2.w});
+  }
+}
+
 // WIDE: block halo above 48 (the long, heavy-tailed kernels of a level with a shifted band):
 // every row's place in the block is tested, rows 0 and 15 included in the walk.
 // Levels whose band starts band_shift bins below zero frequency (planner.h): bins are counted
@@ -62,8 +75,11 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
   constexpr int kGainRow = 16 * 20;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2f* const ex = reinterpret_cast<v2f*>(smem);
+  // W256 twiddles of the inter-stage multiply, lane t's sixteen side by side (pitch 18: 144 bytes, so
+  // that they come in as 16-byte reads and the 16 lanes of a column fall on distinct banks)
+  constexpr int kTwPitch = 18;
   v2f* const twl = ex + 16 * kPlane;
-  float* const stage = reinterpret_cast<float*>(twl + 256);       // gains of kChunk scales
+  float* const stage = reinterpret_cast<float*>(twl + 16 * kTwPitch);   // gains of kChunk scales
   int* const sc_lds = reinterpret_cast<int*>(stage + 8 * kGainRow);   // this level's scale indices
   v2f* const half_lds = reinterpret_cast<v2f*>(sc_lds + 256);         // the level's half-sample factors
 
@@ -94,7 +110,7 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
   // this level's scale entries (read from LDS inside the loop: a global load there would have to
   // wait for vmcnt(0), i.e. for every store still in flight); at most 256 per level
   const int sc_v = tid < lv.n_scales ? scales[tid] : 0;
-  // W256^((t - shift) j) stored [j][t]: the 16 lanes of a column read consecutive entries
+  // W256^((t - shift) j), parked as [t][j]
   const float2 tw_v = tid < 256 ? a.tw256[(((tid & 15) - sh) * (tid >> 4)) & 255] : make_float2(0.f, 0.f);
   // The filter enters as its real gain |H_s[k]|; the half-sample phase that even kernel
   // lengths carry is folded into P when the walk reaches those scales (they come last in
@@ -151,7 +167,7 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
     }
     // the small tables first (they were asked for first), the samples stay in flight meanwhile
     if (tid < lv.n_scales) sc_lds[tid] = sc_v;
-    if (tid < 256) { twl[tid] = (v2f){tw_v.x, tw_v.y}; half_lds[tid] = (v2f){half_v.x, half_v.y}; }
+    if (tid < 256) { twl[(tid & 15) * kTwPitch + (tid >> 4)] = (v2f){tw_v.x, tw_v.y}; half_lds[tid] = (v2f){half_v.x, half_v.y}; }
     park_gains();
     if (lv.n_scales > kChunk) load_gains(kChunk);
     if (kMeasureBuild && a.clock_probe) { __builtin_amdgcn_s_waitcnt(0); probe_ph[0] = __builtin_amdgcn_s_memrealtime(); }
@@ -164,7 +180,7 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
     if (kMeasureBuild && a.clock_probe) probe_ph[1] = __builtin_amdgcn_s_memrealtime();
     if (colw < nblk_wg) {
       // element (writer k1, index t) arrives without its twiddle exp(+2 pi i k1 t / 256): with no
-      // band shift that is twl[16 k1 + t], just parked
+      // band shift that is twl[t][k1], just parked
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) v[k1] = fx[colw * 256 + k1 * 16 + (t ^ k1)];
       if (sh) {                              // workgroup-uniform
@@ -175,7 +191,7 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
         }
       } else {
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmulv(v[k1], twl[16 * k1 + t]);
+        for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmulv(v[k1], twl[t * kTwPitch + k1]);
       }
       idft16v(v);
       const float xs = a.xb_scale;
@@ -222,7 +238,7 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
       wcur = cmulv(wcur, wstep);
     }
     if (tid < lv.n_scales) sc_lds[tid] = sc_v;
-    if (tid < 256) { twl[tid] = (v2f){tw_v.x, tw_v.y}; half_lds[tid] = (v2f){half_v.x, half_v.y}; }
+    if (tid < 256) { twl[(tid & 15) * kTwPitch + (tid >> 4)] = (v2f){tw_v.x, tw_v.y}; half_lds[tid] = (v2f){half_v.x, half_v.y}; }
     park_gains();
     if (lv.n_scales > kChunk) load_gains(kChunk);
   }
@@ -292,9 +308,16 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
       default: gain_first_layer<16>(v, pw, hs); break;
     }
     idft16v_tail(v);
-#pragma unroll
-    for (int j = 0; j < 16; ++j)              // W256^(t j); j = 0 is 1
-      exw[j * sstride] = j == 0 ? v[0] : cmulv(v[dft16_pos(j)], twl[16 * j + t]);
+    // the column's sixteen values, W256^(t j) applied, into its exchange planes: with the stride between
+    // them known at compile time the stores need no address arithmetic and pair up (ds_write2_b64)
+    switch (sstride) {                         // workgroup-uniform: R, or the column count for R > columns
+      case 2: twiddle_to_planes<2>(exw, v, twl + t * kTwPitch); break;
+      case 4: twiddle_to_planes<4>(exw, v, twl + t * kTwPitch); break;
+      case 8: twiddle_to_planes<8>(exw, v, twl + t * kTwPitch); break;
+      case 16: twiddle_to_planes<16>(exw, v, twl + t * kTwPitch); break;
+      case 32: twiddle_to_planes<32>(exw, v, twl + t * kTwPitch); break;
+      default: twiddle_to_planes<0>(exw, v, twl + t * kTwPitch, sstride); break;
+    }
     if (!(kMeasureBuild && (a.drop_stores & 2))) __syncthreads();      // (always taken in the product build: kernels.h)
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) v[k1] = exr[k1 * kPlane];
@@ -358,7 +381,7 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
 template <int NCOL, bool WIDE>
 static hipError_t launch_synth7_n(int mode, const Synth7Args& a, int n_items, int n_channels,
                                   hipStream_t st) {
-  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 256 * 8 + 8 * 320 * 4 + 256 * 4 + 256 * 8;
+  constexpr int lds = 16 * (16 * NCOL + 1) * 8 + 16 * 18 * 8 + 8 * 320 * 4 + 256 * 4 + 256 * 8;
   static bool attr_done[64] = {};            // per device: one process may drive several
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
