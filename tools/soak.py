@@ -2,7 +2,8 @@
 epochs with gaps, sampling rates, frequency ranges down to large decimations, forced time
 blocks, output modes, block requests).  Prints the worst relative error per case; exits
 non-zero on the first case over the 1e-5 gate.  SOAK_N cases (default 60), SOAK_SEED;
-SOAK_BIG=1 adds recordings of up to 2.5 M samples (FFT lengths up to 2^22)."""
+SOAK_BIG=1 adds recordings of up to 2.5 M samples (FFT lengths up to 2^22); SOAK_DETAIL=3e-6 prints the
+per-scale errors of every case above that."""
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np
 from ghost_amd.engine import CwtPlan
@@ -64,6 +65,11 @@ for case in range(n_cases):
     print("case %2d: fs %7.0f ch %d n %6d ep %d g,b %g,%4g scales %d R<=%5d direct %d full %d segs %3d %-9s err %.2e block %s" %
           (case, fs, n_ch, n, len(eb), gamma, beta, f.size, si["decimation"].max(), int((si["method"] == 1).sum()),
            int((si["method"] == 2).sum()), len(p.segments()), output, err, "ok" if same else "DIFFERS"), flush=True)
+    if os.environ.get("SOAK_DETAIL") and err / (tol / TOL) > float(os.environ["SOAK_DETAIL"]):   # per scale: where the error sits
+        e_s = (np.abs(got - ref) / scale).max(axis=(0, 2))
+        print("   per scale: " + ", ".join("%.4g Hz L %d R %d m %d %.1e" % (f[i], si["length"][i], si["decimation"][i], si["method"][i], e_s[i])
+                                           for i in range(f.size)), flush=True)
+        print("   epochs", eb, "kw", {k: v for k, v in kw.items() if k != "epoch_bounds"}, flush=True)
     worst = max(worst, err / (tol / TOL))
     if err > tol or not same:
         print("FAILED", dict(fs=fs, n=n, eb=eb, f=f.tolist(), kw=kw))
