@@ -568,27 +568,48 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     }
     // A workgroup walks all the scales of its blocks unless that is too much for one: the passes
     // of a level's walk (kInterpCols / (q nb) scales each) are cut into runs of at most
-    // `target` output bytes, halved until the launch has a few rounds of workgroups per CU
-    // (long recordings at high decimations: 5 blocks x 24 channels would be 120 workgroups of
-    // 76 MB each).  A run's prologue -- its blocks' spectra -- costs ~8 us.
+    // `target` output bytes, and where a single pass is more than that (high decimations: one
+    // pass of two scales of a block is 14 MB at R = 8192) its wave-tasks are shared out over
+    // several workgroups, each of which repeats the pass's transforms (17 q / R of the work).
+    // `target` is halved until the launch has a few rounds of workgroups per CU.  The list is
+    // ordered largest first and channels run fastest in the grid, so that what is still running
+    // when the launch ends is the small items.  A run's prologue -- its blocks' spectra -- costs ~8 us.
     {
       const int64_t n_ch_slots = (int64_t)hp.prm.n_channels * std::max(1, ep.batch_count);
-      int64_t target = (int64_t)4 << 20;
+      int64_t target = (int64_t)2 << 20;
+      std::vector<int64_t> item_bytes;
       for (int attempt = 0;; ++attempt) {
         items_i.clear();
+        item_bytes.clear();
         for (const auto& pl : pending) {
           const LevelPlan& lp = hp.levels[pl.first];
           const int nb = 1 << pl.second, ns = kInterpCols / (lp.interp_q * nb);
           const int n_pass = ((int)lp.scales.size() + ns - 1) / ns;
           const int64_t pass_bytes = (int64_t)ns * nb * lp.hop * lp.decimation * 4;
           const int run = (int)std::max<int64_t>(1, std::min<int64_t>(n_pass, target / std::max<int64_t>(1, pass_bytes)));
+          const int wps = (lp.hop * (lp.decimation >> 2) + 63) >> 6;     // wave-tasks per (block, scale): synthi.hip
+          const int quads = (wps + 3) / 4;
+          const int parts = run > 1 ? 1 : (int)std::min<int64_t>(quads, (pass_bytes + target - 1) / target);
           for (int b0 = 0; b0 < ep.lv[pl.first].nblk; b0 += nb)
             for (int p0 = 0; p0 < n_pass; p0 += run)
-              items_i.push_back({(int32_t)pl.first, b0, p0, std::min(run, n_pass - p0)});
+              for (int part = 0; part < parts; ++part) {
+                const int lo = 4 * (int)((int64_t)quads * part / parts);
+                const int hi = std::min(wps, 4 * (int)((int64_t)quads * (part + 1) / parts));
+                const int np = std::min(run, n_pass - p0);
+                items_i.push_back({(int32_t)pl.first, b0, p0, np, lo, hi});
+                item_bytes.push_back((int64_t)np * pass_bytes * (hi - lo) / std::max(1, wps));
+              }
         }
         if ((int64_t)items_i.size() * n_ch_slots >= 3072 || target <= ((int64_t)1 << 19) || attempt > 6) break;
         target >>= 1;
       }
+      std::vector<size_t> order(items_i.size());
+      for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return item_bytes[x] > item_bytes[y]; });
+      std::vector<SynthiItem> sorted(items_i.size());
+      for (size_t i = 0; i < order.size(); ++i) sorted[i] = items_i[order[i]];
+      items_i.swap(sorted);
+      if (items_i.size() > 65535) return bail(set_err(GCWT_ERR_UNSUPPORTED, "too many workgroup items for one launch of the interpolating synthesis"));
     }
     p->ep_dev[e].n_items_i = (int)items_i.size();
     if ((rc = upload_vec(&p->ep_dev[e].items_i, items_i, p->stream))) return bail(rc);

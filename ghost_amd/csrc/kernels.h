@@ -137,6 +137,8 @@ hipError_t launch_synth7(int mode, int ncol, bool wide_halo, const Synth7Args& a
 struct SynthiItem {
   int32_t level, blk0;          // first block of the workgroup's group
   int32_t pass0, n_pass;        // the passes (groups of scale slots) of the level's walk it makes
+  int32_t wt_lo, wt_hi;         // the wave-tasks (256 samples each) of every (block, scale) it interpolates and
+                                // stores: [0, all) unless one pass is too much for a workgroup (wt_lo: multiple of 4)
 };
 struct SynthiLevel {
   int32_t decimation, q, log2q, factor;   // R, phases per (block, scale), I = R / q

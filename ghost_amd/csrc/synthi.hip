@@ -82,9 +82,9 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   int* const sc_lds = reinterpret_cast<int*>(stage + kSlotsMax * kGainRowI);
   int* const aux_lds = sc_lds + 256;
 
-  const SynthiItem it = a.items[blockIdx.x];
+  const SynthiItem it = a.items[blockIdx.y];   // (channels run fastest: the largest items, listed first, start first on every channel)
   const SynthiLevel lv = a.levels[it.level];
-  const int c = blockIdx.y;               // workspace slot: segment * n_channels + channel
+  const int c = blockIdx.x;               // workspace slot: segment * n_channels + channel
   const int seg = c / a.seg.n_channels, ch = c - seg * a.seg.n_channels;
   const int R = lv.decimation, q = lv.q, lgq = lv.log2q, hop = lv.hop, halo = lv.halo;
   const int lgnb = lv.log2nb, nb = 1 << lgnb;                       // blocks per workgroup
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   int lgi4 = 0;
   while ((4 << lgi4) < I) ++lgi4;                             // I / 4 = 1 << lgi4
   const int tps = hop * (R >> 2);                             // lane-tasks per (block, scale)
-  const int wps = (tps + 63) >> 6;
+  const int n_wt = it.wt_hi - it.wt_lo;                       // wave-tasks per (block, scale) of this workgroup
   // which 4 of the I sub-sample positions a lane-task k covers: k mod (I / 4).  k = 64 wt + lane
   // and a wave's wave-tasks advance by kWavesI = 4 at a time, so up to I / 4 = 256 the set depends
   // on the lane and on wt mod 4 only -- constant along a wave's run through a z slot
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
         if (b0 + sl >= n_scales || it.blk0 + bl >= lv.nblk) continue;
         const int entry = __builtin_amdgcn_readfirstlane(sc_lds[b0 + sl]);
         const int par = (__builtin_amdgcn_readfirstlane(aux_lds[b0 + sl]) >> 16) & 1;
-        const int wt0 = (wave - zi * wps) & (kWavesI - 1);
+        const int wt0 = (wave - zi * n_wt) & (kWavesI - 1);
         const int key = par | (lgi4 > 6 ? (wt0 & ((1 << (lgi4 - 6)) - 1)) << 1 : 0);
         if (key != cur_par) {       // rare: the level's list is ordered by parity; wt0 changes only when I > 256
           const int sigma = (wt0 * 64 + lane) & ((1 << lgi4) - 1);
@@ -299,9 +299,10 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
         const int s_blk = s_base + bl * hop * R;              // window-relative sample of this block's first
         // the slot's wave-tasks are dealt round-robin over the waves, continuing where the previous
         // slot stopped
-        for (int wt = wt0; wt < wps; wt += kWavesI) {
+        for (int wt = it.wt_lo + wt0; wt < it.wt_hi; wt += kWavesI) {
           const int k = wt * 64 + lane;
           const int s_first = s_blk + 256 * wt;               // window-relative sample of the wave-task's first
+          if (s_first + 256 <= 0 || s_first >= w_len) continue;   // nothing of it inside this launch's window (wave-uniform)
           const bool whole = wt * 64 + 64 <= tps && s_first >= 0 && (int64_t)s_first + 256 <= w_len;
           if (whole || k < tps) {
             const v2f* const zp = zs + (k >> lgi4);
@@ -362,7 +363,8 @@ hipError_t launch_synthi(int mode, const SynthiArgs& a, int n_items, int n_chann
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid(n_items, n_channels), block(kThreadsI);
+  if (n_items > 65535) return hipErrorInvalidValue;
+  dim3 grid(n_channels, n_items), block(kThreadsI);
   if (mode == GCWT_OUT_AMPLITUDE_F32)
     hipLaunchKernelGGL((k_synthi<GCWT_OUT_AMPLITUDE_F32>), grid, block, kLdsBytes, st, a);
   else

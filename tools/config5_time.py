@@ -8,6 +8,9 @@ fs, N, S = 30000.0, int(os.environ.get("C5_N", "18000000")), 200
 C, group = int(os.environ.get("C5_C", "48")), int(os.environ.get("C5_GROUP", "24"))
 reps = int(os.environ.get("C5_REPS", "4"))
 f = np.geomspace(500.0, 1.0, S)
+if os.environ.get("C5_LEVEL"):          # only the scales of one decimation level (per-level rates)
+    dec = CwtPlan(N, group, fs, f).scale_info()["decimation"]
+    f = f[dec == int(os.environ["C5_LEVEL"])]; S = f.size
 plan = CwtPlan(N, group, fs, f, output=os.environ.get("C5_OUT", "amplitude")); plan.set_profiling(True)
 segs = plan.segments()
 x = lfp(2, N, fs, seed=1234)
@@ -29,4 +32,4 @@ for it in range(reps + 1):
     if it:
         tot.append(acc)
 med = {k: round(float(np.median([t[k] for t in tot])), 3) for k in tot[0] if k.endswith("_ms")}
-print(os.environ.get("QB_TAG", ""), "config 5 per step: total min %.2f med %.2f ms |" % (min(t["total_ms"] for t in tot), med["total_ms"]), med)
+print(os.environ.get("QB_TAG", ""), "%d scales" % S, "%.0f GB/s of rows |" % (C * N * S * 4 / max(1e-9, med["synth_ms"]) / 1e6), "config 5 per step: total min %.2f med %.2f ms |" % (min(t["total_ms"] for t in tot), med["total_ms"]), med)
