@@ -96,6 +96,7 @@ struct gcwt_plan {
   hipStream_t stream = nullptr;
   hipStream_t aux[2] = {nullptr, nullptr};   // the level passes of a batch run beside each other (run_pipeline)
   bool level_streams = true;  // GHOSTCWT_LEVEL_STREAMS=0: everything on `stream`
+  int interp_grid = -1;       // GHOSTCWT_INTERP_GRID=0|1: k_synthi's grid order forced (default: by the number of channel slots)
   bool synth_streams = false; // GHOSTCWT_SYNTH_STREAMS=1: the interpolating kernel runs beside k_synth7 on aux[0] (its store-bound
                               // workgroups share the CUs with the arithmetic-bound ones: measured equal on the headline,
                               // profiles/r03_synth_study.md); default: one after the other, so that per-kernel times add up
@@ -300,6 +301,7 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   if (const char* e = getenv("GHOSTCWT_PRUNE_INPUTS")) p->prune_inputs = atoi(e) != 0;
   if (getenv("GHOSTCWT_SLOW_FFT")) p->fast_fft = false;
   if (const char* e = getenv("GHOSTCWT_LEVEL_STREAMS")) p->level_streams = atoi(e) != 0;
+  if (const char* e = getenv("GHOSTCWT_INTERP_GRID")) p->interp_grid = atoi(e) != 0;
   if (const char* e = getenv("GHOSTCWT_SYNTH_STREAMS")) p->synth_streams = atoi(e) != 0;
 #ifdef GCWT_MEASURE
   if (const char* e = getenv("GHOSTCWT_SYNTH_KERNEL")) p->synth_kernel = atoi(e) == 8 ? 8 : 7;
@@ -572,8 +574,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     // pass of two scales of a block is 14 MB at R = 8192) its wave-tasks are shared out over
     // several workgroups, each of which repeats the pass's transforms (17 q / R of the work).
     // `target` is halved until the launch has a few rounds of workgroups per CU.  The list is
-    // ordered largest first and channels run fastest in the grid, so that what is still running
-    // when the launch ends is the small items.  A run's prologue -- its blocks' spectra -- costs ~8 us.
+    // ordered largest first, so that what is still running when the launch ends is the small items.  A run's prologue -- its blocks' spectra -- costs ~8 us.
     {
       const int64_t n_ch_slots = (int64_t)hp.prm.n_channels * std::max(1, ep.batch_count);
       int64_t target = (int64_t)2 << 20;
@@ -846,6 +847,12 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       ai.xr_cstride = hp.max_xr;
       ai.xb_scale = (float)(1.0 / ((double)hp.block * (double)P));
       ai.n_scales = S;
+      // Which index runs fastest in the grid decides what is in flight together: the same few items
+      // of every channel, or many items of one channel.  Measured (profiles/r03_synth_study.md 12): with
+      // 24 channel slots (config 5) channels-fastest is 3 % faster; with 128 it is as fast in most
+      // processes and 8 % slower in some (the placement of the 51 GB of rows decides), items-fastest
+      // never is.
+      ai.channels_fastest = p->interp_grid >= 0 ? p->interp_grid : (slots <= 32 ? 1 : 0);
       ai.seg = sout;
       p->cur = si;
       RUN(ST_INTERP, launch_synthi(mode, ai, dev.n_items_i, slots, si));

@@ -164,6 +164,7 @@ struct SynthiArgs {
   int64_t xr_cstride;
   float xb_scale;              // 1 / (256 P)
   int32_t n_scales;
+  int32_t channels_fastest;   // grid (slots, items) instead of (items, slots): see api.cpp, interp_channels_fastest
   SegOut seg;
 };
 hipError_t launch_synthi(int mode, const SynthiArgs& a, int n_items, int n_channels, hipStream_t st);

@@ -82,9 +82,9 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   int* const sc_lds = reinterpret_cast<int*>(stage + kSlotsMax * kGainRowI);
   int* const aux_lds = sc_lds + 256;
 
-  const SynthiItem it = a.items[blockIdx.y];   // (channels run fastest: the largest items, listed first, start first on every channel)
+  const SynthiItem it = a.items[a.channels_fastest ? blockIdx.y : blockIdx.x];
   const SynthiLevel lv = a.levels[it.level];
-  const int c = blockIdx.x;               // workspace slot: segment * n_channels + channel
+  const int c = a.channels_fastest ? blockIdx.x : blockIdx.y;   // workspace slot: segment * n_channels + channel
   const int seg = c / a.seg.n_channels, ch = c - seg * a.seg.n_channels;
   const int R = lv.decimation, q = lv.q, lgq = lv.log2q, hop = lv.hop, halo = lv.halo;
   const int lgnb = lv.log2nb, nb = 1 << lgnb;                       // blocks per workgroup
@@ -299,10 +299,12 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
         const int s_blk = s_base + bl * hop * R;              // window-relative sample of this block's first
         // the slot's wave-tasks are dealt round-robin over the waves, continuing where the previous
         // slot stopped
-        for (int wt = it.wt_lo + wt0; wt < it.wt_hi; wt += kWavesI) {
+        // (only those with a sample inside this launch's window: task wt covers s_blk + 256 wt .. + 255)
+        const int wt_a = max(it.wt_lo, s_blk >= 0 ? 0 : (-s_blk) >> 8);
+        const int wt_b = (int)min((int64_t)it.wt_hi, max((int64_t)0, (w_len - s_blk + 255) >> 8));
+        for (int wt = wt_a + ((wt0 - wt_a) & (kWavesI - 1)); wt < wt_b; wt += kWavesI) {
           const int k = wt * 64 + lane;
           const int s_first = s_blk + 256 * wt;               // window-relative sample of the wave-task's first
-          if (s_first + 256 <= 0 || s_first >= w_len) continue;   // nothing of it inside this launch's window (wave-uniform)
           const bool whole = wt * 64 + 64 <= tps && s_first >= 0 && (int64_t)s_first + 256 <= w_len;
           if (whole || k < tps) {
             const v2f* const zp = zs + (k >> lgi4);
@@ -363,8 +365,8 @@ hipError_t launch_synthi(int mode, const SynthiArgs& a, int n_items, int n_chann
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if (n_items > 65535) return hipErrorInvalidValue;
-  dim3 grid(n_channels, n_items), block(kThreadsI);
+  if (n_items > 65535 || n_channels > 65535) return hipErrorInvalidValue;
+  const dim3 grid = a.channels_fastest ? dim3(n_channels, n_items) : dim3(n_items, n_channels), block(kThreadsI);
   if (mode == GCWT_OUT_AMPLITUDE_F32)
     hipLaunchKernelGGL((k_synthi<GCWT_OUT_AMPLITUDE_F32>), grid, block, kLdsBytes, st, a);
   else
