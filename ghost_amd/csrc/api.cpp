@@ -610,7 +610,6 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       std::vector<SynthiItem> sorted(items_i.size());
       for (size_t i = 0; i < order.size(); ++i) sorted[i] = items_i[order[i]];
       items_i.swap(sorted);
-      if (items_i.size() > 65535) return bail(set_err(GCWT_ERR_UNSUPPORTED, "too many workgroup items for one launch of the interpolating synthesis"));
     }
     p->ep_dev[e].n_items_i = (int)items_i.size();
     if ((rc = upload_vec(&p->ep_dev[e].items_i, items_i, p->stream))) return bail(rc);
@@ -853,6 +852,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       // processes and 8 % slower in some (the placement of the 51 GB of rows decides), items-fastest
       // never is.
       ai.channels_fastest = p->interp_grid >= 0 ? p->interp_grid : (slots <= 32 ? 1 : 0);
+      if (dev.n_items_i > 65535) ai.channels_fastest = 0;       // (grid.y is 16 bits wide)
       ai.seg = sout;
       p->cur = si;
       RUN(ST_INTERP, launch_synthi(mode, ai, dev.n_items_i, slots, si));

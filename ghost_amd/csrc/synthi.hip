@@ -365,7 +365,7 @@ hipError_t launch_synthi(int mode, const SynthiArgs& a, int n_items, int n_chann
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if (n_items > 65535 || n_channels > 65535) return hipErrorInvalidValue;
+  if ((a.channels_fastest ? n_items : n_channels) > 65535) return hipErrorInvalidValue;
   const dim3 grid = a.channels_fastest ? dim3(n_channels, n_items) : dim3(n_items, n_channels), block(kThreadsI);
   if (mode == GCWT_OUT_AMPLITUDE_F32)
     hipLaunchKernelGGL((k_synthi<GCWT_OUT_AMPLITUDE_F32>), grid, block, kLdsBytes, st, a);
