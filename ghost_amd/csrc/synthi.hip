@@ -1,28 +1,31 @@
 // synthi.hip -- interpolating synthesis: the amplitude / power rows of the levels whose scales
-// are heavily oversampled at the full rate (R >= 16: every scale of such a level occupies at most
-// a fifth of the rate its block transform produces once q = 4 phases are taken).
+// are heavily oversampled at the full rate (R >= 16).
 // (transforms.py:203-204: convolve each epoch with each scale's kernel, keep abs.)
 //
 // k_synth7 pays one point of a 256-point inverse FFT for every stored sample.  Here a (block,
-// scale) goes through that transform only for q of its R phases -- the scale's complex output z
-// at q x the level's rate, demodulated to its band centre so that it is a low-pass signal -- and
-// the R / q = I samples between two of those come from an 8-tap polyphase FIR with real
-// coefficients (interp.h: least-squares design on the level's band; what it adds is bounded per
-// level from the scales' own gains, planner.cpp: plan_interp_level, and stays below 1.5e-7 of a
+// scale) goes through that transform only for q of its R phases (q = 2; 4 / 8 where R / 2 would
+// exceed the largest interpolation factor) -- the scale's complex output z at q x the level's
+// rate, demodulated to its band centre so that it is a low-pass signal -- and the R / q = I
+// samples between two of those come from an 8-tap polyphase FIR with real coefficients
+// (interp.h: minimax design under the envelope of the level's gains; what it adds is bounded per
+// level from the scales' own gains, planner.cpp: plan_interp_level, and stays below 2e-7 of a
 // scale's peak).  |.| does not see the demodulation.  Per stored sample: 8 packed FMAs + |.|
-// against ~20 VALU and 5 LDS instructions, and the stores are whole 1 KB runs per wave.
+// against ~15 VALU and 3.4 LDS instructions, and the stores are whole 1 KB runs per wave.
 //
-// One workgroup (512 threads) = one block of one level; it walks the level's scales 32 / q at a
-// time ("slots").  Per pass:
-//   A  32 columns (slot, phase): P * G_s, DFT16, W256 twiddle, exchange through LDS, DFT16 -- the
-//      loop body of k_synth7 -- with the demodulation folded in: bins are counted from the
+// One workgroup (256 threads = 16 columns) = one or two blocks of one level; it walks the level's
+// scales 16 / (q nb) at a time ("slots").  Per pass:
+//   A  16 columns (block, slot, phase): P * G_s, DFT16, W256 twiddle, exchange through LDS, DFT16
+//      -- the loop body of k_synth7 -- with the demodulation folded in: bins are counted from the
 //      scale's centre k_c (twiddle exponent (t - k_c) a - (k_c / q) p, exchange planes written
 //      rotated by k_c), so z needs no multiply of its own.  z lands in LDS in time order.
-//   B  every wave takes runs of 256 consecutive output samples of one scale: a lane makes 4
-//      consecutive samples from the 8 z values around them (coefficients of its 4 sub-sample
+//   B  every wave takes runs of 256 consecutive output samples of one (block, scale): a lane makes
+//      4 consecutive samples from the 8 z values around them (coefficients of its 4 sub-sample
 //      positions in registers), |.|, one 16-byte store; a wave store is 1 KB contiguous.
 // Kernels of even length carry a half-sample delay: their rows are interpolated at
 // tau - 1/(2 I) with a second coefficient table instead of a phase on the spectrum.
+// How the work is cut (api.cpp): an item is a block group, a run of passes and a range of the
+// wave-tasks of pass B (all of them unless one pass is more than ~2 MB of rows: then several
+// workgroups repeat pass A and share B); items are listed largest first.
 #include <hip/hip_runtime.h>
 
 #include "interp.h"
@@ -39,8 +42,8 @@ namespace {
 constexpr int kT = kInterpTaps;
 static_assert(kT == 8, "the FIR loop below is written for 8 taps");
 // Columns per pass.  16 (256 threads, three workgroups and 12 waves per CU, up to 168 VGPRs: the
-// persistent operand, the FIR coefficients and both transforms' working sets fit without spills)
-// or 32 (512 threads, two workgroups and 16 waves per CU, 128 VGPRs).
+// persistent operand, the FIR coefficients and both transforms' working sets fit without spills);
+// 32 (512 threads, two workgroups and 16 waves per CU, 128 VGPRs) spilled 32 dwords and was slower.
 constexpr int kColsI = kInterpCols;
 constexpr int kLgColsI = kColsI == 32 ? 5 : kColsI == 16 ? 4 : 3;
 constexpr int kThreadsI = 16 * kColsI;
