@@ -1198,9 +1198,9 @@ __global__ void __launch_bounds__(256) k_level_small(const cf* __restrict__ x, c
   for (int idx = threadIdx.x; idx < m; idx += 256) {
     const int j1 = idx / q, m2 = idx - j1 * q;
     cf acc = make_float2(0.f, 0.f);
-    for (int j2 = 0; j2 < q; ++j2) {
+    for (int j2 = 0; j2 < q; ++j2) {          // q <= 4096, a power of two: the phases come from the table
       const cf v = xc[(int64_t)j1 * row_stride + j2];
-      acc = cadd(acc, cmul(v, unit_phase((int64_t)j2 * m2, q, 1)));
+      acc = cadd(acc, cmul(v, tw4096_at<1>(tw4096, ((j2 * m2) & (q - 1)) * (kRowLenDev / q))));
     }
     buf[idx] = cmul(acc, unit_phase((int64_t)j1 * m2, m, 1));
   }
