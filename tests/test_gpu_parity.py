@@ -893,7 +893,7 @@ def test_repeated_executes_are_bit_identical():
 
 def test_fft_length_2_22_blocks():
     """bench.py --config 5's own FFT length: time blocks of 2^22 points (a 1024-point column
-    pass: k_fft_colsq with four interleaved FFT256s per column, real input), two channels with
+    pass: k_fft_colsq_real2, the column's four interleaved real subsequences two per FFT256), two channels with
     different offsets, scales from 500 Hz down to 1.5 Hz at 30 kHz, against the oracle; and the
     2^21-point plan of the same recording must give the same numbers to within rounding."""
     from ghost_amd.engine import CwtPlan
