@@ -2,7 +2,7 @@
 under gpurun_out/pmc_<tag>_{1,2,3}.   Usage: python tools/pmc_summary.py <tag> <round> [kernel]"""
 import collections, csv, glob, json, os, sys
 tag, rnd = sys.argv[1], sys.argv[2]
-kern = sys.argv[3] if len(sys.argv) > 3 else "k_synth7<0, 32>"
+kern = sys.argv[3] if len(sys.argv) > 3 else "k_synth7<0, 32, false>"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 vals = {}
 for d in ("1", "2", "3"):
@@ -33,6 +33,6 @@ out = {
         "lds_insts_per_wave": vals["SQ_INSTS_LDS"] / vals["SQ_WAVES"],
     },
 }
-path = os.path.join(root, "profiles", "%s_pmc_k_synth7.json" % rnd)
+path = os.path.join(root, "profiles", "%s_pmc_%s.json" % (rnd, kern.split("<")[0]))
 json.dump(out, open(path, "w"), indent=1)
 print(path, json.dumps(out["derived"], indent=1))
