@@ -34,7 +34,8 @@ class Params(C.Structure):
                 ("freqs_hz", C.POINTER(C.c_double)), ("n_epochs", C.c_int32),
                 ("out_mode", C.c_int32), ("epoch_bounds", C.POINTER(C.c_int64)),
                 ("device", C.c_int32), ("block", C.c_int32), ("band_eps", C.c_double),
-                ("max_fft_log2", C.c_int32), ("wavelet_flags", C.c_int32)]
+                ("max_fft_log2", C.c_int32), ("wavelet_flags", C.c_int32),
+                ("precision", C.c_int32), ("reserved0", C.c_int32), ("support_tol", C.c_double)]
 
 
 class PlanInfo(C.Structure):

@@ -102,6 +102,10 @@ struct gcwt_plan {
                               // profiles/r03_synth_study.md); default: one after the other, so that per-kernel times add up
   hipStream_t cur = nullptr;  // the stream the stage in hand is launched on (profiling spans follow it)
   // workspace
+  bool high_precision = true; // gcwt_params.precision: float64 forward transform (fwd64.hip) + per-level low cut
+  double2* d_y = nullptr;     // [slots][rows][4096] float64 intermediate of the forward transform
+  int64_t y_stride = 0;
+  double2* d_tw64 = nullptr;  // float64 twiddle tables (fwd64_fill_tables)
   float2* d_x = nullptr;      // [C][max_p]   spectrum (k1-major)
   float2* d_xr = nullptr;     // [C][max_xr]  decimated analytic signals, all levels
   float2* d_xb = nullptr;     // [C][max_xb]  block spectra, all levels
@@ -168,7 +172,7 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
-  fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_xs); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_gain_lv); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
+  fr(p->d_y); fr(p->d_tw64); fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_xs); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_gain_lv); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
@@ -295,6 +299,7 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->hp.prm.epoch_bounds = p->hp.bounds.data();
   p->hp.prm.n_epochs = (int32_t)(p->hp.bounds.size() / 2);
   p->device = params->device;
+  p->high_precision = p->hp.high_precision;
   if (const char* e = getenv("GHOSTCWT_SYNTH16")) p->use_synth16 = e[0] == '1';
   if (const char* e = getenv("GHOSTCWT_SYNTH_COLS")) p->synth_cols = atoi(e) == 16 ? 16 : 32;
   if (const char* e = getenv("GHOSTCWT_FUSE_BLOCKS")) p->fuse_blocks = e[0] != '0';
@@ -398,12 +403,25 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   for (auto& q : p->aux) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
   auto bail = [&](int code) { free_dev(p); return code; };
+  bool he_sync_tables = false;
 
   const bool any_fft = hp.n_direct < S;   // spectral or full-band scales: they share X
   if (any_fft) {
     // one workspace slot per (segment of a batch, channel)
     const int64_t slots = C * hp.max_batch;
     if ((rc = dev_alloc(&p->d_x, (size_t)(slots * hp.max_p)))) return bail(rc);
+    if (p->high_precision && p->fast_fft) {
+      // rows 0 .. P1/2 of the intermediate (all of them when full-band scales read the whole spectrum)
+      for (const EpochPlan& ep : hp.epochs) {
+        const int rows = ep.p1 >= 4 && hp.n_fullband == 0 ? ep.p1 / 2 + 1 : ep.p1;
+        p->y_stride = std::max<int64_t>(p->y_stride, (int64_t)rows * kRowLen);
+      }
+      if ((rc = dev_alloc(&p->d_y, (size_t)(slots * p->y_stride)))) return bail(rc);
+      std::vector<double2> tw(8192);
+      fwd64_fill_tables(tw.data());
+      if ((rc = upload_vec(&p->d_tw64, tw, p->stream))) return bail(rc);
+      he_sync_tables = true;
+    }
     if ((rc = dev_alloc(&p->d_xr, (size_t)(slots * hp.max_xr)))) return bail(rc);
     if ((rc = dev_alloc(&p->d_xb, (size_t)(slots * hp.max_xb)))) return bail(rc);
     for (const EpochPlan& ep : hp.epochs)
@@ -416,6 +434,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       if ((rc = dev_alloc(&p->d_hfull, (size_t)hp.max_p))) return bail(rc);
     }
   }
+  if (he_sync_tables && hipStreamSynchronize(p->stream) != hipSuccess)      // the host table went out of scope
+    return bail(set_err(GCWT_ERR_HIP, "twiddle upload"));
   if ((rc = upload_vec(&p->d_amps, hp.amps, p->stream))) return bail(rc);
   if (p->clock_probe) {
     if ((rc = dev_alloc(&p->d_probe, 8))) return bail(rc);
@@ -713,6 +733,13 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     const bool hermitian = fast_fft && P1 >= 4 && hp.n_fullband == 0;
     const int rows_a = hermitian ? P1 / 2 + 1 : P1;
     // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
+    if (p->d_y) {
+      // precision = high: both passes in float64, the spectrum rounded to float32 per bin (fwd64.hip)
+      RUN(ST_FWD, launch_fwd64_cols(dx, p->d_y, P1, N, p->y_stride, P, p->d_tw64, p->d_sums, inv_n, sin, nb,
+                                    rows_a, st));
+      RUN(ST_FWD, launch_fwd64_rows(p->d_y, p->d_x, rows_a, p->y_stride, P, p->d_tw64, slots,
+                                    hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0, st));
+    } else {
     RUN(ST_FWD, launch_fft_cols_batch(dx, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0, p->d_tw4096,
                                       fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n, sin, nb, st,
                                       rows_a));
@@ -720,6 +747,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     RUN(ST_FWD, launch_fft_rows(-1, p->d_x, p->d_x, kRowLen, rows_a, kRowLen, kRowLen, P, P, 0,
                                 p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, st,
                                 hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0));
+    }
     // the production synthesis kernel computes its blocks' spectra itself (no XB pass)
     const bool fused_blocks = p->fuse_blocks && p->synth_kernel == 7 && !p->use_synth16;
     // The levels are independent once the spectrum is there (rows pass -> column pass per
@@ -758,6 +786,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       const EpochLevel& el = ep.lv[l];
       float2* xr = p->d_xr + el.xr_offset;
       hipStream_t ls = st;
+      RowTaper taper;                      // precision = high: the slice loses what lies below every scale's band
+      if (p->high_precision && lp.taper_hi > 0.0 && lp.band_shift == 0) {
+        const double k1 = lp.taper_hi * (double)P / (2.0 * M_PI), k0 = 0.5 * k1;
+        if (k1 - k0 >= 1.0) { taper.p1 = P1; taper.k0 = (float)k0; taper.inv_width = (float)(1.0 / (k1 - k0)); }
+      }
       if (side) {                          // level (and whoever shares its x_R) -> its own stream
         const int k = stream_of[l];
         ls = k == 0 ? st : p->aux[k - 1];
@@ -786,7 +819,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         // x_R[Q m1 + m2] = sum_{j1} e^{2 pi i j1 m1/P1} e^{2 pi i j1 m2/M} sum_{j2} X~[j1][j2] e^{2 pi i j2 m2/Q}
         RUN(ST_DECIM, launch_fft_rows(+1, src, xr, Q, P1, src_row, Q, src_cstride, hp.max_xr,
                                       P1 > 1 ? el.m : 0, p->d_tw4096,
-                                      fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, ls));
+                                      fast_fft ? p->d_tw256 : nullptr, 1.0f, slots, ls, 0, 0, taper));
         if (P1 > 1)
           RUN(ST_DECIM, launch_fft_cols(+1, false, xr, xr, P1, Q, hp.max_xr, hp.max_xr, 0,
                                         p->d_tw4096, fast_fft ? p->d_tw256 : nullptr, p->d_sums,
@@ -795,7 +828,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         // M = P/R <= 8192: rows j1 < n1 of X~, q leading entries each
         const int n1 = (int)std::min<int64_t>(P1, el.m);
         const int q = (int)(el.m / n1);
-        RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, slots, ls));
+        RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, slots, ls, taper));
       }
       const float scale = (float)(1.0 / ((double)hp.block * (double)P));
       const LevelKernel lk = level_kernel(p, lp);

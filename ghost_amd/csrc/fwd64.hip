@@ -1,0 +1,417 @@
+// fwd64.hip -- the forward FFT of a recording in float64 (round 4, precision = high).
+//
+// Why: the reference works in float64 (transforms.py:142-143, convolution.py:68-77).  Every
+// float32 stage of a transform carries the recording's WHOLE dynamic range: its rounding noise is
+// white at ~1e-7 of the total, which a 1/f^3 background, mains interference 100 x the signal or
+// an electrode offset put above 1e-5 of a quiet band (profiles/r04_spectrum_classes_before.json).
+// The forward transform is the one stage that cannot be protected by a filter in front of it, so
+// it runs in float64: x - mean in float64, both passes in float64 with a float64 intermediate,
+// and only the finished spectrum is rounded to float32 -- per BIN, i.e. relative to that
+// frequency's own content.  Downstream, every level low-cuts its slice of the spectrum below the
+// band of its scales (api.cpp: level taper) before its float32 inverse transform.
+//
+// Same two-pass layout as the float32 path (kernels.hip): P = P1 * 4096,
+//   pass A  Y[k1][n2] = W_P^(-n2 k1) sum_n1 x[4096 n1 + n2] W_P1^(-n1 k1)      (columns, float64 out)
+//   pass B  X~[k1][k2] = sum_n2 Y[k1][n2] W_4096^(-n2 k2) = X[k1 + P1 k2]       (rows, float32 out)
+// with the same register radix-16 FFT256 (16 threads x 16 points, one LDS exchange), the same
+// real-input packing (two real columns, or two real subsequences of a column, per complex
+// transform) and the same reflected rows for the upper half of a real signal's spectrum.
+// Twiddles come from two float64 tables (W_4096^a and W_2^24^b: any W_P^m is one product).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "kernels.h"
+
+namespace gcwt {
+
+typedef double2 cd;
+
+__device__ __forceinline__ cd dmul(cd a, cd b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ cd dadd(cd a, cd b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cd dsub(cd a, cd b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cd dmul_mi(cd a) { return make_double2(a.y, -a.x); }   // times -i
+__device__ __forceinline__ cd dconj(cd a) { return make_double2(a.x, -a.y); }
+
+// forward DFT4 / DFT16 (exp(-2 pi i n k / N)), natural order in and out: kernels.hip dft4 / dft16
+__device__ __forceinline__ void d_dft4(cd& a, cd& b, cd& c, cd& d) {
+  const cd s0 = dadd(a, c), s1 = dsub(a, c), s2 = dadd(b, d), s3 = dmul_mi(dsub(b, d));
+  a = dadd(s0, s2);
+  c = dsub(s0, s2);
+  b = dadd(s1, s3);
+  d = dsub(s1, s3);
+}
+
+__device__ __forceinline__ void d_dft16(cd v[16]) {
+  const double c1 = 0.92387953251128673848, s1 = 0.38268343236508977173;   // cos, sin(pi/8)
+  const double h = 0.70710678118654752440;
+#pragma unroll
+  for (int n1 = 0; n1 < 4; ++n1) d_dft4(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);
+  v[5] = dmul(v[5], make_double2(c1, -s1));
+  v[9] = dmul(v[9], make_double2(h, -h));
+  v[13] = dmul(v[13], make_double2(s1, -c1));
+  v[6] = dmul(v[6], make_double2(h, -h));
+  v[10] = dmul_mi(v[10]);
+  v[14] = dmul(v[14], make_double2(-h, -h));
+  v[7] = dmul(v[7], make_double2(s1, -c1));
+  v[11] = dmul(v[11], make_double2(-h, -h));
+  v[15] = dmul(v[15], make_double2(-c1, s1));
+#pragma unroll
+  for (int k2 = 0; k2 < 4; ++k2) d_dft4(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
+  cd t;
+#define GCWT_SWAP(a, b) t = v[a]; v[a] = v[b]; v[b] = t;
+  GCWT_SWAP(1, 4) GCWT_SWAP(2, 8) GCWT_SWAP(3, 12) GCWT_SWAP(6, 9) GCWT_SWAP(7, 13) GCWT_SWAP(11, 14)
+#undef GCWT_SWAP
+}
+
+__device__ __forceinline__ void d_dft2(cd& a, cd& b) {
+  const cd s = dadd(a, b), d = dsub(a, b);
+  a = s;
+  b = d;
+}
+
+template <int Q>
+__device__ __forceinline__ void d_dft_small(cd v[Q]) {
+  if (Q == 2) d_dft2(v[0], v[1]);
+  else if (Q == 4) d_dft4(v[0], v[1], v[2], v[3]);
+  else if (Q == 16) d_dft16(v);
+}
+
+// exchange planes of the FFT256: 17 doubles per row of 16, columns 290 doubles apart (lanes run
+// over the columns: 2 (290 s + 17 t) words keeps a half-wave on different banks)
+constexpr int kDPitch = 17;
+constexpr int kDCol = 290;
+constexpr size_t kDPlaneBytes = (size_t)16 * kDCol * sizeof(double);      // one plane of 16 columns
+constexpr size_t kFwd64Lds = 2 * kDPlaneBytes + 256 * sizeof(cd);         // planes + twiddle table
+
+// 256-point forward FFT by 16 threads: v[j] = in[t + 16 j] -> out[t + 16 j]; tw_t[16 m2] = W256^(-t m2)
+// from an LDS table.  One __syncthreads inside.
+__device__ __forceinline__ void d_fft256(cd v[16], const cd* tw_t, double* ex_re, double* ex_im, int t) {
+  d_dft16(v);
+#pragma unroll
+  for (int m2 = 0; m2 < 16; ++m2) {
+    const cd u = dmul(v[m2], tw_t[16 * m2]);
+    ex_re[t * kDPitch + m2] = u.x;
+    ex_im[t * kDPitch + m2] = u.y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1)
+    v[k1] = make_double2(ex_re[k1 * kDPitch + t], ex_im[k1 * kDPitch + t]);
+  d_dft16(v);
+}
+
+// exp(-2 pi i num / 2^lg), lg <= 24: tw_hi[a] = exp(-2 pi i a / 4096), tw_lo[b] = exp(-2 pi i b / 2^24)
+__device__ __forceinline__ cd d_phase(const cd* __restrict__ tw_hi, const cd* __restrict__ tw_lo, int64_t num, int lg) {
+  const uint32_t m = (uint32_t)(num & (((int64_t)1 << lg) - 1)) << (24 - lg);
+  return dmul(tw_hi[m >> 12], tw_lo[m & 4095]);
+}
+
+__device__ __forceinline__ void d_fill_twl(cd* twl, const cd* __restrict__ tw_hi, int tid) {
+  twl[tid] = tw_hi[((((tid & 15) * (tid >> 4)) & 255)) << 4];            // W256^(-t j) at [j][t]
+}
+
+// ---------------------------------------------------------------------------
+// Pass A, len = 256 (P = 2^20): two real columns per FFT256 (kernels.hip: k_fft_cols256_real2).
+// Rows 0 .. 128 are written; with rows_out = 256 the mirrored rows too (plans with full-band
+// scales read the whole spectrum).  grid (ld / 32, slots), dynamic LDS kFwd64Lds
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __restrict__ in, cd* __restrict__ out,
+                                                             int ld, int64_t in_cstride, int64_t out_cstride,
+                                                             int lg_p, const cd* __restrict__ tw_hi,
+                                                             const cd* __restrict__ tw_lo,
+                                                             const double* __restrict__ sums, double inv_n,
+                                                             const SegIn segs, int rows_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* const ex_re = reinterpret_cast<double*>(smem);
+  double* const ex_im = ex_re + 16 * kDCol;
+  cd* const tile = reinterpret_cast<cd*>(smem);                          // aliases the planes
+  cd* const twl = reinterpret_cast<cd*>(smem + 2 * kDPlaneBytes);
+  const int c = blockIdx.y, col0 = blockIdx.x * 32, tid = threadIdx.x;   // c: workspace slot
+  const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
+  const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+  const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
+  const double mean = sums[ch] * inv_n;      // transforms.py:142-143: float64 copy minus the global mean
+  const int s = tid & 15, t = tid >> 4;
+  d_fill_twl(twl, tw_hi, tid);
+  cd v[16];
+  const int64_t top = n_valid > 0 ? n_valid - 1 : 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t n = (int64_t)(t + 16 * j) * ld + col0 + 2 * s;
+    const int64_t na = min(max(n, n_lead), top), nb = min(max(n + 1, n_lead), top);
+    const float a = x[na], b = x[nb];               // clamped: no branch around the loads
+    v[j] = make_double2(n >= n_lead && n < n_valid ? (double)a - mean : 0.0,
+                        n + 1 >= n_lead && n + 1 < n_valid ? (double)b - mean : 0.0);
+  }
+  __syncthreads();                                   // the twiddle table
+  d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
+  __syncthreads();                                   // the tile aliases the planes
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tile[(t + 16 * j) * 17 + s] = v[j];
+  __syncthreads();
+  // split and twiddle: thread = one real column, rows k = k0 + 8 i
+  const int cr = tid & 31, k0 = tid >> 5, m = cr >> 1;
+  const bool odd = cr & 1;
+  const int64_t col = col0 + cr;
+  cd w = d_phase(tw_hi, tw_lo, col * k0, lg_p);
+  const cd st = d_phase(tw_hi, tw_lo, col * 8, lg_p);
+  cd* o = out + (int64_t)c * out_cstride + col;
+  for (int k = k0; k <= 128; k += 8) {
+    const cd zk = tile[k * 17 + m], zm = tile[((256 - k) & 255) * 17 + m];
+    const cd val = odd ? make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x))
+                       : make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+    o[(int64_t)k * ld] = dmul(val, w);
+    if (rows_out > 129 && k > 0 && k < 128)          // Y0[256 - k] = conj(Y0[k]) for a real column
+      o[(int64_t)(256 - k) * ld] = dmul(dconj(val), d_phase(tw_hi, tw_lo, col * (256 - k), lg_p));
+    w = dmul(w, st);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Pass A, len = 256 q, q = 2 or 4 (P = 2^21, 2^22): two real subsequences of a column per FFT256
+// (kernels.hip: k_fft_colsq_real2).  grid (ld / 16, slots); dynamic LDS kFwd64Lds (+ one tile for q = 4)
+// ---------------------------------------------------------------------------
+template <int LQ>
+__global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restrict__ in, cd* __restrict__ out,
+                                                           int ld, int64_t in_cstride, int64_t out_cstride,
+                                                           int lg_p, const cd* __restrict__ tw_hi,
+                                                           const cd* __restrict__ tw_lo,
+                                                           const double* __restrict__ sums, double inv_n,
+                                                           const SegIn segs, int rows_out) {
+  constexpr int q = 1 << LQ, len = 256 * q, np = q / 2;
+  static_assert(q == 2 || q == 4, "two or four subsequences");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* const ex_re = reinterpret_cast<double*>(smem);
+  double* const ex_im = ex_re + 16 * kDCol;
+  cd* const planes = reinterpret_cast<cd*>(smem);                        // last pair's tile aliases the planes
+  cd* const twl = reinterpret_cast<cd*>(smem + 2 * kDPlaneBytes);
+  cd* const tile0 = twl + 256;                                           // first pair's tile (q = 4)
+  const int c = blockIdx.y, col0 = blockIdx.x * 16, tid = threadIdx.x;
+  const int s = tid & 15, t = tid >> 4;
+  d_fill_twl(twl, tw_hi, tid);
+  const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
+  const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+  const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
+  const double mean = sums[ch] * inv_n;
+  const int64_t top = n_valid > 0 ? n_valid - 1 : 0;
+  cd v[16], u[np > 1 ? 16 : 1];
+#pragma unroll
+  for (int p = 0; p < np; ++p) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t na = (int64_t)(q * (t + 16 * j) + 2 * p) * ld + col0 + s, nb = na + ld;
+      const float xa = x[min(max(na, n_lead), top)], xb = x[min(max(nb, n_lead), top)];   // clamped
+      v[j] = make_double2(na >= n_lead && na < n_valid ? (double)xa - mean : 0.0,
+                          nb >= n_lead && nb < n_valid ? (double)xb - mean : 0.0);
+    }
+    __syncthreads();                      // twiddle table written / previous exchange read
+    d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
+    if (p < np - 1) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { tile0[(t + 16 * j) * 17 + s] = v[j]; u[j] = v[j]; }
+    }
+  }
+  __syncthreads();                        // the last pair's tile aliases the planes
+#pragma unroll
+  for (int j = 0; j < 16; ++j) planes[(t + 16 * j) * 17 + s] = v[j];
+  __syncthreads();
+  cd* o = out + (int64_t)c * out_cstride + col0 + s;
+  const int64_t col = col0 + s;
+  const cd stq = d_phase(tw_hi, tw_lo, col * 256, lg_p), st16 = d_phase(tw_hi, tw_lo, col * 16, lg_p);
+  cd wj = d_phase(tw_hi, tw_lo, col * t, lg_p);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int kb = t + 16 * j, km = (256 - kb) & 255;
+    cd w[q];
+#pragma unroll
+    for (int p = 0; p < np; ++p) {
+      const cd zk = p < np - 1 ? u[j] : v[j];
+      const cd zm = p < np - 1 ? tile0[km * 17 + s] : planes[km * 17 + s];
+      const cd xa = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+      const cd xb = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+      // W_len^(-a kb), a = 2p, 2p + 1: index a kb (4096 / len) of the 4096 table
+      w[2 * p] = p == 0 ? xa : dmul(xa, tw_hi[(2 * p * kb * (kRowLenDev / len)) & 4095]);
+      w[2 * p + 1] = dmul(xb, tw_hi[((2 * p + 1) * kb * (kRowLenDev / len)) & 4095]);
+    }
+    d_dft_small<q>(w);
+    cd ph = wj;
+#pragma unroll
+    for (int ka = 0; ka < q; ++ka) {
+      const int k = kb + 256 * ka;
+      if (k < rows_out) o[(int64_t)k * ld] = dmul(w[ka], ph);
+      ph = dmul(ph, stq);
+    }
+    wj = dmul(wj, st16);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Pass A, any len = 1 .. 128 (P = 2^12 .. 2^19): radix-2 in LDS, 16 columns per workgroup
+// (kernels.hip: k_fft_cols<-1, true>).  grid (ld / 16, slots), dynamic LDS len * 16 * 16 bytes
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fwd64_cols_small(const float* __restrict__ in, cd* __restrict__ out,
+                                                          int len, int log2len, int ld, int64_t in_cstride,
+                                                          int64_t out_cstride, int lg_p,
+                                                          const cd* __restrict__ tw_hi, const cd* __restrict__ tw_lo,
+                                                          const double* __restrict__ sums, double inv_n,
+                                                          const SegIn segs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cd* buf = reinterpret_cast<cd*>(smem);
+  const int c = blockIdx.y, col0 = blockIdx.x * 16, total = len * 16;
+  const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
+  const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+  const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
+  const double mean = sums[ch] * inv_n;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int i = e >> 4, cc = e & 15;
+    const int64_t n = (int64_t)i * ld + col0 + cc;
+    buf[e] = make_double2(n >= n_lead && n < n_valid ? (double)x[n] - mean : 0.0, 0.0);
+  }
+  __syncthreads();
+  const int half_total = 16 * (len >> 1);
+  for (int h = len >> 1, st = 0; h >= 1; h >>= 1, ++st) {          // decimation in frequency
+    for (int b = threadIdx.x; b < half_total; b += 256) {
+      const int f = b & 15, j = b >> 4;
+      const int pos = j & (h - 1);
+      const int i0 = ((j - pos) << 1) + pos;
+      cd* p0 = buf + i0 * 16 + f;
+      cd* p1 = p0 + h * 16;
+      const cd a = *p0, cc = *p1;
+      const cd w = tw_hi[(pos << st) * (kRowLenDev >> log2len)];
+      *p0 = dadd(a, cc);
+      *p1 = dmul(dsub(a, cc), w);
+    }
+    __syncthreads();
+  }
+  cd* o = out + (int64_t)c * out_cstride;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int k = e >> 4, cc = e & 15;
+    const int kr = log2len ? (int)(__brev((unsigned)k) >> (32 - log2len)) : 0;
+    cd v = buf[kr * 16 + cc];
+    if (len > 1) v = dmul(v, d_phase(tw_hi, tw_lo, (int64_t)k * (col0 + cc), lg_p));
+    o[(int64_t)k * ld + col0 + cc] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Pass B: one 4096-point row per workgroup -- FFT256 over the 16 stride-16 subsequences, twiddle
+// W_4096^(-kb a), DFT16 over a (kernels.hip: rows_fast_body<-1, 4>) -- float64 in, float32 out.
+//   mirror > 0: outputs below 2048 go to row `row`, the upper half as the reflected lower half of
+//   row mirror - row (spectrum of a real signal, k1-major); mirror = 0: outputs below out_len.
+// grid (n_rows, slots), dynamic LDS kFwd64Lds
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int dpad(int i) { return i + (i >> 4); }
+
+__global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, float2* __restrict__ out,
+                                                    int64_t in_cstride, int64_t out_cstride,
+                                                    const cd* __restrict__ tw_hi, int out_len, int mirror) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* const ex_re = reinterpret_cast<double*>(smem);
+  double* const ex_im = ex_re + 16 * kDCol;
+  cd* const buf = reinterpret_cast<cd*>(smem);                           // 4096 (+256 pad) elements, aliases the planes
+  cd* const twl = reinterpret_cast<cd*>(smem + 2 * kDPlaneBytes);
+  const int tid = threadIdx.x, a = tid & 15, t = tid >> 4, row = blockIdx.x;
+  const cd* x = in + (int64_t)blockIdx.y * in_cstride + (int64_t)row * kRowLenDev;
+  float2* o = out + (int64_t)blockIdx.y * out_cstride;
+  d_fill_twl(twl, tw_hi, tid);
+  cd v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = x[16 * (t + 16 * j) + a];
+  __syncthreads();
+  d_fft256(v, twl + t, ex_re + a * kDCol, ex_im + a * kDCol, t);
+  __syncthreads();                       // the element buffer aliases the exchange planes
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int kb = t + 16 * j;
+    buf[dpad(16 * kb + a)] = dmul(v[j], tw_hi[(kb * a) & 4095]);
+  }
+  __syncthreads();
+  const int kb = tid;
+  cd u[16];
+#pragma unroll
+  for (int aa = 0; aa < 16; ++aa) u[aa] = buf[dpad(16 * kb + aa)];
+  d_dft16(u);
+#pragma unroll
+  for (int ka = 0; ka < 16; ++ka) {
+    const int idx = kb + 256 * ka;
+    const float2 val = make_float2((float)u[ka].x, (float)u[ka].y);
+    if (mirror == 0) {
+      if (256 * ka < out_len) o[(int64_t)row * kRowLenDev + idx] = val;
+    } else if (idx < kRowLenDev / 2) {
+      o[(int64_t)row * kRowLenDev + idx] = val;
+    } else if (row > 0 && 2 * row < mirror) {
+      o[(int64_t)(mirror - row) * kRowLenDev + (kRowLenDev - 1 - idx)] = make_float2(val.x, -val.y);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int ilog2_64(int64_t v) { int l = 0; while (((int64_t)1 << l) < v) ++l; return l; }
+
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+  return bytes > 48 * 1024 ? hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+                           : hipSuccess;
+}
+
+// tables: [0, 4096) W_4096^a, [4096, 8192) W_2^24^b
+void fwd64_fill_tables(double2* host) {
+  for (int a = 0; a < 4096; ++a) {
+    const double ang = -2.0 * M_PI * (double)a / 4096.0;
+    host[a] = make_double2(std::cos(ang), std::sin(ang));
+  }
+  // exact at the eighths of the circle (cos / sin of float64 multiples of pi are not)
+  host[0] = make_double2(1.0, 0.0); host[1024] = make_double2(0.0, -1.0);
+  host[2048] = make_double2(-1.0, 0.0); host[3072] = make_double2(0.0, 1.0);
+  for (int b = 0; b < 4096; ++b) {
+    const double ang = -2.0 * M_PI * (double)b / 16777216.0;
+    host[4096 + b] = make_double2(std::cos(ang), std::sin(ang));
+  }
+}
+
+hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cstride, int64_t y_cstride,
+                             int64_t p, const double2* tables, const double* sums, double inv_n,
+                             const SegIn& segs, int n_segments, int rows_out, hipStream_t st) {
+  const int slots = segs.n_channels * n_segments, ld = kRowLenDev, lg_p = ilog2_64(p);
+  const cd* tw_hi = tables;
+  const cd* tw_lo = tables + 4096;
+  if (lg_p > 24 || ((int64_t)p1 * kRowLenDev) != p) return hipErrorInvalidValue;
+  hipError_t e;
+  if (p1 == 256) {
+    if ((e = allow_lds(k_fwd64_cols256_real2, kFwd64Lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fwd64_cols256_real2, dim3(ld / 32, slots), dim3(256), kFwd64Lds, st, in, y, ld,
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out);
+  } else if (p1 == 512) {
+    if ((e = allow_lds(k_fwd64_colsq_real2<1>, kFwd64Lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fwd64_colsq_real2<1>, dim3(ld / 16, slots), dim3(256), kFwd64Lds, st, in, y, ld,
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out);
+  } else if (p1 == 1024) {
+    const size_t lds = kFwd64Lds + 256 * 17 * sizeof(cd);
+    if ((e = allow_lds(k_fwd64_colsq_real2<2>, lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fwd64_colsq_real2<2>, dim3(ld / 16, slots), dim3(256), lds, st, in, y, ld,
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out);
+  } else if (p1 >= 1 && p1 <= 128) {
+    const size_t lds = (size_t)p1 * 16 * sizeof(cd);
+    hipLaunchKernelGGL(k_fwd64_cols_small, dim3(ld / 16, slots), dim3(256), lds, st, in, y, p1, ilog2_64(p1), ld,
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
+                             const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st) {
+  hipError_t e = allow_lds(k_fwd64_rows, kFwd64Lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_fwd64_rows, dim3(n_rows, n_slots), dim3(256), kFwd64Lds, st, y, x, y_cstride, x_cstride,
+                     tables, out_len, mirror);
+  return hipGetLastError();
+}
+
+}  // namespace gcwt

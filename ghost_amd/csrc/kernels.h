@@ -208,10 +208,26 @@ hipError_t launch_fft_cols_batch(const float* in, float2* out, int len, int ld, 
                                  int64_t out_cstride, int64_t tw_n, const float2* tw4096,
                                  const float2* tw256, const double* sums, double inv_n,
                                  const SegIn& segs, int n_segments, hipStream_t st, int rows_out);
+// Low cut of a level's slice of the spectrum (precision = high; planner.h: LevelPlan::taper_hi): element
+// i of row r is bin k = r + p1 i; it is multiplied by 0 for k <= k0, by 1 for k >= k0 + 1 / inv_width and
+// by half a cosine in between.  p1 = 0: no cut.
+struct RowTaper {
+  int32_t p1 = 0;
+  float k0 = 0.f, inv_width = 0.f;
+};
 hipError_t launch_fft_rows(int sign, const float2* in, float2* out, int len, int64_t n_rows,
                            int64_t in_ld, int64_t out_ld, int64_t in_cstride, int64_t out_cstride,
                            int64_t tw_n, const float2* tw4096, const float2* tw256, float scale,
-                           int n_channels, hipStream_t st, int out_len = 0, int mirror = 0);
+                           int n_channels, hipStream_t st, int out_len = 0, int mirror = 0,
+                           RowTaper taper = RowTaper());
+// float64 forward transform (fwd64.hip): pass A real columns -> y (float64), pass B rows -> the float32
+// k1-major spectrum; tables from fwd64_fill_tables (8192 double2)
+void fwd64_fill_tables(double2* host);
+hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cstride, int64_t y_cstride,
+                             int64_t p, const double2* tables, const double* sums, double inv_n,
+                             const SegIn& segs, int n_segments, int rows_out, hipStream_t st);
+hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
+                             const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st);
 // shifted band of a level: Xs[k1][j2] = X[k1 + P1 (j2 - u2)] from the positive half of a real signal's
 // k1-major spectrum (kernels.hip: k_shift_gather)
 hipError_t launch_shift_gather(const float2* x, float2* xs, int p1, int q, int u2, int64_t x_row,
@@ -234,7 +250,7 @@ hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi
                          int64_t col0, int64_t row_len, int64_t max_len, hipStream_t st);
 hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_t p1_stride,
                               int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,
-                              int n_channels, hipStream_t st);
+                              int n_channels, hipStream_t st, RowTaper taper = RowTaper());
 hipError_t launch_cmul_inplace(float2* a, const float2* b, int64_t n, hipStream_t st);
 // Bluestein pieces (arbitrary-length DFT, analytic signal)
 hipError_t launch_chirp_kernel(float2* b, int64_t N, int64_t P, hipStream_t st);

@@ -34,6 +34,12 @@ __device__ __forceinline__ cf mul_si(cf a) {
   return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
 }
 
+// low cut of a level's spectrum slice (kernels.h: RowTaper): factor for element i of row `row`
+__device__ __forceinline__ float row_taper(const RowTaper& tp, int row, int i) {
+  const float u = ((float)(row + tp.p1 * i) - tp.k0) * tp.inv_width;
+  return u >= 1.f ? 1.f : (u <= 0.f ? 0.f : 0.5f - 0.5f * cospif(u));
+}
+
 // ---------------------------------------------------------------------------
 // 16-point DFT in registers, natural order in and out.
 //   X[k] = sum_n x[n] exp(SIGN 2 pi i n k / 16)
@@ -389,7 +395,7 @@ __global__ void __launch_bounds__(256) k_fft_rows(const cf* __restrict__ in, cf*
                                                   int64_t out_ld, int64_t in_cstride,
                                                   int64_t out_cstride, int64_t tw_n,
                                                   const cf* __restrict__ tw4096, float scale,
-                                                  int n_rows) {
+                                                  int n_rows, const RowTaper tp) {
   __shared__ __attribute__((aligned(16))) cf buf[kRowLenDev];
   const int c = blockIdx.y;
   const int rows = kRowLenDev >> log2len;
@@ -397,7 +403,12 @@ __global__ void __launch_bounds__(256) k_fft_rows(const cf* __restrict__ in, cf*
   const cf* x = in + (int64_t)c * in_cstride;
   for (int e = threadIdx.x; e < kRowLenDev; e += 256) {
     const int r = e >> log2len, i = e & (len - 1);
-    buf[e] = row0 + r < n_rows ? x[(int64_t)(row0 + r) * in_ld + i] : make_float2(0.f, 0.f);
+    cf v = row0 + r < n_rows ? x[(int64_t)(row0 + r) * in_ld + i] : make_float2(0.f, 0.f);
+    if (tp.p1) {
+      const float f = row_taper(tp, row0 + r, i);
+      v = make_float2(v.x * f, v.y * f);
+    }
+    buf[e] = v;
   }
   __syncthreads();
   lds_fft_radix2<SIGN>(buf, len, log2len, rows, len, 1, tw4096);
@@ -468,6 +479,7 @@ __device__ __forceinline__ cf unit_phase(int64_t num, int64_t den, int sign) {
 
 __device__ __forceinline__ int pad32(int i) { return i + (i >> 5); }
 
+
 // Rows of length Q = 256 q, q = 1 << LQ: FFT256 over the stride-q subsequences,
 // twiddle W_Q^(kb a), DFT_q over a; output index kb + 256 ka is contiguous in kb.
 template <int SIGN, int LQ>
@@ -476,7 +488,7 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
                                                int64_t out_ld, int64_t tw_n,
                                                const cf* __restrict__ tw4096,
                                                const cf* __restrict__ tw256, float scale, int row0,
-                                               int n_rows, int out_len, int mirror) {
+                                               int n_rows, int out_len, int mirror, const RowTaper& tp) {
   constexpr int q = 1 << LQ, Q = 256 * q, rows = 16 >> LQ;
   const int tid = threadIdx.x;
   // Lanes run over the 16 interleaved subsequences (row, a) so that each load instruction
@@ -499,6 +511,14 @@ __device__ __forceinline__ void rows_fast_body(const cf* __restrict__ x, cf* __r
     for (int j = 0; j < 16; ++j) {
       const cf u = xp[q * 16 * j];
       v[j] = live ? u : make_float2(0.f, 0.f);
+    }
+    if (tp.p1 && ((float)(row0 + rr + tp.p1 * (q * t + a)) - tp.k0) * tp.inv_width < 1.f) {
+      // (the thread's lowest bin lies inside the cut: its higher ones may too)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float f = row_taper(tp, row0 + rr, q * t + a + q * 16 * j);
+        v[j] = make_float2(v[j].x * f, v[j].y * f);
+      }
     }
   }
   fft256_16t<SIGN>(v, tw, ex_re + s * col_stride, ex_im + s * col_stride, t);
@@ -569,7 +589,7 @@ __global__ void __launch_bounds__(256, 4) k_fft_rows_fast(const cf* __restrict__
                                                        int64_t in_cstride, int64_t out_cstride,
                                                        int64_t tw_n, const cf* __restrict__ tw4096,
                                                        const cf* __restrict__ tw256, float scale,
-                                                       int n_rows, int out_len, int mirror) {
+                                                       int n_rows, int out_len, int mirror, const RowTaper tp) {
   // the exchange planes (2 x 16 x 290 floats) alias the 4096(+128 pad)-element buffer of
   // the second stage
   __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
@@ -579,11 +599,11 @@ __global__ void __launch_bounds__(256, 4) k_fft_rows_fast(const cf* __restrict__
   cf* o = out + (int64_t)blockIdx.y * out_cstride;
   const int row0 = blockIdx.x * (16 >> lq);
   switch (lq) {
-    case 0: rows_fast_body<SIGN, 0>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
-    case 1: rows_fast_body<SIGN, 1>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
-    case 2: rows_fast_body<SIGN, 2>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
-    case 3: rows_fast_body<SIGN, 3>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
-    default: rows_fast_body<SIGN, 4>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror); break;
+    case 0: rows_fast_body<SIGN, 0>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror, tp); break;
+    case 1: rows_fast_body<SIGN, 1>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror, tp); break;
+    case 2: rows_fast_body<SIGN, 2>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror, tp); break;
+    case 3: rows_fast_body<SIGN, 3>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror, tp); break;
+    default: rows_fast_body<SIGN, 4>(x, o, buf, ex_re, ex_im, in_ld, out_ld, tw_n, tw4096, tw256, scale, row0, n_rows, out_len, mirror, tp); break;
   }
 }
 
@@ -1190,7 +1210,7 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
 __global__ void __launch_bounds__(256) k_level_small(const cf* __restrict__ x, cf* __restrict__ xr,
                                                      int n1, int log2n1, int q, int64_t row_stride,
                                                      int64_t x_cstride, int64_t xr_cstride,
-                                                     const cf* __restrict__ tw4096) {
+                                                     const cf* __restrict__ tw4096, const RowTaper tp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* buf = reinterpret_cast<cf*>(smem);
   const cf* xc = x + (int64_t)blockIdx.x * x_cstride;
@@ -1199,7 +1219,11 @@ __global__ void __launch_bounds__(256) k_level_small(const cf* __restrict__ x, c
     const int j1 = idx / q, m2 = idx - j1 * q;
     cf acc = make_float2(0.f, 0.f);
     for (int j2 = 0; j2 < q; ++j2) {          // q <= 4096, a power of two: the phases come from the table
-      const cf v = xc[(int64_t)j1 * row_stride + j2];
+      cf v = xc[(int64_t)j1 * row_stride + j2];
+      if (tp.p1) {
+        const float f = row_taper(tp, j1, j2);
+        v = make_float2(v.x * f, v.y * f);
+      }
       acc = cadd(acc, cmul(v, tw4096_at<1>(tw4096, ((j2 * m2) & (q - 1)) * (kRowLenDev / q))));
     }
     buf[idx] = cmul(acc, unit_phase((int64_t)j1 * m2, m, 1));
@@ -1500,7 +1524,7 @@ static hipError_t launch_fft_cols_segs(int sign, bool real_in, const void* in, c
 hipError_t launch_fft_rows(int sign, const cf* in, cf* out, int len, int64_t n_rows, int64_t in_ld,
                            int64_t out_ld, int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
                            const cf* tw4096, const cf* tw256, float scale, int n_channels,
-                           hipStream_t st, int out_len, int mirror) {
+                           hipStream_t st, int out_len, int mirror, RowTaper taper) {
   const int l2 = ilog2(len);
   if (mirror && !(len == kRowLenDev && tw256)) return hipErrorInvalidValue;   // fast 4096-point rows only
   const int rows = kRowLenDev / len;
@@ -1509,20 +1533,20 @@ hipError_t launch_fft_rows(int sign, const cf* in, cf* out, int len, int64_t n_r
     if (sign < 0)
       hipLaunchKernelGGL((k_fft_rows_fast<-1>), grid, block, 0, st, in, out, l2 - 8, in_ld, out_ld,
                          in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows,
-                         out_len > 0 ? out_len : len, mirror);
+                         out_len > 0 ? out_len : len, mirror, taper);
     else
       hipLaunchKernelGGL((k_fft_rows_fast<1>), grid, block, 0, st, in, out, l2 - 8, in_ld, out_ld,
                          in_cstride, out_cstride, tw_n, tw4096, tw256, scale, (int)n_rows,
-                         out_len > 0 ? out_len : len, mirror);
+                         out_len > 0 ? out_len : len, mirror, taper);
     GCWT_LAUNCH_CHECK();
     return hipSuccess;
   }
   if (sign < 0)
     hipLaunchKernelGGL((k_fft_rows<-1>), grid, block, 0, st, in, out, len, l2, in_ld, out_ld,
-                       in_cstride, out_cstride, tw_n, tw4096, scale, (int)n_rows);
+                       in_cstride, out_cstride, tw_n, tw4096, scale, (int)n_rows, taper);
   else
     hipLaunchKernelGGL((k_fft_rows<1>), grid, block, 0, st, in, out, len, l2, in_ld, out_ld,
-                       in_cstride, out_cstride, tw_n, tw4096, scale, (int)n_rows);
+                       in_cstride, out_cstride, tw_n, tw4096, scale, (int)n_rows, taper);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -1577,7 +1601,7 @@ hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, co
 
 hipError_t launch_level_small(const cf* x, cf* xr, int n1, int q, int64_t row_stride,
                               int64_t x_cstride, int64_t xr_cstride, const cf* tw4096,
-                              int n_channels, hipStream_t st) {
+                              int n_channels, hipStream_t st, RowTaper taper) {
   const size_t lds = (size_t)n1 * q * sizeof(cf);
   static bool attr_done[64] = {};            // per device: one process may drive several
   int dev_ = 0;
@@ -1590,7 +1614,7 @@ hipError_t launch_level_small(const cf* x, cf* xr, int n1, int q, int64_t row_st
     attr_set = true;
   }
   hipLaunchKernelGGL(k_level_small, dim3(n_channels), dim3(256), lds, st, x, xr, n1, ilog2(n1), q,
-                     row_stride, x_cstride, xr_cstride, tw4096);
+                     row_stride, x_cstride, xr_cstride, tw4096, taper);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }

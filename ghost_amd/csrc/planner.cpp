@@ -194,6 +194,14 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
   sp->theta_hi = 2.0 * M_PI * (double)(top + 1) / (double)L;
   sp->theta_neg = neg_to_nyquist ? M_PI : std::min(M_PI, 2.0 * M_PI * (double)neg / (double)L);
   sp->band_ok = sp->theta_hi + sp->theta_neg <= M_PI;
+  // theta_lo: from zero frequency up, the half-bins (side-lobe maxima) whose |G| stays below low_tol
+  {
+    const double low = hp.low_tol * pk;
+    int64_t m = 0;
+    const int64_t m_stop = std::min<int64_t>(m_pk, 4096);
+    while (m < m_stop && env(m) <= low) ++m;
+    sp->theta_lo = sp->theta_neg > 0.0 ? 0.0 : 2.0 * M_PI * (double)m / (double)L;
+  }
 
   // |psi(centre + t)|^2 = |(1/L) sum_j A_j e^{i theta_j t}|^2, same on both sides (A real);
   // total energy (1/L) sum A_j^2 (Parseval).  Walk in from t = L/2 until the tails hold
@@ -361,7 +369,11 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   hp->block = 256;
   hp->band_tol = prm.band_eps > 0 ? prm.band_eps : 2e-7;
   if (hp->band_tol > 1e-3) return fail(GCWT_ERR_INVALID, "band_eps too large");
-  if (const char* e = getenv("GHOSTCWT_SUPPORT_TOL")) hp->support_tol = atof(e);
+  if (prm.support_tol > 0) hp->support_tol = prm.support_tol;
+  if (hp->support_tol > 1e-2) return fail(GCWT_ERR_INVALID, "support_tol too large");
+  if (prm.reserved0 != 0) return fail(GCWT_ERR_INVALID, "gcwt_params.reserved0 must be 0 (caller built against an older ghostcwt.h?)");
+  if (prm.precision < 0 || prm.precision > 2) return fail(GCWT_ERR_INVALID, "bad precision (0 default, 1 fast, 2 high)");
+  hp->high_precision = prm.precision != GCWT_PRECISION_FAST;
   hp->freqs.assign(prm.freqs_hz, prm.freqs_hz + prm.n_freqs);
   hp->out_elem_bytes = prm.out_mode == GCWT_OUT_COMPLEX_C64 ? 8 : 4;
 
@@ -662,6 +674,18 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       if (shift > 0 && lp.scales.size() > 256)
         return fail(GCWT_ERR_UNSUPPORTED, "more than 256 heavy-tailed scales in one decimation level");
     }
+  }
+  // precision = high: the low cut of every x_R, below the band of all the scales that read it
+  // (a decimation's levels share x_R; a shifted band holds the negative frequencies: no cut)
+  if (hp->high_precision) {
+    std::vector<double> lo(hp->levels.size(), 1e30);
+    for (const LevelPlan& lp : hp->levels) {
+      double& o = lo[(size_t)lp.xr_owner];
+      if (lp.band_shift > 0) o = 0.0;
+      for (int i : lp.scales) o = std::min(o, hp->scales[i].theta_lo);
+    }
+    for (size_t l = 0; l < hp->levels.size(); ++l)
+      hp->levels[l].taper_hi = hp->levels[l].xr_owner == (int)l && lo[l] < 1e29 ? lo[l] : 0.0;
   }
   for (LevelPlan& lp : hp->levels) {
     lp.hop = B - 2 * lp.halo;

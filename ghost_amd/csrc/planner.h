@@ -45,6 +45,8 @@ struct ScalePlan {
   double theta_hi = 0;             // |G| <= band_tol * peak for theta in [theta_hi, 2 pi - theta_neg]
   double theta_neg = 0;            // ... : how far below zero frequency the response still matters (the side
                                    // lobes of the L-tap truncation; 0 for the default wavelet)
+  double theta_lo = 0;             // |G| <= low_tol * peak for theta in [0, theta_lo]: what a level may cut out of its
+                                   // slice of the spectrum before the float32 stages see it (precision = high)
   double support = 0;              // samples either side of the centre that hold all but
                                    // support_tol of the kernel's energy (L2)
   bool band_ok = false;            // theta_hi + theta_neg <= pi: some decimation R >= 2 is exact to band_tol
@@ -64,6 +66,9 @@ struct LevelPlan {
   int band_shift = 0;              // bins of the level's 256-point grid that lie BELOW zero frequency: the level's
                                    // band is [-band_shift, 256 - band_shift) * 2 pi / (256 R); x_R is made from that
                                    // slice of the spectrum (heavy-tailed wavelets; 0 for the default one)
+  double taper_hi = 0;             // precision = high, set on the level that owns x_R: the slice of the spectrum x_R is made
+                                   // from is cut to zero below taper_hi / 2 and raised (half a cosine) to one at taper_hi
+                                   // rad / sample -- below every gain of every scale that reads this x_R; 0: no cut
   // Interpolating synthesis (synthi.hip, interp.h; amplitude and power only): the level's scales
   // are made at q x the level's rate and brought to the full rate by a T-tap polyphase FIR.
   int interp_q = 0;                // phases of the 256-point inverse FFT per (block, scale); 0: not interpolated
@@ -112,6 +117,9 @@ struct HostPlan {
   int block = 256;                 // B
   double band_tol = 2e-7;          // out-of-band response tolerated, relative to the peak
   double support_tol = 4.5e-6;     // kernel energy (L2, relative) a block halo may cut off
+  double low_tol = 2e-8;           // response below a scale's band a level's low cut may drop, relative to the peak
+                                   // (the L-tap truncation's side lobes sit at 5e-9 .. 1e-8 there for the default wavelet)
+  bool high_precision = true;      // gcwt_params.precision: float64 forward transform + per-level low cut
   double w0 = 0;                   // (beta/gamma)^(1/gamma)          (morseutils.py:315)
   double base_length = 0;          // 2 sqrt2 sqrt(gamma beta)/w0 * 4 (morse.py:115-116)
   double u_lo = 0, u_hi = 0;       // continuous spectrum above 1e-18 of its peak on [u_lo, u_hi] * omega

@@ -83,7 +83,7 @@ class CwtPlan:
 
     def __init__(self, n_samples, n_channels, fs, freqs_hz, *, gamma=3.0, beta=20.0,
                  epoch_bounds=None, output="amplitude", device=-1, band_eps=0.0, block=0,
-                 max_fft_log2=0, normalization=None, order=0):
+                 max_fft_log2=0, normalization=None, order=0, precision=None, support_tol=0.0):
         self._handle = C.c_void_p()
         self.freqs = np.ascontiguousarray(freqs_hz, dtype=np.float64)
         if epoch_bounds is None:
@@ -112,6 +112,12 @@ class CwtPlan:
         if not 0 <= int(order) <= 32:
             raise ValueError("order must be between 0 and 32")
         p.wavelet_flags = int(order) | (_lib.WAVELET_ENERGY if normalization == "energy" else 0)
+        # 'high' (default): float64 forward transform and per-level low cut, the reference's dynamic
+        # range (it computes in float64: transforms.py:142-143); 'fast': float32 throughout
+        if precision not in (None, "default", "fast", "high"):
+            raise ValueError("precision must be 'fast' or 'high'")
+        p.precision = {None: 0, "default": 0, "fast": 1, "high": 2}[precision]
+        p.support_tol = float(support_tol)
         check(lib.gcwt_plan_create(C.byref(self._handle), C.byref(p)))
         self.n_samples, self.n_channels = int(n_samples), int(n_channels)
         self.n_freqs = int(self.freqs.size)

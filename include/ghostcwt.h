@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GCWT_ABI_VERSION 3
+#define GCWT_ABI_VERSION 4
 
 typedef enum {
   GCWT_OK = 0,
@@ -90,9 +90,25 @@ typedef struct {
                                   (morse.py:84-91).  Bits 0-7: order k of the orthogonal
                                   family (0 = first; morseutils.py:181-196); bit 8: 'energy'
                                   normalisation (morseutils.py:119-124, 186-189)         */
+  int32_t precision;           /* gcwt_precision; 0 = default (high)                                     */
+  int32_t reserved0;           /* must be 0                                                              */
+  double support_tol;          /* share of a kernel's energy (L2, relative) a block halo may cut off;
+                                  0 = 4.5e-6                                                              */
 } gcwt_params;
 
 #define GCWT_WAVELET_ENERGY 0x100
+
+/* The reference computes in float64 (transforms.py:142-143, convolution.py:68-77).  HIGH (the
+ * default): x - mean and the forward FFT of every epoch in float64, and every decimation level cuts
+ * its slice of the spectrum to zero below the band of its scales (where every gain is under 2e-8 of
+ * its peak) before the float32 stages: a band of the recording 100 x below the rest (1/f^3
+ * backgrounds, mains interference, drift, offsets) still meets 1e-5.  FAST: float32 throughout
+ * (rounds 1-3), for recordings whose spectrum is within ~10 x of flat across the analysed range. */
+typedef enum {
+  GCWT_PRECISION_DEFAULT = 0,
+  GCWT_PRECISION_FAST = 1,
+  GCWT_PRECISION_HIGH = 2
+} gcwt_precision;
 
 typedef struct {
   int32_t abi_version;
