@@ -113,7 +113,9 @@ struct gcwt_plan {
   float* d_gain = nullptr;    // [S][B] |H|
   float* d_gain_lv = nullptr; // the same rows in level-list order, transposed for k_synth7 (+8 zero rows)
   float2* d_half_tw = nullptr; // [levels][256] exp(-i pi k/(256 R))
-  float2* d_psi = nullptr;    // direct kernels
+  float2* d_psi = nullptr;    // direct kernels: running sums of the taps (kernels.hip: k_build_direct)
+  float2* d_psi_tail = nullptr; // [n_direct] sum of all taps of each
+  float2* d_psi_lit = nullptr;  // the literal taps, d_psi's layout (gcwt_direct_kernel)
   unsigned long long* d_probe = nullptr;   // GHOSTCWT_CLOCK_PROBE=1: [cycles, 100 MHz ticks] of the synthesis workgroups
   double* d_amps = nullptr;   // kept spectrum samples A_j of every scale (planner.h: amps)
   float2* d_xs = nullptr;     // [C][xs_stride] shifted slice of the spectrum of the level in hand (levels with a
@@ -172,7 +174,7 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
-  fr(p->d_y); fr(p->d_tw64); fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_xs); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_gain_lv); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_tw4096);
+  fr(p->d_y); fr(p->d_tw64); fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_xs); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_gain_lv); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_psi_tail); fr(p->d_psi_lit); fr(p->d_tw4096);
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
@@ -445,6 +447,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   if ((rc = dev_alloc(&p->d_bank, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_gain, (size_t)S * B))) return bail(rc);
   if ((rc = dev_alloc(&p->d_psi, (size_t)hp.direct_total))) return bail(rc);
+  if ((rc = dev_alloc(&p->d_psi_lit, (size_t)hp.direct_total))) return bail(rc);
+  if ((rc = dev_alloc(&p->d_psi_tail, (size_t)hp.n_direct))) return bail(rc);
   {   // zero taps in front of every kernel and behind it up to a multiple of 8 (+8): k_direct reads whole groups
     hipError_t hz = hipMemsetAsync(p->d_psi, 0, sizeof(float2) * (size_t)std::max<int64_t>(1, hp.direct_total), p->stream);
     if (hz != hipSuccess) return bail(hip_err(hz, "psi reset"));
@@ -641,7 +645,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   he = launch_scale_windows(p->d_gain, p->d_scale_list, p->n_listed, (float)hp.band_tol, p->d_gain_lv,
                             p->prune_inputs, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "scale_windows"));
-  he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, p->d_amps, p->stream);
+  he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, p->d_amps, p->d_psi_tail,
+                           p->d_psi_lit, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_direct"));
   he = hipStreamSynchronize(p->stream);  // host vectors above go out of scope
   if (he != hipSuccess) return bail(hip_err(he, "plan upload"));
@@ -988,7 +993,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     auto flush = [&]() -> int {
       if (ne > 0)
         RUN(ST_DIRECT, launch_direct(mode, dx, dout, p->d_psi, p->d_direct_sc, hp.n_direct, p->d_sums,
-                                     inv_n, N, S, eps, ne, r0, row_len, p->max_direct_len, st));
+                                     inv_n, N, S, eps, ne, r0, row_len, p->max_direct_len, p->d_psi_tail, st));
       ne = 0;
       return GCWT_OK;
     };
@@ -1157,7 +1162,7 @@ int gcwt_direct_kernel(gcwt_plan* p, int scale, float* psi) {
   if (s.method != GCWT_SCALE_DIRECT) return set_err(GCWT_ERR_INVALID, "not a direct scale");
   int rc = gcwt_plan_upload(p);
   if (rc) return rc;
-  HIP_TRY(hipMemcpy(psi, p->d_psi + s.direct_offset + direct_front_pad(s.length), sizeof(float2) * (size_t)s.length,
+  HIP_TRY(hipMemcpy(psi, p->d_psi_lit + s.direct_offset + direct_front_pad(s.length), sizeof(float2) * (size_t)s.length,
                     hipMemcpyDeviceToHost));
   return GCWT_OK;
 }
@@ -1213,6 +1218,20 @@ int gcwt_debug_level_band_shift(const gcwt_plan* p, int level, int32_t* shift) {
   if (!p || !shift) return set_err(GCWT_ERR_INVALID, "NULL argument");
   if (level < 0 || level >= (int)p->hp.levels.size()) return set_err(GCWT_ERR_INVALID, "level out of range");
   *shift = p->hp.levels[level].band_shift;
+  return GCWT_OK;
+}
+
+int gcwt_debug_level_low_cut(const gcwt_plan* p, int level, double* theta_cut) {
+  if (!p || !theta_cut) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  if (level < 0 || level >= (int)p->hp.levels.size()) return set_err(GCWT_ERR_INVALID, "level out of range");
+  const LevelPlan& own = p->hp.levels[p->hp.levels[level].xr_owner];
+  *theta_cut = p->hp.high_precision && own.band_shift == 0 ? own.taper_hi : 0.0;
+  return GCWT_OK;
+}
+
+int gcwt_debug_scale_theta_lo(const gcwt_plan* p, double* theta_lo) {
+  if (!p || !theta_lo) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  for (size_t i = 0; i < p->hp.scales.size(); ++i) theta_lo[i] = p->hp.scales[i].theta_lo;
   return GCWT_OK;
 }
 

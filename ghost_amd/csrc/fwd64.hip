@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) k_fwd64_cols_small(const float* __restric
                                                           int64_t out_cstride, int lg_p,
                                                           const cd* __restrict__ tw_hi, const cd* __restrict__ tw_lo,
                                                           const double* __restrict__ sums, double inv_n,
-                                                          const SegIn segs) {
+                                                          const SegIn segs, int rows_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* buf = reinterpret_cast<cd*>(smem);
   const int c = blockIdx.y, col0 = blockIdx.x * 16, total = len * 16;
@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(256) k_fwd64_cols_small(const float* __restric
   cd* o = out + (int64_t)c * out_cstride;
   for (int e = threadIdx.x; e < total; e += 256) {
     const int k = e >> 4, cc = e & 15;
+    if (k >= rows_out) continue;                     // (real input: the caller may keep rows 0 .. len/2 only)
     const int kr = log2len ? (int)(__brev((unsigned)k) >> (32 - log2len)) : 0;
     cd v = buf[kr * 16 + cc];
     if (len > 1) v = dmul(v, d_phase(tw_hi, tw_lo, (int64_t)k * (col0 + cc), lg_p));
@@ -380,7 +381,8 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
   const int slots = segs.n_channels * n_segments, ld = kRowLenDev, lg_p = ilog2_64(p);
   const cd* tw_hi = tables;
   const cd* tw_lo = tables + 4096;
-  if (lg_p > 24 || ((int64_t)p1 * kRowLenDev) != p) return hipErrorInvalidValue;
+  if (lg_p > 24 || ((int64_t)p1 * kRowLenDev) != p || rows_out < 1 || rows_out > p1 ||
+      (int64_t)rows_out * kRowLenDev > y_cstride) return hipErrorInvalidValue;     // y holds rows_out rows per slot
   hipError_t e;
   if (p1 == 256) {
     if ((e = allow_lds(k_fwd64_cols256_real2, kFwd64Lds)) != hipSuccess) return e;
@@ -398,7 +400,7 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
   } else if (p1 >= 1 && p1 <= 128) {
     const size_t lds = (size_t)p1 * 16 * sizeof(cd);
     hipLaunchKernelGGL(k_fwd64_cols_small, dim3(ld / 16, slots), dim3(256), lds, st, in, y, p1, ilog2_64(p1), ld,
-                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs);
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out);
   } else {
     return hipErrorInvalidValue;
   }

@@ -197,8 +197,9 @@ hipError_t launch_fullband_mul(const float2* x, const float2* h, float2* z, int6
 hipError_t launch_fullband_store(int mode, const float2* y, float* out, int64_t p, int scale,
                                  int n_scales, int64_t row_len, const SegOut& seg, int n_segments,
                                  hipStream_t st);
+// psi: per scale the running sums of its taps (tap L - 1 zero); tail[scale]: the sum of all taps (k_build_direct)
 hipError_t launch_build_direct(float2* psi, const DirectScale* sc, int n_direct, int64_t max_len,
-                               const double* amps, hipStream_t st);
+                               const double* amps, float2* tail, float2* psi_literal, hipStream_t st);
 hipError_t launch_fft_cols(int sign, bool real_in, const void* in, float2* out, int len, int ld,
                            int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
                            const float2* tw4096, const float2* tw256, const double* sums, double inv_n, int64_t n_valid,
@@ -247,7 +248,7 @@ struct DirectEpochs {                // time-domain scales: epochs handled by on
 hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi,
                          const DirectScale* sc, int n_direct, const double* sums, double inv_n,
                          int64_t n_samples, int n_scales, const DirectEpochs& eps, int n_epochs,
-                         int64_t col0, int64_t row_len, int64_t max_len, hipStream_t st);
+                         int64_t col0, int64_t row_len, int64_t max_len, const float2* tail, hipStream_t st);
 hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_t p1_stride,
                               int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,
                               int n_channels, hipStream_t st, RowTaper taper = RowTaper());

@@ -275,24 +275,55 @@ __global__ void k_scale_windows(const float* __restrict__ gain, int32_t* __restr
 // over the scale's kept spectrum samples A_j (planner.h: amps)    (morseutils.py:147-149)
 // grid (n_direct, ceil(Lmax/256))
 // ---------------------------------------------------------------------------
-__global__ void k_build_direct(cf* __restrict__ psi, const DirectScale* __restrict__ sc,
-                               const double* __restrict__ amps) {
+__global__ void __launch_bounds__(256) k_build_direct(cf* __restrict__ psi, const DirectScale* __restrict__ sc,
+                                                      const double* __restrict__ amps, cf* __restrict__ tail,
+                                                      cf* __restrict__ psi_literal) {
+  // The taps k_direct uses are the RUNNING SUMS Psi[j] = psi[0] + .. + psi[j], j < L - 1, applied to the first
+  // difference of the signal (summation by parts, exact:
+  //   sum_j x[q - j] psi[j] = Psi[L-1] x[q - L + 1] + sum_{j < L-1} Psi[j] (x[q - j] - x[q - j - 1]) ),
+  // so that float32 products are made with the increments of the recording, not with its level: a slow
+  // background 100 x a quiet band no longer costs that band its low bits (round 4).  Tap L - 1 is zero;
+  // tail[scale] = Psi[L-1], the kernel's response at zero frequency, multiplies x itself.
+  __shared__ double sre[256], sim[256];
   const DirectScale p = sc[blockIdx.x];
-  const int64_t n = (int64_t)blockIdx.y * 256 + threadIdx.x;
-  if (n >= p.length) return;
   const int64_t L = p.length;
-  double re = 0.0, im = 0.0;
-  for (int32_t i = 0; i < p.n_bins; ++i) {
-    const int64_t k = p.bin_lo + i;
-    // phase = pi k (L+1)/L + 2 pi k n / L, reduced exactly: (k (L+1 + 2n)) mod 2L over L
-    const int64_t q = (k * ((L + 1 + 2 * n) % (2 * L))) % (2 * L);
-    double sn, cs;
-    sincospi((double)q / (double)L, &sn, &cs);
-    const double a = amps[p.amp_offset + i];
-    re += a * cs;
-    im += a * sn;
+  double carry_re = 0.0, carry_im = 0.0;
+  for (int64_t n0 = 0; n0 < L; n0 += 256) {
+    const int64_t n = n0 + threadIdx.x;
+    double re = 0.0, im = 0.0;
+    if (n < L) {
+      for (int32_t i = 0; i < p.n_bins; ++i) {
+        const int64_t k = p.bin_lo + i;
+        // phase = pi k (L+1)/L + 2 pi k n / L, reduced exactly: (k (L+1 + 2n)) mod 2L over L
+        const int64_t q = (k * ((L + 1 + 2 * n) % (2 * L))) % (2 * L);
+        double sn, cs;
+        sincospi((double)q / (double)L, &sn, &cs);
+        const double a = amps[p.amp_offset + i];
+        re += a * cs;
+        im += a * sn;
+      }
+      re /= (double)L;
+      im /= (double)L;
+    }
+    if (n < L) psi_literal[p.offset + p.front + n] = make_float2((float)re, (float)im);   // (gcwt_direct_kernel: tests)
+    sre[threadIdx.x] = re;
+    sim[threadIdx.x] = im;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {               // inclusive scan
+      const double ar = threadIdx.x >= off ? sre[threadIdx.x - off] : 0.0;
+      const double ai = threadIdx.x >= off ? sim[threadIdx.x - off] : 0.0;
+      __syncthreads();
+      sre[threadIdx.x] += ar;
+      sim[threadIdx.x] += ai;
+      __syncthreads();
+    }
+    const double pr = carry_re + sre[threadIdx.x], pi = carry_im + sim[threadIdx.x];
+    if (n < L - 1) psi[p.offset + p.front + n] = make_float2((float)pr, (float)pi);
+    else if (n == L - 1) { psi[p.offset + p.front + n] = make_float2(0.f, 0.f); tail[blockIdx.x] = make_float2((float)pr, (float)pi); }
+    carry_re += sre[255];
+    carry_im += sim[255];
+    __syncthreads();
   }
-  psi[p.offset + p.front + n] = make_float2((float)(re / (double)L), (float)(im / (double)L));
 }
 
 // ---------------------------------------------------------------------------
@@ -1051,7 +1082,10 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a) {
 // ---------------------------------------------------------------------------
 // Direct scales: W[n] = sum_j (x[n + (L-1)/2 - j] - mean) psi[j] inside the epoch
 // (convolution.py:68-87 'same' crop; transforms.py:202-204), for kernels of up to
-// kDirectMaxLen taps.
+// kDirectMaxLen taps -- evaluated by parts (k_build_direct): the tile holds the first DIFFERENCE
+// d[m] = x~[m] - x~[m-1] of the mean-removed, zero-extended epoch (x[m] - x[m-1] inside it: exact or
+// rounded relative to the increment; x~[0] and -x~[Ne-1] at its two ends), the taps are the running
+// sums of psi, and the kernel's zero-frequency response times x~[q - L + 1] is added at the end.
 //
 // One workgroup owns kDirectTile consecutive output samples of one (epoch, channel): it
 // parks the samples those outputs need (tile + half the longest kernel on either side,
@@ -1111,7 +1145,7 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
                                                 const double* __restrict__ sums, double inv_n,
                                                 int64_t n_samples, int n_scales,
                                                 const DirectEpochs eps, int64_t col0,
-                                                int64_t row_len, int halo) {
+                                                int64_t row_len, int halo, const cf* __restrict__ tail) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
   constexpr int kStageWave = 512 * kElem + 32 * kElem;        // floats of one wave's transposition area
@@ -1125,9 +1159,17 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
   const float* xe = x + (int64_t)c * n_samples + epoch_start;
   // sample base - halo + i of the epoch is element i & 7 of chunk i >> 3
   const int n_tile = kDirectTile + 2 * halo;
+  float* const xt = tile + direct_chunk(n_tile >> 3) + 4 * kStageWave;   // x~ itself, plain layout (the tail term)
   for (int i = threadIdx.x; i < n_tile; i += 256) {
     const int64_t m = base - halo + i;
-    tile[direct_chunk(i >> 3) + (i & 7)] = m >= 0 && m < epoch_len ? (float)((double)xe[m] - mean) : 0.f;
+    const bool in = m >= 0 && m < epoch_len;
+    const float xv = in ? (float)((double)xe[m] - mean) : 0.f;
+    float d = 0.f;
+    if (m >= 1 && m < epoch_len) d = xe[m] - xe[m - 1];        // the mean cancels
+    else if (m == 0) d = xv;                                      // x~[0] - 0
+    else if (m == epoch_len) d = -(float)((double)xe[m - 1] - mean);   // 0 - x~[Ne - 1]
+    tile[direct_chunk(i >> 3) + (i & 7)] = d;
+    xt[i] = xv;
   }
   __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1158,6 +1200,15 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
         direct_group(acc, b0, b1, a0, a1, taps + 8);
       }
       taps += 16;
+    }
+    {   // + Psi[L-1] x~[q - L + 1]: the kernel's response at zero frequency times the signal itself
+      const cf tl = tail[d];
+      const float* xq = xt + halo + 8 * tid + (int)((p.length - 1) / 2) - (int)(p.length - 1);
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const float xv = xq[o];
+        acc[o] = v2f{fmaf(xv, tl.x, acc[o].x), fmaf(xv, tl.y, acc[o].y)};
+      }
     }
     // this thread's 8 * kElem floats, then the wave's 512 * kElem floats in runs of 4 per lane
     float v[8 * kElem];
@@ -1402,10 +1453,10 @@ hipError_t launch_scale_windows(const float* gain, int32_t* scale_list, int n_li
 }
 
 hipError_t launch_build_direct(cf* psi, const DirectScale* sc, int n_direct, int64_t max_len,
-                               const double* amps, hipStream_t st) {
+                               const double* amps, cf* tail, cf* psi_literal, hipStream_t st) {
   if (n_direct == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_build_direct, dim3(n_direct, (unsigned)((max_len + 255) / 256)), dim3(256),
-                     0, st, psi, sc, amps);
+  (void)max_len;
+  hipLaunchKernelGGL(k_build_direct, dim3(n_direct), dim3(256), 0, st, psi, sc, amps, tail, psi_literal);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -1577,7 +1628,7 @@ hipError_t launch_synth(int mode, const SynthArgs& a, int n_items, int n_channel
 hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, const DirectScale* sc,
                          int n_direct, const double* sums, double inv_n, int64_t n_samples,
                          int n_scales, const DirectEpochs& eps, int n_epochs, int64_t col0,
-                         int64_t row_len, int64_t max_len, hipStream_t st) {
+                         int64_t row_len, int64_t max_len, const cf* tail, hipStream_t st) {
   int64_t longest = 0;
   for (int e = 0; e < n_epochs; ++e) longest = std::max(longest, eps.g_hi[e] - eps.g_lo[e]);
   if (n_direct == 0 || n_epochs == 0 || longest <= 0) return hipSuccess;
@@ -1586,11 +1637,11 @@ hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, co
   // (front zeros included: top + front + 1 <= halo and L - top + 6 <= halo)
   const int halo = (int)(((max_len / 2 + 9) + 7) & ~7);
   const int elem = mode == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
-  const size_t lds = sizeof(float) * (size_t)((kDirectTile + 2 * halo) / 8 * 12 + 4 * 544 * elem);
+  const size_t lds = sizeof(float) * (size_t)((kDirectTile + 2 * halo) / 8 * 12 + 4 * 544 * elem + (kDirectTile + 2 * halo));
   dim3 grid((unsigned)((longest + kDirectTile - 1) / kDirectTile), 1, eps.n_channels * n_epochs), block(256);
 #define GCWT_DIRECT(M)                                                                       \
   hipLaunchKernelGGL((k_direct<M>), grid, block, lds, st, x, out, psi, sc, n_direct, sums,   \
-                     inv_n, n_samples, n_scales, eps, col0, row_len, halo)
+                     inv_n, n_samples, n_scales, eps, col0, row_len, halo, tail)
   if (mode == GCWT_OUT_AMPLITUDE_F32) GCWT_DIRECT(GCWT_OUT_AMPLITUDE_F32);
   else if (mode == GCWT_OUT_POWER_F32) GCWT_DIRECT(GCWT_OUT_POWER_F32);
   else GCWT_DIRECT(GCWT_OUT_COMPLEX_C64);

@@ -150,8 +150,11 @@ class CwtPlan:
                                           support.ctypes.data_as(f64p), n_bins.ctypes.data_as(i32p)))
         theta_neg = np.zeros(s, np.float64)
         check(lib.gcwt_debug_scale_theta_neg(self._handle, theta_neg.ctypes.data_as(f64p)))
+        theta_lo = np.zeros(s, np.float64)
+        check(lib.gcwt_debug_scale_theta_lo(self._handle, theta_lo.ctypes.data_as(f64p)))
         return {"method": method, "decimation": dec, "halo": halo, "hop": hop, "length": length,
-                "theta_hi": theta_hi, "theta_neg": theta_neg, "support": support, "n_bins": n_bins}
+                "theta_hi": theta_hi, "theta_neg": theta_neg, "theta_lo": theta_lo, "support": support,
+                "n_bins": n_bins}
 
     # -- device -----------------------------------------------------------
     def upload(self):
@@ -241,8 +244,10 @@ class CwtPlan:
                                             C.byref(hp), C.byref(nb), C.byref(m)))
             sh = C.c_int32()
             check(lib.gcwt_debug_level_band_shift(self._handle, l, C.byref(sh)))
+            cut = C.c_double()
+            check(lib.gcwt_debug_level_low_cut(self._handle, l, C.byref(cut)))
             res.append({"decimation": d.value, "halo": h.value, "hop": hp.value,
-                        "nblk": nb.value, "m": m.value, "band_shift": sh.value})
+                        "nblk": nb.value, "m": m.value, "band_shift": sh.value, "low_cut": cut.value})
         return res
 
     def debug_interp(self):

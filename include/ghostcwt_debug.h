@@ -22,6 +22,12 @@ int gcwt_debug_level_info(const gcwt_plan* plan, int epoch, int level, int32_t* 
 /* Bins of a level's 256-point grid that lie below zero frequency (heavy-tailed wavelets: the level's
  * band is [-shift, 256 - shift) * 2 pi / (256 R); 0 for the default wavelet). */
 int gcwt_debug_level_band_shift(const gcwt_plan* plan, int level, int32_t* shift);
+/* precision = high: x_R of the level's decimation is made from a slice of the spectrum that is zero
+ * below theta_cut / 2 and raised (half a cosine) to one at theta_cut radians per sample -- below the band
+ * of every scale that reads it (planner.h: LevelPlan::taper_hi); 0: no cut.  Per scale: theta_lo, up to
+ * which its exact response stays under 2e-8 of its peak. */
+int gcwt_debug_level_low_cut(const gcwt_plan* plan, int level, double* theta_cut);
+int gcwt_debug_scale_theta_lo(const gcwt_plan* plan, double* theta_lo);
 /* Segments of equal FFT length are launched together: first segment and size of the batch
  * that `segment` belongs to. */
 int gcwt_debug_batch_of(const gcwt_plan* plan, int segment, int32_t* first, int32_t* count);

@@ -3,7 +3,9 @@
 Per scale the engine's planner picks one of three evaluations of the SAME quantity, the
 convolution with the reference's L-tap kernel:
 
-  spectral   X = FFT_P(x - mean, zero padded); x_R = IFFT_{P/R}(X[0:P/R]) / R  -- for a level whose
+  spectral   X = FFT_P(x - mean, zero padded); x_R = IFFT_{P/R}(T_R X[0:P/R]) / R, T_R the level's low
+             cut (precision = high: zero below theta_cut / 2, half a cosine up to one at theta_cut, below
+             the band of every scale of the decimation; ``low_cut`` of ``debug_levels``)  -- for a level whose
              band starts `shift` bins of its 256-point grid below zero frequency (heavy-tailed
              wavelets), IFFT_{P/R}(X[-U : P/R - U]) with U = shift (P/R)/256 and every bin k
              below standing for the frequency k - shift;
@@ -62,6 +64,18 @@ def exact_response(theta, omega, length, gamma=3.0, beta=20.0, normalization="ba
     return exact_gain(theta, omega, length, gamma, beta, normalization, order) * np.exp(-1j * theta * d)
 
 
+def low_cut(theta_cut, p_big, m):
+    """T_R on bins 0 .. m-1 of a P-point grid (csrc/kernels.hip: row_taper)."""
+    if not theta_cut > 0:
+        return np.ones(m)
+    k1 = theta_cut * p_big / (2 * np.pi)
+    k0 = 0.5 * k1
+    if k1 - k0 < 1:
+        return np.ones(m)
+    u = np.clip((np.arange(m) - k0) / (k1 - k0), 0.0, 1.0)
+    return 0.5 - 0.5 * np.cos(np.pi * u)
+
+
 def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=256, plan=None,
                   normalization="bandpass", order=0):
     """Model output, complex128 (S, N).  ``plan``: a CwtPlan for the same layout (made
@@ -78,6 +92,7 @@ def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=25
                        normalization=normalization, order=order)
     si = plan.scale_info()
     shift_of = {lv["decimation"]: lv["band_shift"] for lv in plan.debug_levels()}
+    cut_of = {lv["decimation"]: lv["low_cut"] for lv in plan.debug_levels()}
     omegas = orc.hz_to_rad(freqs_hz, fs)
     lengths = orc.morse_lengths(omegas, gamma, beta)
     assert np.array_equal(lengths, si["length"])
@@ -105,7 +120,10 @@ def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=25
             shift = shift_of[R]
             if R not in xr_cache:
                 U = shift * M // B
-                xr_cache[R] = ifft(X[(np.arange(M) - U) % p_big]) / R      # the engine's x_R: bin u is frequency u - U
+                sl = X[(np.arange(M) - U) % p_big]
+                if not shift:
+                    sl = sl * low_cut(cut_of[R], p_big, M)
+                xr_cache[R] = ifft(sl) / R                                 # the engine's x_R: bin u is frequency u - U
             xr = xr_cache[R]
             k = np.arange(B)
             H = exact_response(2 * np.pi * (k - shift) / (B * R), om, L, gamma, beta, normalization, order)
@@ -140,6 +158,7 @@ def amplitude_interpolated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=2
     si, di, levels = plan.scale_info(), plan.debug_interp(), plan.debug_levels()
     by_r = {lv["decimation"]: d for lv, d in zip(levels, di["levels"])}
     shift_of = {lv["decimation"]: lv["band_shift"] for lv in levels}
+    cut_of = {lv["decimation"]: lv["low_cut"] for lv in levels}
     omegas = orc.hz_to_rad(freqs_hz, fs)
     xc = x - x.mean()
     fft_len = {(a, b): p for (a, b, p) in plan.segments()}
@@ -160,7 +179,10 @@ def amplitude_interpolated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=2
             assert kc % q == 0, (kc, q)
             M = p_big // R
             shift = shift_of[R]
-            xr = ifft(X[(np.arange(M) - shift * M // B) % p_big]) / R
+            sl = X[(np.arange(M) - shift * M // B) % p_big]
+            if not shift:
+                sl = sl * low_cut(cut_of[R], p_big, M)
+            xr = ifft(sl) / R
             k = np.arange(B)
             G = exact_gain(2 * np.pi * (k - shift) / (B * R), om, int(L), gamma, beta)
             tw = np.exp(2j * np.pi * np.outer(k, np.arange(q)) / (B * q))            # phase p of bin k

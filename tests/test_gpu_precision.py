@@ -1,0 +1,116 @@
+"""Parity on recordings whose spectrum is far from flat (round 4): 1/f^2 and 1/f^3 backgrounds, mains
+interference 30 x and 100 x the signal, drift 1000 x the signal, large offsets -- the inputs on which
+float32 transforms lose a quiet band's low bits.  The reference computes in float64
+(transforms.py:142-143, convolution.py:68-77); the engine's default precision ('high': float64
+forward FFT, per-level low cut, time-domain scales by parts) must meet the same 1e-5 gate here."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import ghost_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _run(x, fs, f, output, **kw):
+    from ghost_amd.engine import CwtPlan
+    p = CwtPlan(x.size, 1, fs, f, output=output, **kw)
+    got = p.execute(x[None])[0]
+    si = p.scale_info()
+    p.close()
+    return got, si
+
+
+def _offset(name, n, fs):
+    from ghost_amd.synthetic import power_law_noise
+    expo, off = {"f3_offset": (3.0, 100.37), "brown_offset": (2.0, -0.37)}[name]
+    return (power_law_noise(n, expo, 91) + off).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["brown", "f3", "line30", "line100", "drift1000", "f3_offset", "brown_offset"])
+def test_headline_scales_on_steep_spectra(name):
+    """N = 1e6 @ 1 kHz, the headline's 100 scales 200 .. 2 Hz (every decimation level), complex and
+    amplitude (the interpolating synthesis), against the oracle."""
+    from ghost_amd.synthetic import spectrum_class
+    fs, n = 1000.0, 1000000
+    f = np.geomspace(200.0, 2.0, 100)
+    x = _offset(name, n, fs) if name.endswith("_offset") else spectrum_class(name, n, fs)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f, n_threads=8)
+    c, si = _run(x, fs, f, "complex")
+    assert sorted(set(si["decimation"])) == [2, 4, 8, 16, 32, 64, 128]
+    e_c = rel_err(c, ref)
+    a, _ = _run(x, fs, f, "amplitude")
+    e_a = rel_err(a, np.abs(ref))
+    print("%s: complex %.2e amplitude %.2e" % (name, e_c.max(), e_a.max()))
+    assert e_c.max() < TOL and e_a.max() < TOL, (name, e_c.max(), e_a.max())
+
+
+def test_float32_front_end_is_what_fails_there():
+    """precision='fast' (rounds 1-3: float32 throughout) on the 1/f^3 recording: over the gate, which is
+    why 'high' is the default; on the pink workload data both meet it."""
+    from ghost_amd.synthetic import spectrum_class
+    fs, n = 1000.0, 1000000
+    f = np.geomspace(200.0, 2.0, 100)[::5]
+    x = spectrum_class("f3", n, fs)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f, n_threads=8)
+    fast, _ = _run(x, fs, f, "complex", precision="fast")
+    high, _ = _run(x, fs, f, "complex", precision="high")
+    e_f, e_h = rel_err(fast, ref).max(), rel_err(high, ref).max()
+    print("1/f^3: fast %.2e high %.2e" % (e_f, e_h))
+    assert e_h < 2e-6 and e_f > 5 * e_h
+    x = spectrum_class("pink_lfp", n, fs)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f, n_threads=8)
+    fast, _ = _run(x, fs, f, "complex", precision="fast")
+    assert rel_err(fast, ref).max() < TOL
+
+
+@pytest.mark.parametrize("name", ["f3", "f3_offset", "line100"])
+def test_default_grid_with_time_domain_scales_on_steep_spectra(name):
+    """The default grid reaches 0.39 fs: its top scales are time-domain convolutions (k_direct, by
+    parts).  Every scale of the grid, complex and amplitude."""
+    from ghost_amd.synthetic import spectrum_class
+    fs, n = 1000.0, 300000
+    f = orc.frequency_grid(fs, n)[::3]
+    x = _offset(name, n, fs) if name.endswith("_offset") else spectrum_class(name, n, fs)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f, n_threads=8)
+    c, si = _run(x, fs, f, "complex")
+    assert (si["method"] == 1).sum() >= 2
+    e_c = rel_err(c, ref)
+    a, _ = _run(x, fs, f, "amplitude")
+    e_a = rel_err(a, np.abs(ref))
+    print("%s: direct %.2e spectral %.2e (complex), %.2e (amplitude)" % (
+        name, e_c[si["method"] == 1].max(), e_c[si["method"] == 0].max(), e_a.max()))
+    assert e_c.max() < TOL and e_a.max() < TOL, (name, e_c, e_a)
+
+
+def test_config5_block_on_a_steep_spectrum():
+    """Config 5's regime -- 30 kHz, 200 scales 500 .. 1 Hz, time blocks of 2^22 samples, decimations up to
+    8192 -- on a 1/f^2 recording with an offset: rows spread over the levels against the oracle, over a
+    window that straddles a seam between time blocks."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import power_law_noise
+    fs, n, S = 30000.0, 6000000, 200
+    f = np.geomspace(500.0, 1.0, S)
+    x = (power_law_noise(n, 2.0, 5) + 3.0).astype(np.float32)
+    p = CwtPlan(n, 1, fs, f, output="amplitude")
+    segs = p.segments()
+    assert len(segs) >= 2
+    seam = segs[0][1]
+    a, ln = seam - 150000, 300000
+    got = p.execute_block(x[None], a, ln)[0]
+    om = orc.hz_to_rad(f, fs)
+    lengths = orc.morse_lengths(om)
+    xc = x.astype(np.float64)
+    xc -= xc.mean()
+    worst = 0.0
+    for sc in (0, 40, 80, 120, 160, 199):
+        L = int(lengths[sc])
+        psi, _ = orc.morse_kernel(L, om[sc])
+        w0, w1 = max(0, a - L), min(n, a + ln + L)
+        ref = np.abs(orc.overlap_add_convolve(xc[w0:w1], psi)[a - w0:a - w0 + ln])
+        e = float(np.abs(got[sc] - ref).max() / ref.max())
+        worst = max(worst, e)
+    print("config-5 block, brown + offset: worst %.2e" % worst)
+    assert worst < TOL
+    p.close()
