@@ -19,6 +19,7 @@
 #include "interp.h"
 #include "kernels.h"
 #include "morse_exact.h"
+#include "options.h"
 #include "planner.h"
 
 using namespace gcwt;
@@ -96,6 +97,7 @@ struct gcwt_plan {
   hipStream_t stream = nullptr;
   hipStream_t aux[2] = {nullptr, nullptr};   // the level passes of a batch run beside each other (run_pipeline)
   bool level_streams = true;  // GHOSTCWT_LEVEL_STREAMS=0: everything on `stream`
+  int interp_lgnb = -1;       // option interp_lgnb: blocks per k_synthi workgroup forced (A/B runs)
   int interp_grid = -1;       // GHOSTCWT_INTERP_GRID=0|1: k_synthi's grid order forced (default: by the number of channel slots)
   bool synth_streams = false; // GHOSTCWT_SYNTH_STREAMS=1: the interpolating kernel runs beside k_synth7 on aux[0] (its store-bound
                               // workgroups share the CUs with the arithmetic-bound ones: measured equal on the headline,
@@ -302,19 +304,19 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->hp.prm.n_epochs = (int32_t)(p->hp.bounds.size() / 2);
   p->device = params->device;
   p->high_precision = p->hp.high_precision;
-  if (const char* e = getenv("GHOSTCWT_SYNTH16")) p->use_synth16 = e[0] == '1';
-  if (const char* e = getenv("GHOSTCWT_SYNTH_COLS")) p->synth_cols = atoi(e) == 16 ? 16 : 32;
-  if (const char* e = getenv("GHOSTCWT_FUSE_BLOCKS")) p->fuse_blocks = e[0] != '0';
-  if (const char* e = getenv("GHOSTCWT_PRUNE_INPUTS")) p->prune_inputs = atoi(e) != 0;
-  if (getenv("GHOSTCWT_SLOW_FFT")) p->fast_fft = false;
-  if (const char* e = getenv("GHOSTCWT_LEVEL_STREAMS")) p->level_streams = atoi(e) != 0;
-  if (const char* e = getenv("GHOSTCWT_INTERP_GRID")) p->interp_grid = atoi(e) != 0;
-  if (const char* e = getenv("GHOSTCWT_SYNTH_STREAMS")) p->synth_streams = atoi(e) != 0;
-#ifdef GCWT_MEASURE
-  if (const char* e = getenv("GHOSTCWT_SYNTH_KERNEL")) p->synth_kernel = atoi(e) == 8 ? 8 : 7;
-  if (const char* e = getenv("GHOSTCWT_SYNTH_DROP_STORES")) p->drop_stores = std::max(1, atoi(e));   // tools/stage_times.py ablations
-  p->clock_probe = getenv("GHOSTCWT_CLOCK_PROBE") != nullptr;
-#endif
+  // options (options.h): read once, here; an execute never looks at them or at the environment
+  p->use_synth16 = option_or("synth16", 0) == 1;
+  p->synth_cols = option_or("synth_cols", 32) == 16 ? 16 : 32;
+  p->fuse_blocks = option_or("fuse_blocks", 1) != 0;
+  p->prune_inputs = option_or("prune_inputs", 1) != 0;
+  p->fast_fft = option_or("slow_fft", 0) == 0;
+  p->level_streams = option_or("level_streams", 1) != 0;
+  if (option_is_set("interp_grid")) p->interp_grid = option_or("interp_grid", 0) != 0;
+  p->synth_streams = option_or("synth_streams", 0) != 0;
+  p->interp_lgnb = (int)option_or("interp_lgnb", -1);
+  p->synth_kernel = kMeasureBuild && option_or("synth_kernel", 7) == 8 ? 8 : 7;
+  p->drop_stores = kMeasureBuild && option_is_set("synth_drop_stores") ? (int)std::max<long long>(1, option_or("synth_drop_stores", 1)) : 0;
+  p->clock_probe = kMeasureBuild && option_is_set("clock_probe");
   for (const auto& s : p->hp.scales)
     if (s.method == GCWT_SCALE_DIRECT) p->max_direct_len = std::max(p->max_direct_len, s.length);
   *out = p;
@@ -579,7 +581,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       // two blocks per workgroup up to R = 32, one from R = 64 up (measured per level,
       // profiles/r03_synth_study.md; the 16 columns of a pass are blocks x scales x phases).
       int lgnb = lp.decimation <= 32 ? 1 : 0;
-      if (const char* e = getenv("GHOSTCWT_INTERP_LGNB")) lgnb = std::min(std::max(atoi(e), 0), 2);   // (A/B runs; read at upload)
+      if (p->interp_lgnb >= 0) lgnb = std::min(p->interp_lgnb, 2);
       while (lgnb > 0 && (lp.interp_q << lgnb) > kInterpMaxPhases) --lgnb;
       // what k_synthi's indexing assumes (synthi.hip); the planner guarantees it
       if (lp.interp_q < 2 || lp.interp_q > kInterpMaxPhases || (lp.interp_q & (lp.interp_q - 1)) ||
@@ -1221,6 +1223,13 @@ int gcwt_debug_level_band_shift(const gcwt_plan* p, int level, int32_t* shift) {
   return GCWT_OK;
 }
 
+int gcwt_debug_set_option(const char* name, int64_t value, int clear) {
+  const int rc = option_set(name, (long long)value, clear != 0);
+  if (rc == -1) return set_err(GCWT_ERR_INVALID, std::string("unknown option: ") + (name ? name : "(null)"));
+  if (rc == -2) return set_err(GCWT_ERR_UNSUPPORTED, std::string("option ") + name + " exists in libghostcwt_measure.so only");
+  return GCWT_OK;
+}
+
 int gcwt_debug_level_low_cut(const gcwt_plan* p, int level, double* theta_cut) {
   if (!p || !theta_cut) return set_err(GCWT_ERR_INVALID, "NULL argument");
   if (level < 0 || level >= (int)p->hp.levels.size()) return set_err(GCWT_ERR_INVALID, "level out of range");
@@ -1295,7 +1304,7 @@ int gcwt_debug_clock(gcwt_plan* p, double* ghz, double* workgroup_seconds) {
   HIP_TRY(hipMemset(p->d_probe, 0, sizeof(v)));
   *ghz = v[1] ? (double)v[0] / (double)v[1] * 0.1 : 0.0;
   if (workgroup_seconds) *workgroup_seconds = (double)v[1] * 1e-8;
-  if (getenv("GHOSTCWT_CLOCK_PHASES") && v[6])   // mean microseconds into a k_synth7 workgroup's life at its marks
+  if (kMeasureBuild && option_is_set("clock_phases") && v[6])   // mean microseconds into a k_synth7 workgroup's life at its marks
     fprintf(stderr, "k_synth7 workgroups %llu: loads parked %.2f us, spectra exchanged %.2f, spectra done %.2f, loop starts %.2f, ends %.2f\n",
             v[6], v[2] * 0.01 / v[6], v[3] * 0.01 / v[6], v[4] * 0.01 / v[6], v[5] * 0.01 / v[6], v[1] * 0.01 / v[6]);
   return GCWT_OK;

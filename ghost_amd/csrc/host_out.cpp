@@ -1,4 +1,5 @@
 #include "host_out.h"
+#include "options.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -56,8 +57,8 @@ hipError_t HostOut::drain(const float* d_src, size_t src_pitch_floats, size_t n_
   // Tiles of the result: whole rows while they fit a staging buffer, else pieces of one
   // row (recordings longer than 8 M samples), so any row length streams through the ring.
   size_t chunk_floats = kChunkBytes / sizeof(float);
-  if (const char* env = getenv("GHOSTCWT_STAGE_FLOATS"))   // tests: force small tiles
-    chunk_floats = std::min(chunk_floats, std::max<size_t>(64, (size_t)atoll(env)));
+  if (option_is_set("stage_floats"))                        // tests: force small tiles
+    chunk_floats = std::min(chunk_floats, std::max<size_t>(64, (size_t)option_or("stage_floats", 0)));
   const size_t cols_per = std::min(row_floats, chunk_floats);
   const size_t rows_per = std::max<size_t>(1, chunk_floats / cols_per);
   const size_t col_tiles = (row_floats + cols_per - 1) / cols_per;

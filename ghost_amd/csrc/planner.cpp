@@ -2,6 +2,7 @@
 #include "planner.h"
 #include "interp.h"
 #include "morse_exact.h"
+#include "options.h"
 
 #include <algorithm>
 #include <climits>
@@ -14,11 +15,8 @@ namespace gcwt {
 
 // Decimated samples a block gives up at each edge beyond the kernel's measured support.  One is
 // structural (a phase r/R of the synthesis looks up to one decimated sample past its block
-// position); the second is slack.  GHOSTCWT_HALO_MARGIN overrides (measurement).
-static int halo_margin() {
-  const char* e = getenv("GHOSTCWT_HALO_MARGIN");
-  return e ? std::max(0, atoi(e)) : 2;
-}
+// position); the second is slack.  Option halo_margin overrides (measure build only).
+static int halo_margin() { return (int)std::max<long long>(0, option_or("halo_margin", 2)); }
 
 double morse_log_gain(double u, double gamma, double beta) {
   return beta * std::log(u) - (beta / gamma) * (std::pow(u, gamma) - 1.0);
@@ -243,8 +241,8 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
   // FFT-per-sample work and the interpolation does not pay (profiles/r03_synth_study.md);
   // GHOSTCWT_INTERP_MIN_R moves the line, GHOSTCWT_INTERP_Q sets the phases per scale (A/B runs).
   int min_r = 16, q = 2;
-  if (const char* e = getenv("GHOSTCWT_INTERP_MIN_R")) min_r = std::max(8, atoi(e));
-  if (const char* e = getenv("GHOSTCWT_INTERP_Q")) q = atoi(e) == 4 ? 4 : 2;
+  min_r = (int)std::max<long long>(8, option_or("interp_min_r", min_r));     // (measure build only)
+  q = option_or("interp_q", q) == 4 ? 4 : 2;
   if (R < min_r || R < 4 * q || lp->scales.empty()) return;     // I = R / q >= 4: a lane makes 4 samples of one interval
   while (R / q > kInterpMaxFactor) q *= 2;
   if (q > kInterpMaxPhases) return;                        // a pass of the kernel has 16 columns
@@ -528,8 +526,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   // 3.6.  Cost model per level: (3 + scales) / hop.  Only merges that keep the plain block
   // layout (halo <= 32) are taken.  GHOSTCWT_MERGE_LEVELS=0 keeps every scale at its largest R.
   {
-    const char* e = getenv("GHOSTCWT_MERGE_LEVELS");
-    if (!e || atoi(e) != 0) {
+    if (option_or("merge_levels", 1) != 0) {
       std::map<int, std::vector<int>> by_r;
       for (int i = 0; i < prm.n_freqs; ++i)
         if (hp->scales[i].method == GCWT_SCALE_SPECTRAL) by_r[hp->scales[i].decimation].push_back(i);
@@ -617,7 +614,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   // prologue is paid per level), so it is off by default.
   const int r_cap = (int)std::min<int64_t>(kMaxDecimation, pmin / B);
   bool split = false;
-  if (const char* e = getenv("GHOSTCWT_SPLIT_LEVELS")) split = e[0] == '1';
+  split = option_or("split_levels", 0) == 1;
   std::map<std::pair<int, int>, int> level_of;
   std::map<int, int> owner_of_r;
   for (int i = 0; i < prm.n_freqs; ++i) {
@@ -699,8 +696,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   }
   // GHOSTCWT_INTERP=0: every level on the FFT-per-sample kernels (A/B runs, tests)
   {
-    const char* e = getenv("GHOSTCWT_INTERP");
-    if (!e || atoi(e) != 0)
+    if (option_or("interp", 1) != 0)
       for (LevelPlan& lp : hp->levels) plan_interp_level(hp, &lp);
   }
 
@@ -724,7 +720,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   // the workspace, so the batch size is bounded by a memory budget.
   const int64_t C = prm.n_channels;
   int64_t budget = (int64_t)6 << 30;
-  if (const char* e = getenv("GHOSTCWT_BATCH_BYTES")) budget = std::max<int64_t>(0, atoll(e));
+  budget = std::max<int64_t>(0, option_or("batch_bytes", budget));
   for (size_t first = 0; first < hp->epochs.size();) {
     EpochPlan& lead = hp->epochs[first];
     int64_t blocks = 0;

@@ -11,7 +11,13 @@ import numpy as np
 from . import _lib
 from ._lib import lib, check
 
-__all__ = ["CwtPlan", "DeviceBuffer", "device_count", "device_name", "device_memory"]
+__all__ = ["CwtPlan", "DeviceBuffer", "set_option", "device_count", "device_name", "device_memory"]
+
+
+def set_option(name, value=None):
+    """Test / measurement switch of the library (include/ghostcwt_debug.h: gcwt_debug_set_option), read by
+    plans created afterwards; ``value=None`` restores the default."""
+    check(lib.gcwt_debug_set_option(name.encode(), 0 if value is None else int(value), 1 if value is None else 0))
 
 
 def device_count():

@@ -16,6 +16,15 @@ enum {
   GCWT_DEBUG_BLOCK_SPECTRA = 2  /* XB[blk][k] of one level, nblk*B complex values        */
 };
 
+/* Named switches read when a plan is created (csrc/options.h): which kernel instantiation or planning
+ * layout is used -- "synth16", "synth_cols", "fuse_blocks", "slow_fft", "level_streams", "interp",
+ * "interp_grid", "interp_lgnb", "synth_streams", "merge_levels", "split_levels" (all compute the same
+ * rows; the tests compare them) and the budgets "batch_bytes", "stage_floats".  Options that change
+ * accuracy or exist for measurements ("halo_margin", "interp_q", "interp_min_r", "prune_inputs",
+ * "clock_phases", "synth_kernel", "synth_drop_stores", "clock_probe") are refused with
+ * GCWT_ERR_UNSUPPORTED by the product library: libghostcwt_measure.so takes them.  clear != 0 returns
+ * the option to its default.  Process-wide; not part of the drop-in surface. */
+int gcwt_debug_set_option(const char* name, int64_t value, int clear);
 int gcwt_debug_level_count(const gcwt_plan* plan);
 int gcwt_debug_level_info(const gcwt_plan* plan, int epoch, int level, int32_t* decimation,
                           int32_t* halo, int32_t* hop, int32_t* nblk, int64_t* m);

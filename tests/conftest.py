@@ -29,3 +29,18 @@ def rel_err(y, ref):
     num = np.abs(y - ref).max(axis=-1)
     den = np.abs(ref).max(axis=-1)
     return num / den
+
+
+@pytest.fixture
+def option():
+    """Sets a named switch of the library (ghostcwt_debug.h: gcwt_debug_set_option) for the test and
+    restores the default afterwards: ``option("synth16", 1)``; ``option("synth16", None)`` clears."""
+    from ghost_amd.engine import set_option
+    touched = set()
+
+    def _set(name, value):
+        set_option(name, value)
+        touched.add(name)
+    yield _set
+    for name in touched:
+        set_option(name, None)

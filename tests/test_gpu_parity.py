@@ -115,7 +115,7 @@ def test_config2_reduced(golden):
     err = rel_err(c[0][:, g["cols"]], g["complex_cols"].astype(np.complex128))
     assert err.max() < TOL, err
     np.testing.assert_allclose(np.abs(c[0]).max(axis=1), g["amplitude_rowmax"], rtol=2e-5)
-    # amplitude / power go through the production kernel (k_synth7), all seven decimation levels
+    # amplitude / power: k_synth7 on the levels R = 2, 4, 8, the interpolating kernel k_synthi from R = 16 up
     # (the scales that reach R = 256 are folded into the R = 128 level)
     p, a = _plan(g["x"], float(g["fs"]), g["frequencies"], output="amplitude")
     assert sorted(set(p.scale_info()["decimation"])) == [2, 4, 8, 16, 32, 64, 128]
@@ -236,11 +236,11 @@ def test_integration_stub_from_the_docs_runs():
     assert rel_err(amp, ref).max() < TOL
 
 
-def test_fallback_synthesis_kernel(monkeypatch):
+def test_fallback_synthesis_kernel(option):
     """k_synth (16 columns, staged tile) serves, level by level, the layouts the production
     kernel does not take: block halos above 48 (a long kernel on a short epoch caps the
     decimation) and levels with more than 256 scales; halos of 33..48 run the production
-    kernel's deep-halo rows; GHOSTCWT_SYNTH16=1 forces the 16-column kernel everywhere."""
+    kernel's deep-halo rows; option synth16 = 1 forces the 16-column kernel everywhere."""
     from ghost_amd.engine import CwtPlan
     from ghost_amd.synthetic import lfp
     fs = 1000.0
@@ -260,7 +260,7 @@ def test_fallback_synthesis_kernel(monkeypatch):
     ref2 = np.abs(orc.cwt_complex(x1[0].astype(np.float64), fs, f2))
     assert rel_err(p2.execute(x1)[0], ref2).max() < TOL
     # forced, on a multi-epoch (batched) layout, every output mode
-    monkeypatch.setenv("GHOSTCWT_SYNTH16", "1")
+    option("synth16", 1)
     xs = lfp(2, 20000, fs)
     eb = [[i * 2000, i * 2000 + 1900] for i in range(10)]
     f3 = [150.0, 60.0, 25.0]
@@ -271,8 +271,8 @@ def test_fallback_synthesis_kernel(monkeypatch):
         assert (np.abs(p3.execute(xs) - want) / sc).max() < 2 * TOL, output
 
 
-def test_sixteen_column_build_of_the_production_kernel(monkeypatch):
-    """GHOSTCWT_SYNTH_COLS=16 and GHOSTCWT_SLOW_FFT=1 select the other instantiations
+def test_sixteen_column_build_of_the_production_kernel(option):
+    """Options synth_cols = 16 and slow_fft = 1 select the other instantiations
     (k_synth7<.,16>, radix-2 FFT passes): same gate."""
     from ghost_amd.engine import CwtPlan
     from ghost_amd.synthetic import lfp
@@ -280,12 +280,12 @@ def test_sixteen_column_build_of_the_production_kernel(monkeypatch):
     x = lfp(2, n, fs)
     f = [200.0, 90.0, 30.0, 11.0, 4.0]
     ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f) for c in range(2)])
-    monkeypatch.setenv("GHOSTCWT_SYNTH_COLS", "16")
+    option("synth_cols", 16)
     for output, want in (("complex", ref), ("amplitude", np.abs(ref))):
         p = CwtPlan(n, 2, fs, f, output=output)
         assert rel_err(p.execute(x), want).max() < TOL
-    monkeypatch.delenv("GHOSTCWT_SYNTH_COLS")
-    monkeypatch.setenv("GHOSTCWT_SLOW_FFT", "1")
+    option("synth_cols", None)
+    option("slow_fft", 1)
     p = CwtPlan(n, 2, fs, f, output="complex")
     assert rel_err(p.execute(x), ref).max() < TOL
 
@@ -629,7 +629,7 @@ def test_headline_workload_is_checked():
     xbuf.free()
 
 
-def test_host_results_of_any_row_length(monkeypatch):
+def test_host_results_of_any_row_length(option):
     """Host output streams through pinned staging tiles; rows longer than a tile (recordings
     beyond 8 M samples with the real 32 MB tiles) are cut by columns.  Forced here with
     small tiles: float64 (the reference's dtype, transform()'s default) and float32,
@@ -642,14 +642,14 @@ def test_host_results_of_any_row_length(monkeypatch):
         p, ref = _plan(x, fs, f, output=output)
         ref64 = p.execute(x, wide=True)
         np.testing.assert_array_equal(ref64, ref.astype(ref64.dtype))
-        monkeypatch.setenv("GHOSTCWT_STAGE_FLOATS", "4099")
+        option("stage_floats", 4099)
         np.testing.assert_array_equal(p.execute(x), ref)
         np.testing.assert_array_equal(p.execute(x, wide=True), ref64)
         np.testing.assert_array_equal(p.execute_block(x, 1234, 20000, wide=True), ref64[:, :, 1234:21234])
-        monkeypatch.delenv("GHOSTCWT_STAGE_FLOATS")
+        option("stage_floats", None)
     cwt = _cwt(x[0], fs, freq_limits=[10, 100], voices_per_octave=4)
     a = cwt.amplitude.copy()
-    monkeypatch.setenv("GHOSTCWT_STAGE_FLOATS", "1000")
+    option("stage_floats", 1000)
     cwt2 = _cwt(x[0], fs, freq_limits=[10, 100], voices_per_octave=4)
     assert cwt2.amplitude.dtype == np.float64
     np.testing.assert_array_equal(cwt2.amplitude, a)
@@ -725,10 +725,10 @@ def test_nelpy_round_trip_end_to_end(monkeypatch):
         output_numpy_or_asa(np.zeros(3), spectrogram, output_type="asa")
 
 
-def test_synthesis_kernels_agree(monkeypatch):
+def test_synthesis_kernels_agree(option):
     """The three ways a level can be synthesised -- the interpolating kernel (k_synthi: amplitude
-    and power at R >= 16), k_synth7 (GHOSTCWT_INTERP=0 sends every level there) and the 16-column
-    fallback (GHOSTCWT_SYNTH16=1) -- give the same rows, both epochs of a recording whose gap and
+    and power at R >= 16), k_synth7 (option interp = 0 sends every level there) and the 16-column
+    fallback (option synth16 = 1) -- give the same rows, both epochs of a recording whose gap and
     ends fall on no multiple of 4 samples (the interpolating kernel stores 16 bytes at a time and
     switches to single samples where a window edge runs through them).  In the measure build
     (GHOSTCWT_LIB=libghostcwt_measure.so) k_synth8 is compared as well."""
@@ -739,30 +739,28 @@ def test_synthesis_kernels_agree(monkeypatch):
     f = np.geomspace(180.0, 3.0, 37)
     eb = [[0, 15001], [15006, 40001]]
     for output in ("amplitude", "power"):
-        for var in ("GHOSTCWT_INTERP", "GHOSTCWT_SYNTH16", "GHOSTCWT_SYNTH_KERNEL", "GHOSTCWT_SYNTH_COLS"):
-            monkeypatch.delenv(var, raising=False)
         p, prod = _plan(x, fs, f, output=output, epoch_bounds=eb)
         assert p.info["n_interp"] > 0 and any(d is not None for d in p.debug_interp()["levels"])
         scale = np.abs(prod).max(axis=-1, keepdims=True)
-        monkeypatch.setenv("GHOSTCWT_INTERP", "0")
+        option("interp", 0)
         p7, ref7 = _plan(x, fs, f, output=output, epoch_bounds=eb)
         assert p7.info["n_interp"] == 0
         assert (np.abs(prod - ref7) / scale).max() < 2e-6, output
-        monkeypatch.setenv("GHOSTCWT_SYNTH16", "1")
+        option("synth16", 1)
         _, ref16 = _plan(x, fs, f, output=output, epoch_bounds=eb)
         assert (np.abs(prod - ref16) / scale).max() < 2e-6, output
-        monkeypatch.delenv("GHOSTCWT_SYNTH16")
+        option("synth16", None)
         if lib.gcwt_debug_measure_build():
-            for cols in ("32", "16"):
-                monkeypatch.setenv("GHOSTCWT_SYNTH_KERNEL", "8")
-                monkeypatch.setenv("GHOSTCWT_SYNTH_COLS", cols)
+            for cols in (32, 16):
+                option("synth_kernel", 8)
+                option("synth_cols", cols)
                 _, got = _plan(x, fs, f, output=output, epoch_bounds=eb)
                 assert (np.abs(got - ref7) / scale).max() < 2e-6, (output, cols)
-            monkeypatch.delenv("GHOSTCWT_SYNTH_KERNEL")
-            monkeypatch.delenv("GHOSTCWT_SYNTH_COLS")
+            option("synth_kernel", None)
+            option("synth_cols", None)
         # zeros outside the epochs survive (transforms.py:185)
         assert not prod[:, :, 15001:15006].any()
-    monkeypatch.delenv("GHOSTCWT_INTERP")
+    option("interp", None)
     # complex coefficients are never interpolated (the demodulation would have to be undone)
     pc, _ = _plan(x, fs, f, output="complex", epoch_bounds=eb)
     assert pc.info["n_interp"] == 0
@@ -848,11 +846,13 @@ def test_config5_at_the_shape_the_bench_runs():
     xb.free()
 
 
-def test_first_pass_windows_beside_strong_tones(monkeypatch):
+def test_first_pass_windows_beside_strong_tones(option):
     """The synthesis skips, per scale, the first-pass inputs whose bins lie above the scale's
     band (gain below band_eps of the peak there: k_scale_windows).  A recording with tones 20 x
     the background just above the bands of three scales -- inside what is skipped -- must still
-    meet the gate, and must agree with the build that computes every input."""
+    meet the gate, and (measure build, which alone takes the accuracy-changing option prune_inputs)
+    must agree with the build that computes every input."""
+    from ghost_amd._lib import lib
     from ghost_amd.synthetic import lfp_channel
     fs, n = 1000.0, 60000
     f = np.geomspace(100.0, 5.0, 24)
@@ -867,9 +867,11 @@ def test_first_pass_windows_beside_strong_tones(monkeypatch):
     assert rel_err(c[0], ref).max() < TOL
     p, a = _plan(x, fs, f, output="amplitude")
     assert rel_err(a[0], np.abs(ref)).max() < TOL
-    monkeypatch.setenv("GHOSTCWT_PRUNE_INPUTS", "0")
+    if not lib.gcwt_debug_measure_build():
+        return
+    option("prune_inputs", 0)
     p, c_all = _plan(x, fs, f, output="complex")
-    monkeypatch.delenv("GHOSTCWT_PRUNE_INPUTS")
+    option("prune_inputs", None)
     assert rel_err(c_all[0], ref).max() < TOL
     diff = np.abs(c_all[0] - c[0]).max(axis=1) / np.abs(ref).max(axis=1)
     assert 0 < diff.max() < 2e-6, diff          # inputs are skipped, and what they carried is below the tolerance
@@ -982,15 +984,15 @@ def test_bench_runs_two_ranks_end_to_end(tmp_path):
     assert res.returncode != 0 and b"ranks never share a GPU" in res.stderr
 
 
-def test_split_levels_option(monkeypatch):
-    """GHOSTCWT_SPLIT_LEVELS=1 (two block grids per decimation, x_R shared; measured slower on
+def test_split_levels_option(option):
+    """Option split_levels = 1 (two block grids per decimation, x_R shared; measured slower on
     the headline workload, kept as an option) gives the same numbers to rounding."""
     from ghost_amd.synthetic import lfp
     fs = 1000.0
     x = lfp(2, 30000, fs)
     f = np.geomspace(190.0, 3.0, 41)
     p0, ref = _plan(x, fs, f, output="complex")
-    monkeypatch.setenv("GHOSTCWT_SPLIT_LEVELS", "1")
+    option("split_levels", 1)
     p1, got = _plan(x, fs, f, output="complex")
     assert p1.info["n_levels"] > p0.info["n_levels"]
     assert set(p1.scale_info()["halo"].tolist()) >= {16} and p1.scale_info()["halo"].max() > 16

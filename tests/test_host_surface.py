@@ -327,7 +327,7 @@ def test_interpolated_levels_model_matches_oracle(golden):
     assert (demod % 2 == 0).all() and (demod > 0).all() and (demod < 256).all()
     a = amplitude_interpolated(x, 1000.0, f, plan=plan)
     assert rel_err(a[:, g["cols"]], g["amplitude_cols"]).max() < 5e-7
-    # complex output is never interpolated; GHOSTCWT_INTERP=0 switches the design off (A/B runs)
+    # complex output is never interpolated; option interp = 0 switches the design off (A/B runs)
     assert CwtPlan(x.size, 1, 1000.0, f, output="complex").info["n_interp"] == 0
     g = golden("g5_two_epochs.npz")
     a = amplitude_interpolated(g["x"], float(g["fs"]), g["frequencies"][::4], g["epoch_bounds"])
@@ -489,7 +489,7 @@ def test_time_blocks_tile_the_epochs():
     assert p.scale_info()["decimation"].tolist() == [32, 2048, 16384]
 
 
-def test_segments_of_equal_fft_length_are_batched(monkeypatch):
+def test_segments_of_equal_fft_length_are_batched(option):
     """Many short epochs (or the time blocks of a long one) become extra 'channels' of one
     launch set, up to 16 at a time and within a workspace budget."""
     fs = 1000.0
@@ -506,7 +506,7 @@ def test_segments_of_equal_fft_length_are_batched(monkeypatch):
     # time blocks of one long epoch batch too, until the budget says stop
     p3 = CwtPlan(200000, 1, fs, [100.0, 40.0], max_fft_log2=13)
     assert p3.debug_batches()[0] == (0, 16) and len(p3.segments()) > 16
-    monkeypatch.setenv("GHOSTCWT_BATCH_BYTES", "1")
+    option("batch_bytes", 1)
     p4 = CwtPlan(200000, 1, fs, [100.0, 40.0], max_fft_log2=13)
     assert all(c == 1 for _, c in p4.debug_batches())
 
