@@ -258,6 +258,19 @@ def spot_check(obuf, base, fs, freqs, C, N, distinct, output="amplitude"):
     return bool(worst <= gate and same), worst
 
 
+def full_output_check(obuf, C, N, S, distinct, output="amplitude"):
+    """Every value of the device result, on the device (gcwt_debug_check_output): none may be Inf / NaN,
+    and every row of a channel c >= distinct must equal the same row of channel c % distinct bit for bit
+    (the bench tiles `distinct` recordings over its channels) -- all C x S rows, not a sample of them."""
+    import ctypes
+    from ghost_amd._lib import lib, check
+    w = 2 if output == "complex" else 1
+    bad, diff = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib.gcwt_debug_check_output(obuf.ptr, w * N, w * N, S, C, distinct, ctypes.byref(bad), ctypes.byref(diff)))
+    return {"rows": C * S, "values": C * S * N * w, "nonfinite": bad.value, "tiled_twin_mismatches": diff.value,
+            "ok": bad.value == 0 and diff.value == 0}
+
+
 # ----------------------------------------------------------------------------
 # one rank
 # ----------------------------------------------------------------------------
@@ -519,10 +532,11 @@ def run_rank(args):
                                                            group, segs)
         if not cfg5 and not args.no_check:
             ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=args.output)
-            line["checked"] = ok
+            full = full_output_check(obuf, C, N, S, distinct, output=args.output)
+            line["checked"] = bool(ok and full["ok"])
             line["check"] = {"rows": "channels {0,7,C-1} x scales {0,57%%,S-1} vs the oracle, "
                                      "tiled channels c / c+%d bit-equal" % distinct,
-                             "worst_rel_err": float("%.3g" % worst)}
+                             "worst_rel_err": float("%.3g" % worst), "full_output": full}
         if world == 1 and not cfg5 and args.output == "amplitude" and not args.no_other_modes:
             # Secondary measurement, after and outside the timed region: the same workload with the
             # complex coefficients stored (8 B per coefficient: SURVEY.md 8d's second target).
@@ -531,6 +545,20 @@ def run_rank(args):
             line["other_modes"] = {"complex": other_mode("complex", N, C, fs, freqs, S, xbuf, dev, lib, check,
                                                          steps=args.steps, warmup=args.warmup,
                                                          check_against=None if args.no_check else (base, distinct))}
+        if world == 1 and not cfg5 and not args.no_other_configs:
+            # BASELINE.json's configs 2 and 5, after and outside the timed region, so that the driver's run
+            # carries them too (round 3: builder-run only).  Everything of the headline is released first.
+            for b in (locals().get("obuf"), xbuf):
+                try:
+                    b.free()
+                except Exception:
+                    pass
+            try:
+                plan.close()
+            except Exception:
+                pass
+            line["other_configs"] = {"config2": config2_leg(fs, freqs, dev, lib, check, no_check=args.no_check),
+                                     "config5": config5_leg(args)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(fs, freqs)
         emit(line)
@@ -559,6 +587,94 @@ def check_config5(plan, xbuf, ring_buf, base, distinct, fs, freqs, N, S, group, 
         "rows": "time block %d of %d (samples %d..%d), channels {0, %d} x scales {0, %d, %d} vs the oracle"
                 % (i_mid, len(segs), a, b, group - 1, S // 2, S - 1),
         "worst_rel_err": float("%.3g" % worst)}
+
+
+def config2_leg(fs, freqs, dev, lib, check, no_check=False, steps=20, warmup=3):
+    """BASELINE.json config 2: 1 channel x 1e6 samples x 100 scales 200..2 Hz on one GPU.  (a) device-resident
+    execute, plan prebuilt (the metric's definition: SURVEY.md 8d); (b) the public call
+    ContinuousWaveletTransform.transform() end to end -- host array in, host result out over PCIe, the
+    reference's float64 result and dtype=float32 -- which is what a user of the reference's class sees."""
+    from ghost_amd.engine import CwtPlan, DeviceBuffer
+    from ghost_amd.synthetic import lfp_channel
+    from ghost_amd.wave import ContinuousWaveletTransform
+    N, S = 1000000, len(freqs)
+    x = lfp_channel(N, fs, channel=0, seed=4321)
+    plan = CwtPlan(N, 1, fs, freqs, output="amplitude", device=dev)
+    plan.upload()
+    plan.set_profiling(True)
+    xb, ob = DeviceBuffer(4 * N), DeviceBuffer(plan.info["out_bytes"])
+    xb.upload(x)
+    for _ in range(warmup):
+        plan.execute_device(xb, ob)
+    check(lib.gcwt_device_synchronize())
+    wall, dev_ms, synth = [], [], []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        plan.execute_device(xb, ob)
+        wall.append(time.perf_counter() - t0)
+        tm = plan.timings()
+        dev_ms.append(tm["total_ms"])
+        synth.append(tm["synth_ms"])
+    alg = N * (4 + 4 * S)
+    el, k = float(np.median(wall)), float(np.median(synth))
+    res = {"workload": "1 ch x %d samples @ 1 kHz x %d Morse scales 200..2 Hz, amplitude f32" % (N, S),
+           "device_resident": {"ms_per_step": round(el * 1e3, 4), "device_ms": round(float(np.median(dev_ms)), 4),
+                               "value": round(N / el / 1e6, 2), "unit": "Msamples/s", "steps": steps, "warmup": warmup,
+                               "statistic": "median"},
+           "roofline": {"bound": "hbm", "kernel": "synthesis (k_synthi + k_synth7)", "kernel_ms": round(k, 4),
+                        "algorithmic_bytes": alg, "achieved": round(alg / (k * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(alg / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "one channel is 404 MB of rows: a launch of ~0.3 ms that does not fill the chip for long"}}
+    if not no_check:
+        from oracle import ghost_oracle as orc
+        rows = [0, S // 2, S - 1]
+        ref = orc.cwt_amplitude(x.astype(np.float64), fs, freqs[rows])
+        worst = 0.0
+        for i, sc in enumerate(rows):
+            row = ob.download((N,), np.float32, offset_bytes=4 * sc * N)
+            worst = max(worst, float(np.abs(row - ref[i]).max() / ref[i].max()))
+        res["checked"], res["worst_rel_err"] = bool(worst <= 1e-5), float("%.3g" % worst)
+    xb.free(); ob.free(); plan.close()
+    api = {}
+    for name, kw in (("float64", {}), ("float32", {"dtype": np.float32})):
+        cwt = ContinuousWaveletTransform()
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            cwt.transform(x, fs=fs, freqs=freqs[::-1].copy(), **kw)
+            ts.append(time.perf_counter() - t0)
+        api[name] = {"ms_per_call": round(float(np.median(ts[1:])) * 1e3, 2), "first_call_ms": round(ts[0] * 1e3, 2),
+                     "value": round(N / float(np.median(ts[1:])) / 1e6, 2), "unit": "Msamples/s",
+                     "result_bytes": int(cwt.amplitude.nbytes)}
+        del cwt
+    res["transform_end_to_end"] = dict(api, note="host in, host out over PCIe, plan creation included: never the headline value")
+    return res
+
+
+def config5_leg(args):
+    """BASELINE.json config 5 per GPU (48 of its 384 channels), 3 timed steps and the config-5 check, as a
+    child process that runs after this one has released the device: its JSON line, trimmed."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "5", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-ceilings", "--sustain", "0"]
+    if args.no_check:
+        cmd.append("--no-check")
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            return {"error": "exit %d: %s" % (out.returncode, out.stderr[-300:])}
+        j = json.loads(lines[-1])
+    except Exception as e:                                  # the headline line must not depend on this leg
+        return {"error": repr(e)[:300]}
+    keep = {k: j.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "checked", "check",
+                                  "whole_job_frac_of_hbm_peak", "stages_ms")}
+    keep["workload"] = j["config"]["workload"]
+    keep["roofline"] = {k: j["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                          "kernel_ms", "launches_per_step", "algorithmic_bytes", "kernels")}
+    keep["wall_s"] = round(time.perf_counter() - t0, 1)
+    return keep
 
 
 def other_mode(output, N, C, fs, freqs, S, xbuf, dev, lib, check, steps=10, warmup=2, check_against=None):
@@ -593,7 +709,8 @@ def other_mode(output, N, C, fs, freqs, S, xbuf, dev, lib, check, steps=10, warm
     if check_against is not None:
         base, distinct = check_against
         ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=output)
-        res["checked"], res["worst_rel_err"] = ok, float("%.3g" % worst)
+        full = full_output_check(obuf, C, N, S, distinct, output=output)
+        res["checked"], res["worst_rel_err"], res["full_output"] = bool(ok and full["ok"]), float("%.3g" % worst), full
     obuf.free()
     plan.close()
     return res
@@ -616,6 +733,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config-2 and config-5 legs after the timed steps")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the complex-output measurement after the timed steps")
     ap.add_argument("--dry-run", default="", metavar="DIR",
                     help="launcher rehearsal: every rank writes DIR/rank<r>.json and exits (no GPU)")

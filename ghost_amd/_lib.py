@@ -110,6 +110,7 @@ def _load():
         "gcwt_debug_scale_demod": (C.c_int, [vp, i32p]),
         "gcwt_debug_scale_theta_neg": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "gcwt_debug_clock": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "gcwt_debug_check_output": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, i64p, i64p]),
         "gcwt_debug_bandwidth": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_double)]),
         "gcwt_debug_fetch": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int64]),
     }

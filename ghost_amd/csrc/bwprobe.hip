@@ -41,9 +41,59 @@ __global__ void bw_fill_rows(float* p, size_t row_len, int rows, float v) {
   }
 }
 
+// Whole-result properties (bench.py, after the timed steps): values that are not finite, and values of
+// channel c >= distinct that differ in any bit from the same row of channel c % distinct (the bench tiles
+// `distinct` recordings over its channels: equal inputs must give equal rows whatever workgroup made them).
+// grid (chunks, rows), rows = n_channels * rows_per_channel
+__global__ void __launch_bounds__(256) k_check_rows(const uint32_t* __restrict__ out, int64_t pitch, int64_t n_valid,
+                                                    int rows_per_channel, int distinct,
+                                                    unsigned long long* __restrict__ counts) {
+  const int64_t row = blockIdx.y;
+  const int c = (int)(row / rows_per_channel), s = (int)(row - (int64_t)c * rows_per_channel);
+  const uint32_t* p = out + row * pitch;
+  const uint32_t* twin = c >= distinct ? out + ((int64_t)(c % distinct) * rows_per_channel + s) * pitch : nullptr;
+  unsigned bad = 0, diff = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_valid; i += (int64_t)gridDim.x * 256) {
+    const uint32_t v = p[i];
+    bad += (v & 0x7f800000u) == 0x7f800000u;          // Inf or NaN
+    if (twin) diff += v != twin[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) { bad += __shfl_down(bad, off, 64); diff += __shfl_down(diff, off, 64); }
+  if ((threadIdx.x & 63) == 0) {
+    if (bad) atomicAdd(&counts[0], (unsigned long long)bad);
+    if (diff) atomicAdd(&counts[1], (unsigned long long)diff);
+  }
+}
+
 }  // namespace
 
 int gcwt_internal_set_error(int code, const char* msg);
+
+extern "C" int gcwt_debug_check_output(const void* out_device, int64_t row_pitch_floats, int64_t n_valid_floats,
+                                       int32_t rows_per_channel, int32_t n_channels, int32_t distinct,
+                                       int64_t* n_nonfinite, int64_t* n_mismatched) {
+  if (!out_device || !n_nonfinite || !n_mismatched || row_pitch_floats < n_valid_floats || n_valid_floats <= 0 ||
+      rows_per_channel <= 0 || n_channels <= 0 || distinct <= 0 ||
+      (int64_t)rows_per_channel * n_channels > 65535)
+    return gcwt_internal_set_error(GCWT_ERR_INVALID, "gcwt_debug_check_output: bad argument");
+  unsigned long long* d = nullptr;
+  hipError_t err = hipMalloc((void**)&d, 16);
+  if (err == hipSuccess) err = hipMemset(d, 0, 16);
+  unsigned long long h[2] = {0, 0};
+  if (err == hipSuccess) {
+    const unsigned chunks = (unsigned)std::min<int64_t>(64, (n_valid_floats + 4095) / 4096);
+    const int64_t rows = (int64_t)rows_per_channel * n_channels;     // grid.y: at most 65535 rows per call
+    hipLaunchKernelGGL(k_check_rows, dim3(chunks, (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, 0,
+                       (const uint32_t*)out_device, row_pitch_floats, n_valid_floats, rows_per_channel, distinct, d);
+    err = hipGetLastError();
+    if (err == hipSuccess) err = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d);
+  if (err != hipSuccess) return gcwt_internal_set_error(GCWT_ERR_HIP, hipGetErrorString(err));
+  *n_nonfinite = (int64_t)h[0];
+  *n_mismatched = (int64_t)h[1];
+  return GCWT_OK;
+}
 
 extern "C" int gcwt_debug_bandwidth(int pattern, size_t bytes, double* gb_per_s) {
   if (!gb_per_s || bytes < ((size_t)64 << 20) || pattern < 0 || pattern > 2)

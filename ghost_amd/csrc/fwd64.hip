@@ -79,10 +79,10 @@ __device__ __forceinline__ void d_dft_small(cd v[Q]) {
   else if (Q == 16) d_dft16(v);
 }
 
-// exchange planes of the FFT256: 17 doubles per row of 16, columns 290 doubles apart (lanes run
-// over the columns: 2 (290 s + 17 t) words keeps a half-wave on different banks)
+// exchange planes of the FFT256: 17 doubles per row of 16, columns 273 doubles apart (lanes run
+// over the columns)
 constexpr int kDPitch = 17;
-constexpr int kDCol = 290;
+constexpr int kDCol = 273;   // = 1 (mod 16): the 16 lanes of a 64-bit LDS access (one t, columns s) fall on 16 different bank pairs
 constexpr size_t kDPlaneBytes = (size_t)16 * kDCol * sizeof(double);      // one plane of 16 columns
 constexpr size_t kFwd64Lds = 2 * kDPlaneBytes + 256 * sizeof(cd);         // planes + twiddle table
 
@@ -118,6 +118,9 @@ __device__ __forceinline__ void d_fill_twl(cd* twl, const cd* __restrict__ tw_hi
 // Rows 0 .. 128 are written; with rows_out = 256 the mirrored rows too (plans with full-band
 // scales read the whole spectrum).  grid (ld / 32, slots), dynamic LDS kFwd64Lds
 // ---------------------------------------------------------------------------
+constexpr int kColsTiles = 4;     // column tiles (32 real columns each) a workgroup walks: the next tile's samples
+                                  // are in flight while this one is transformed (2 workgroups = 8 waves per CU are
+                                  // all the LDS allows: without the prefetch the waves wait 71 % of their cycles)
 __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __restrict__ in, cd* __restrict__ out,
                                                              int ld, int64_t in_cstride, int64_t out_cstride,
                                                              int lg_p, const cd* __restrict__ tw_hi,
@@ -129,44 +132,60 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
   double* const ex_im = ex_re + 16 * kDCol;
   cd* const tile = reinterpret_cast<cd*>(smem);                          // aliases the planes
   cd* const twl = reinterpret_cast<cd*>(smem + 2 * kDPlaneBytes);
-  const int c = blockIdx.y, col0 = blockIdx.x * 32, tid = threadIdx.x;   // c: workspace slot
+  const int c = blockIdx.y, tid = threadIdx.x;                           // c: workspace slot
   const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
-  const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+  // (segment-local sample indices are below P <= 2^24: 32-bit arithmetic, a third of the kernel's instructions
+  // were 64-bit clamps and compares)
+  const int n_valid = (int)segs.n_valid[g], n_lead = (int)segs.n_lead[g];
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
   const double mean = sums[ch] * inv_n;      // transforms.py:142-143: float64 copy minus the global mean
   const int s = tid & 15, t = tid >> 4;
   d_fill_twl(twl, tw_hi, tid);
-  cd v[16];
-  const int64_t top = n_valid > 0 ? n_valid - 1 : 0;
+  const int top = n_valid > 0 ? n_valid - 1 : 0;
+  const int tile0 = blockIdx.x * kColsTiles, n_tiles = min(kColsTiles, ld / 32 - tile0);
+  float ra[16], rb[16];
+  auto fetch = [&](int col0) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int64_t n = (int64_t)(t + 16 * j) * ld + col0 + 2 * s;
-    const int64_t na = min(max(n, n_lead), top), nb = min(max(n + 1, n_lead), top);
-    const float a = x[na], b = x[nb];               // clamped: no branch around the loads
-    v[j] = make_double2(n >= n_lead && n < n_valid ? (double)a - mean : 0.0,
-                        n + 1 >= n_lead && n + 1 < n_valid ? (double)b - mean : 0.0);
-  }
+    for (int j = 0; j < 16; ++j) {
+      const int n = (t + 16 * j) * ld + col0 + 2 * s;
+      ra[j] = x[min(max(n, n_lead), top)];           // clamped: no branch around the loads
+      rb[j] = x[min(max(n + 1, n_lead), top)];
+    }
+  };
+  fetch(tile0 * 32);
   __syncthreads();                                   // the twiddle table
-  d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
-  __syncthreads();                                   // the tile aliases the planes
+  for (int it = 0; it < n_tiles; ++it) {
+    const int col0 = (tile0 + it) * 32;
+    cd v[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) tile[(t + 16 * j) * 17 + s] = v[j];
-  __syncthreads();
-  // split and twiddle: thread = one real column, rows k = k0 + 8 i
-  const int cr = tid & 31, k0 = tid >> 5, m = cr >> 1;
-  const bool odd = cr & 1;
-  const int64_t col = col0 + cr;
-  cd w = d_phase(tw_hi, tw_lo, col * k0, lg_p);
-  const cd st = d_phase(tw_hi, tw_lo, col * 8, lg_p);
-  cd* o = out + (int64_t)c * out_cstride + col;
-  for (int k = k0; k <= 128; k += 8) {
-    const cd zk = tile[k * 17 + m], zm = tile[((256 - k) & 255) * 17 + m];
-    const cd val = odd ? make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x))
-                       : make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-    o[(int64_t)k * ld] = dmul(val, w);
-    if (rows_out > 129 && k > 0 && k < 128)          // Y0[256 - k] = conj(Y0[k]) for a real column
-      o[(int64_t)(256 - k) * ld] = dmul(dconj(val), d_phase(tw_hi, tw_lo, col * (256 - k), lg_p));
-    w = dmul(w, st);
+    for (int j = 0; j < 16; ++j) {
+      const int n = (t + 16 * j) * ld + col0 + 2 * s;
+      v[j] = make_double2(n >= n_lead && n < n_valid ? (double)ra[j] - mean : 0.0,
+                          n + 1 >= n_lead && n + 1 < n_valid ? (double)rb[j] - mean : 0.0);
+    }
+    if (it + 1 < n_tiles) fetch(col0 + 32);          // in flight during this tile's transform
+    d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
+    __syncthreads();                                 // the tile aliases the planes
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[(t + 16 * j) * 17 + s] = v[j];
+    __syncthreads();
+    // split and twiddle: thread = one real column, rows k = k0 + 8 i
+    const int cr = tid & 31, k0 = tid >> 5, m = cr >> 1;
+    const bool odd = cr & 1;
+    const int64_t col = col0 + cr;
+    cd w = d_phase(tw_hi, tw_lo, col * k0, lg_p);
+    const cd st = d_phase(tw_hi, tw_lo, col * 8, lg_p);
+    cd* o = out + (int64_t)c * out_cstride + col;
+    for (int k = k0; k <= 128; k += 8) {
+      const cd zk = tile[k * 17 + m], zm = tile[((256 - k) & 255) * 17 + m];
+      const cd val = odd ? make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x))
+                         : make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+      o[(int64_t)k * ld] = dmul(val, w);
+      if (rows_out > 129 && k > 0 && k < 128)          // Y0[256 - k] = conj(Y0[k]) for a real column
+        o[(int64_t)(256 - k) * ld] = dmul(dconj(val), d_phase(tw_hi, tw_lo, col * (256 - k), lg_p));
+      w = dmul(w, st);
+    }
+    __syncthreads();                                 // the tile is read before the next exchange overwrites it
   }
 }
 
@@ -193,16 +212,16 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
   const int s = tid & 15, t = tid >> 4;
   d_fill_twl(twl, tw_hi, tid);
   const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
-  const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+  const int n_valid = (int)segs.n_valid[g], n_lead = (int)segs.n_lead[g];      // below P <= 2^24
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
   const double mean = sums[ch] * inv_n;
-  const int64_t top = n_valid > 0 ? n_valid - 1 : 0;
+  const int top = n_valid > 0 ? n_valid - 1 : 0;
   cd v[16], u[np > 1 ? 16 : 1];
 #pragma unroll
   for (int p = 0; p < np; ++p) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int64_t na = (int64_t)(q * (t + 16 * j) + 2 * p) * ld + col0 + s, nb = na + ld;
+      const int na = (q * (t + 16 * j) + 2 * p) * ld + col0 + s, nb = na + ld;
       const float xa = x[min(max(na, n_lead), top)], xb = x[min(max(nb, n_lead), top)];   // clamped
       v[j] = make_double2(na >= n_lead && na < n_valid ? (double)xa - mean : 0.0,
                           nb >= n_lead && nb < n_valid ? (double)xb - mean : 0.0);
@@ -386,7 +405,7 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
   hipError_t e;
   if (p1 == 256) {
     if ((e = allow_lds(k_fwd64_cols256_real2, kFwd64Lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_fwd64_cols256_real2, dim3(ld / 32, slots), dim3(256), kFwd64Lds, st, in, y, ld,
+    hipLaunchKernelGGL(k_fwd64_cols256_real2, dim3((ld / 32 + kColsTiles - 1) / kColsTiles, slots), dim3(256), kFwd64Lds, st, in, y, ld,
                        in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out);
   } else if (p1 == 512) {
     if ((e = allow_lds(k_fwd64_colsq_real2<1>, kFwd64Lds)) != hipSuccess) return e;

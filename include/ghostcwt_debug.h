@@ -76,6 +76,14 @@ int gcwt_debug_clock(gcwt_plan* plan, double* ghz, double* workgroup_seconds);
 enum { GCWT_BW_FILL = 0, GCWT_BW_COPY = 1, GCWT_BW_SYNTH_STORES = 2 };
 int gcwt_debug_bandwidth(int pattern, size_t bytes, double* gb_per_s);
 
+/* Whole-result properties of a device-resident result of rows_per_channel x n_channels rows (at most 65535) of
+ * n_valid_floats floats, row_pitch_floats apart: how many values are Inf / NaN, and how many values of a
+ * channel c >= distinct differ in any bit from the same row of channel c % distinct (a caller that tiled
+ * `distinct` recordings over its channels expects 0: bench.py). */
+int gcwt_debug_check_output(const void* out_device, int64_t row_pitch_floats, int64_t n_valid_floats,
+                            int32_t rows_per_channel, int32_t n_channels, int32_t distinct,
+                            int64_t* n_nonfinite, int64_t* n_mismatched);
+
 #ifdef __cplusplus
 }
 #endif

@@ -739,6 +739,8 @@ def test_synthesis_kernels_agree(option):
     f = np.geomspace(180.0, 3.0, 37)
     eb = [[0, 15001], [15006, 40001]]
     for output in ("amplitude", "power"):
+        for name in ("interp", "synth16", "synth_cols"):
+            option(name, None)
         p, prod = _plan(x, fs, f, output=output, epoch_bounds=eb)
         assert p.info["n_interp"] > 0 and any(d is not None for d in p.debug_interp()["levels"])
         scale = np.abs(prod).max(axis=-1, keepdims=True)
