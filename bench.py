@@ -321,9 +321,15 @@ def run_rank(args):
         group = min(C, args.group or 24)
         while C % group:                             # the largest divisor of C within the request
             group -= 1
-    total_channels = C * world                       # weak scaling: fixed channels per GPU
-    c0, c1 = shard_channels(total_channels, rank, world)
-    assert c1 - c0 == C
+    time_shard = args.shard == "time"
+    if time_shard and not cfg5:
+        raise SystemExit("--shard time is config 5's split (few channels, long recording): add --config 5")
+    if time_shard:
+        total_channels = C                           # strong scaling: every rank holds all C channels and takes
+    else:                                            # its share of the recording's time blocks
+        total_channels = C * world                   # weak scaling: fixed channels per GPU
+        c0, c1 = shard_channels(total_channels, rank, world)
+        assert c1 - c0 == C
 
     comm = Comm(rank, world, device=dev)
     t_plan = time.perf_counter()
@@ -338,7 +344,10 @@ def run_rank(args):
     # what this box's HBM delivers (measured once, before anything is timed)
     ceilings = {}
     if rank == 0 and not args.no_ceilings:
-        for key, pat in (("peak_measured_copy", 1), ("peak_measured_fill", 0), ("store_pattern_ceiling", 2)):
+        # store_pattern_ceiling: k_synthi's own pattern (1 KB runs per wave, 53 KB visits; round 4) -- the kernel that
+        # writes 63 of the 100 scales; store_pattern_ceiling_synth7: k_synth7's 128-byte runs (rounds 1-3's probe)
+        for key, pat in (("peak_measured_copy", 1), ("peak_measured_fill", 0), ("store_pattern_ceiling", 3),
+                         ("store_pattern_ceiling_synth7", 2)):
             g = ctypes.c_double(0)
             check(lib.gcwt_debug_bandwidth(pat, 12 << 30 if pat == 1 else 48 << 30, ctypes.byref(g)))
             ceilings[key] = round(g.value, 1)
@@ -346,12 +355,21 @@ def run_rank(args):
 
     # synthetic LFP: 8 distinct generated channels per rank, tiled over the block
     distinct = min(C, 8 if not cfg5 else 2)
-    base = lfp(distinct, N, fs, seed=1234 + 1000 * rank)
+    base = lfp(distinct, N, fs, seed=1234 + (0 if time_shard else 1000 * rank))   # (time shards: one recording)
     xbuf = DeviceBuffer(4 * C * N)
     for c in range(C):
         xbuf.upload(base[c % distinct], offset_bytes=4 * c * N)
     b_out = 8 if args.output == "complex" else 4
     segs = plan.segments()
+    if time_shard:
+        # BASELINE.json north_star: "independent channels/epochs shard embarrassingly" -- for few channels the
+        # independent units are the time blocks (each carries its own halo: no exchange)
+        from ghost_amd.dist import shard_time_blocks
+        lo, hi = shard_time_blocks(segs, rank, world)
+        all_segs = segs
+        segs = [sg for sg in segs if lo <= sg[0] < hi]
+        if not segs:
+            raise SystemExit("rank %d of %d has no time block: %d blocks in the recording" % (rank, world, len(all_segs)))
     if cfg5:
         core = max(b - a for a, b, _ in segs)
         ring = [DeviceBuffer(b_out * group * S * core) for _ in range(2)]
@@ -420,12 +438,14 @@ def run_rank(args):
     numas = comm.allgather(-1 if numa is None else numa)
 
     if rank == 0:
-        units = world * C * N * args.steps
+        units = (1 if time_shard else world) * C * N * args.steps
         value = units / elapsed / 1e6
         launches = max(1, stats["synth_launches"])
         k_ms = stats["synth_ms"] / launches
         ki_ms = stats.get("interp_ms", 0.0) / launches
         alg_step = C * N * (4 + S * b_out)           # per channel-sample 4 + S*b_out
+        if time_shard:                               # this rank's share of the recording
+            alg_step = C * sum(b - a for a, b, _ in segs) * (4 + S * b_out)
         alg_launch = alg_step * args.steps / launches
         achieved = alg_launch / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
@@ -446,11 +466,13 @@ def run_rank(args):
             "metric": "Msamples/s CWT (128ch x 1e6 samp x 100 scales); % HBM roofline; 1/2/4/8 GPU",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if time_shard else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic %g kHz LFP (pink noise + 8 Hz rhythm + 40 Hz bursts), "
                     "%d generated channels tiled over each GPU's block" % (fs / 1e3, distinct),
             "config": {"workload": workload, "channels_total": total_channels,
-                       "parallelism": "channel-sharded x%d" % world,
+                       "parallelism": ("time-block-sharded x%d (every rank: all %d channels, %d of the recording's "
+                                       "%d time blocks)" % (world, C, len(segs), len(all_segs))) if time_shard
+                                      else "channel-sharded x%d" % world,
                        "bank": bank_via, "comm": comm.backend, "device": device_name(dev),
                        "plan_create_ms": round(plan_ms, 2),
                        "scales": {"spectral": info["n_spectral"], "direct": info["n_direct"],
@@ -726,6 +748,9 @@ def main():
     ap.add_argument("--samples", type=int, default=0)
     ap.add_argument("--scales", type=int, default=0)
     ap.add_argument("--output", default="amplitude", choices=["amplitude", "power", "complex"])
+    ap.add_argument("--shard", default="channels", choices=["channels", "time"],
+                    help="how N > 1 ranks split the job: contiguous channel blocks (weak scaling, the default) or, "
+                         "with --config 5, the time blocks of one recording that every rank holds whole (strong scaling)")
     ap.add_argument("--group", type=int, default=0, help="config 5: channels per plan execution (default 24)")
     ap.add_argument("--max-fft-log2", type=int, default=0, help="longest FFT of the plan (time-block size), 0 = library default")
     ap.add_argument("--sustain", type=float, default=2.0,

@@ -41,6 +41,28 @@ __global__ void bw_fill_rows(float* p, size_t row_len, int rows, float v) {
   }
 }
 
+// k_synthi's store pattern (profiles/r04_store_study.md, tools/store_geom.hip): 256-thread workgroups, three per CU
+// (42 KB of LDS each), a workgroup owns `visit` samples of a channel's rows and walks the level's 15 rows four at a
+// time; inside a (row, range) visit its four waves write 1 KB runs round-robin with 16-byte nt stores.  Items fastest
+// over the grid, as the kernel launches at 128 channels.  grid (ceil(n / visit), channels)
+__global__ void __launch_bounds__(256, 3) bw_fill_synthi(float* __restrict__ out, int64_t pitch, int n_samples, int visit,
+                                                         int n_rows, int rows_total) {
+  extern __shared__ char lds_[];
+  (void)lds_;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t col0 = (int64_t)blockIdx.x * visit;
+  const int len = min(visit, n_samples - (int)col0);
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 val = {1.f, 2.f, 3.f, 4.f};
+  for (int row = 0; row < n_rows; ++row) {
+    float* dst = out + ((int64_t)blockIdx.y * rows_total + row) * pitch + col0;
+    for (int wt = wave; wt * 256 < len; wt += 4) {
+      const int smp = wt * 256 + 4 * lane;
+      if (smp + 4 <= len) __builtin_nontemporal_store(val, reinterpret_cast<v4*>(dst + smp));
+    }
+  }
+}
+
 // Whole-result properties (bench.py, after the timed steps): values that are not finite, and values of
 // channel c >= distinct that differ in any bit from the same row of channel c % distinct (the bench tiles
 // `distinct` recordings over its channels: equal inputs must give equal rows whatever workgroup made them).
@@ -96,7 +118,7 @@ extern "C" int gcwt_debug_check_output(const void* out_device, int64_t row_pitch
 }
 
 extern "C" int gcwt_debug_bandwidth(int pattern, size_t bytes, double* gb_per_s) {
-  if (!gb_per_s || bytes < ((size_t)64 << 20) || pattern < 0 || pattern > 2)
+  if (!gb_per_s || bytes < ((size_t)64 << 20) || pattern < 0 || pattern > 3)
     return gcwt_internal_set_error(GCWT_ERR_INVALID, "gcwt_debug_bandwidth: bad argument");
   float *a = nullptr, *b = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -108,7 +130,9 @@ extern "C" int gcwt_debug_bandwidth(int pattern, size_t bytes, double* gb_per_s)
   // flight) and of three timed passes each; the first pass of all touches the pages
   double best_ms = 1e30, moved = 0.0;
   const unsigned grids[4] = {2048, 4096, 8192, 16384};
-  for (int gi = 0; gi < (pattern == GCWT_BW_SYNTH_STORES ? 1 : 4) && err == hipSuccess; ++gi) {
+  if (err == hipSuccess && pattern == GCWT_BW_SYNTHI_STORES)
+    err = hipFuncSetAttribute((const void*)bw_fill_synthi, hipFuncAttributeMaxDynamicSharedMemorySize, 42 * 1024);
+  for (int gi = 0; gi < (pattern >= GCWT_BW_SYNTH_STORES ? 1 : 4) && err == hipSuccess; ++gi) {
     for (int it = 0; it < (gi == 0 ? 4 : 3) && err == hipSuccess; ++it) {
       (void)hipEventRecord(e0, 0);
       if (pattern == GCWT_BW_FILL) {
@@ -117,6 +141,14 @@ extern "C" int gcwt_debug_bandwidth(int pattern, size_t bytes, double* gb_per_s)
       } else if (pattern == GCWT_BW_COPY) {
         hipLaunchKernelGGL(bw_copy128, dim3(grids[gi]), dim3(256), 0, 0, (const float4*)a, (float4*)b, bytes / 16);
         moved = 2.0 * (double)bytes;
+      } else if (pattern == GCWT_BW_SYNTHI_STORES) {
+        // the R = 32 level of the headline: 15 rows of a channel's 100, 53 KB visits (two blocks of 212 x 32 samples)
+        const int64_t pitch = 1000032;
+        const int n = 1000000, visit = 13568, n_rows = 15, rows_total = 100;
+        const int n_ch = (int)std::min<size_t>(128, bytes / ((size_t)rows_total * pitch * 4));
+        hipLaunchKernelGGL(bw_fill_synthi, dim3((n + visit - 1) / visit, n_ch), dim3(256), 42 * 1024, 0, a, pitch, n, visit,
+                           n_rows, rows_total);
+        moved = (double)n_ch * n_rows * n * 4.0;
       } else {
         const size_t row_len = 1000000 / 32 * 32 + 32;
         const int rows = 100;

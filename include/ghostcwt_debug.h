@@ -73,7 +73,9 @@ int gcwt_debug_clock(gcwt_plan* plan, double* ghz, double* workgroup_seconds);
 /* Measurement only: GB/s this device reaches on `bytes` (>= 64 MiB) of HBM with a plain
  * 16-byte fill, a 16-byte copy (read + write counted), or the store pattern of the
  * synthesis kernel (128-byte runs into 100 rows a megasample apart).  Best of three. */
-enum { GCWT_BW_FILL = 0, GCWT_BW_COPY = 1, GCWT_BW_SYNTH_STORES = 2 };
+enum { GCWT_BW_FILL = 0, GCWT_BW_COPY = 1, GCWT_BW_SYNTH_STORES = 2,
+       GCWT_BW_SYNTHI_STORES = 3 /* k_synthi's: 1 KB runs per wave, 53 KB visits, four rows per pass, three
+                                    256-thread workgroups per CU (profiles/r04_store_study.md) */ };
 int gcwt_debug_bandwidth(int pattern, size_t bytes, double* gb_per_s);
 
 /* Whole-result properties of a device-resident result of rows_per_channel x n_channels rows (at most 65535) of

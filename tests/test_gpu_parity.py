@@ -986,6 +986,33 @@ def test_bench_runs_two_ranks_end_to_end(tmp_path):
     assert res.returncode != 0 and b"ranks never share a GPU" in res.stderr
 
 
+def test_bench_shards_time_blocks_over_two_ranks(tmp_path):
+    """`python bench.py --gpus 2 --config 5 --shard time`: few channels, one long recording -- every rank holds
+    all the channels and takes a contiguous run of the recording's time blocks (BASELINE.json north_star's split for
+    config 5; no exchange: each block carries its halo).  Two ranks on this box's one GPU (file control plane), rank
+    0 checks one of its blocks against the oracle; strong scaling is what the line says."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(GHOSTCWT_ALLOW_SHARED_GPU="1", GHOSTCWT_COMM="file", GHOSTCWT_RDZV_DIR=str(tmp_path))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "5", "--shard", "time",
+                          "--channels", "2", "--group", "2", "--samples", "6000000", "--max-fft-log2", "21",
+                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-ceilings", "--sustain", "0"],
+                         env=env, capture_output=True, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["checked"] is True, line
+    assert line["config"]["channels_total"] == 2 and "time-block-sharded x2" in line["config"]["parallelism"]
+    # the whole job is the recording once, whatever the number of ranks
+    assert line["value"] == pytest.approx(2 * 6000000 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+
+
 def test_split_levels_option(option):
     """Option split_levels = 1 (two block grids per decimation, x_R shared; measured slower on
     the headline workload, kept as an option) gives the same numbers to rounding."""

@@ -37,6 +37,27 @@ def test_fastconv_time_domain():
         fastconv_hip(x.reshape(2, -1), psi)
 
 
+def test_reference_operator_names_run_on_the_device():
+    """`from ghost.sigtools import fastconv_scipy, fastconv_fftw, ...` (the reference's own names,
+    tests/test_convolution.py:1-2 of the reference imports exactly these) through the alias package:
+    the reference's test shapes, every mode."""
+    from ghost.sigtools import (fastconv_scipy, fastconv_fftw, fastconv_freq_scipy, fastconv_freq_fftw,
+                                analytic_signal_fftw, chirpz_dft)
+    from scipy.signal import hilbert
+    rng = np.random.default_rng(4)
+    x, y = rng.random(10000), rng.random(1000)
+    Y = fft(y, n=4096)
+    for mode in ("full", "same", "valid"):
+        ref = convolve(x, y, mode=mode)
+        for fn in (fastconv_scipy, fastconv_fftw):
+            assert _close(fn(x, y, mode=mode, fft_length=4096), ref), (fn.__name__, mode)
+        for fn in (fastconv_freq_scipy, fastconv_freq_fftw):
+            assert _close(fn(x, Y, 1000, mode=mode), ref), (fn.__name__, mode)
+    assert _close(fastconv_fftw(x, y, n_threads=4), convolve(x, y, mode="same"))
+    assert _close(analytic_signal_fftw(x[:5000] - 0.5, n_threads=2), hilbert(x[:5000] - 0.5))
+    assert _close(chirpz_dft(x[:777]), fft(x[:777]))
+
+
 def test_fastconv_freq_domain():
     from ghost_amd.sigtools import fastconv_freq_hip
     rng = np.random.default_rng(2)

@@ -298,8 +298,19 @@ def test_reference_import_name_is_an_alias():
     import ghost
     assert ContinuousWaveletTransform is ghost_amd.wave.transforms.ContinuousWaveletTransform
     assert Morse is ghost_amd.wave.Morse and mu is ghost_amd.wave.morseutils
-    assert conv is ghost_amd.sigtools.convolution and standardize_asa is ghost_amd.formats.standardize_asa
+    assert standardize_asa is ghost_amd.formats.standardize_asa
     assert ghost.__version__ == ghost_amd.__version__
+    # the reference's operator names (ghost/sigtools/convolution.py:3-4, analytic.py:3, fourier.py:9) exist and
+    # are bound to the GPU operators, the GPU names stay importable beside them
+    from ghost.sigtools import (fastconv_scipy, fastconv_fftw, fastconv_freq_scipy, fastconv_freq_fftw,   # noqa: F401
+                                analytic_signal_fftw, chirpz_dft, fastconv_hip)
+    import inspect
+    assert conv.fastconv_hip is ghost_amd.sigtools.convolution.fastconv_hip is fastconv_hip
+    assert list(inspect.signature(fastconv_fftw).parameters) == ["signal", "kernel", "mode", "fft_length", "n_threads"]
+    assert list(inspect.signature(fastconv_freq_fftw).parameters) == ["signal_td", "kernel_fd", "kernel_len", "mode", "n_threads"]
+    assert list(inspect.signature(analytic_signal_fftw).parameters) == ["signal", "fft_length", "n_threads"]
+    with pytest.raises(ValueError):
+        fastconv_scipy(np.zeros((2, 8)), np.ones(3))        # "Signal must be 1D" before anything touches a device
 
 
 def test_interpolated_levels_model_matches_oracle(golden):
