@@ -18,7 +18,7 @@ OUT_AMPLITUDE, OUT_POWER, OUT_COMPLEX = 0, 1, 2
 X_ON_DEVICE, OUT_ON_DEVICE, REUSE_MEANS, OUT_F64 = 1, 2, 4, 8
 SCALE_SPECTRAL, SCALE_DIRECT, SCALE_FULLBAND = 0, 1, 2
 WAVELET_ENERGY = 0x100
-ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_COMM = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_COMM, ERR_COMM_INCOMPLETE = -1, -2, -3, -4, -5, -6, -7
 COMM_ID_BYTES = 128
 
 

@@ -73,6 +73,10 @@ struct EpochDev {
   int n_items_i = 0;
 };
 
+// full-band responses kept on the device across executes (one P-point row per (scale, FFT length)); counted in
+// gcwt_plan_info.workspace_bytes
+constexpr int64_t kFullbandCacheBytes = (int64_t)4 << 30;
+
 enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_FULLBAND, ST_INTERP, ST_COUNT };
 
 }  // namespace
@@ -208,7 +212,8 @@ int get_event(gcwt_plan* p, hipEvent_t* e) {
 // fallback.  GHOSTCWT_SYNTH16=1 sends everything to the fallback (A/B tests).
 enum LevelKernel { LK_SYNTH16 = 0, LK_SYNTH7 = 7, LK_INTERP = 9 };
 inline LevelKernel level_kernel(const gcwt_plan* p, const LevelPlan& lp) {
-  if (p->use_synth16) return LK_SYNTH16;
+  // (the 16-column kernel knows nothing of a band shift: shifted levels keep k_synth7 whatever the option says)
+  if (p->use_synth16 && lp.band_shift == 0) return LK_SYNTH16;
   if (lp.interp_q > 0) return LK_INTERP;
   // (a shifted band is built into k_synth7 and k_synthi only; k_synth7<WIDE> takes its long halos)
   return lp.fast || (lp.band_shift > 0 && lp.scales.size() <= 256) ? LK_SYNTH7 : LK_SYNTH16;
@@ -348,7 +353,26 @@ int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info) {
   for (const auto& l : hp.levels) r = std::max(r, l.decimation);
   info->max_decimation = r;
   info->fft_length = hp.max_p;
-  info->workspace_bytes = hp.workspace_bytes;
+  // the planner's figure (X, x_R, XB, Z, bank, tables) plus what this file allocates on top of it
+  {
+    const int64_t C = hp.prm.n_channels, slots = C * hp.max_batch;
+    int64_t extra = 0, xs = 0, y = 0;
+    for (const EpochPlan& ep : hp.epochs) {
+      for (size_t l = 0; l < hp.levels.size(); ++l)
+        if (hp.levels[l].band_shift > 0) xs = std::max<int64_t>(xs, ep.lv[l].m);
+      const int rows = ep.p1 >= 4 && hp.n_fullband == 0 ? ep.p1 / 2 + 1 : ep.p1;
+      y = std::max<int64_t>(y, (int64_t)rows * kRowLen);
+    }
+    extra += 8 * 3 * slots * xs;                                        // shifted-band slices, one per level stream
+    if (hp.high_precision && hp.n_direct < hp.prm.n_freqs) extra += 16 * (slots * y + 8192);   // float64 intermediate + twiddles
+    int64_t listed = 0;
+    for (const LevelPlan& lp : hp.levels) listed += (int64_t)lp.scales.size();
+    extra += 4 * (listed + 8) * 256 + 8 * 256 * (int64_t)hp.levels.size();   // gain rows in list order, half-sample twiddles
+    extra += 8 * (int64_t)channel_sum_doubles((size_t)C) + 4 * (int64_t)hp.interp_coef.size();
+    if (hp.n_fullband > 0)
+      extra += std::min<int64_t>(kFullbandCacheBytes, 8 * (int64_t)hp.n_fullband * hp.max_p * (int64_t)hp.epochs.size());
+    info->workspace_bytes = hp.workspace_bytes + extra;
+  }
   info->out_bytes = (int64_t)hp.out_elem_bytes * hp.prm.n_channels * hp.prm.n_freqs * hp.prm.n_samples;
   return GCWT_OK;
 }
@@ -964,18 +988,27 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         h = cached->second;
       } else {
         float2* dst = p->d_hfull;
+        float2* keep = nullptr;
         const int64_t bytes = (int64_t)sizeof(float2) * P;
-        if (p->hfull_cache_bytes + bytes <= ((int64_t)4 << 30)) {
-          float2* keep = nullptr;
-          if (hipMalloc((void**)&keep, (size_t)bytes) == hipSuccess) {
-            p->hfull_cache[{i, P1}] = keep;
-            p->hfull_cache_bytes += bytes;
-            dst = keep;
-          } else {
-            (void)hipGetLastError();           // no room: compute into the scratch row as before
-          }
+        if (p->hfull_cache_bytes + bytes <= kFullbandCacheBytes) {
+          if (hipMalloc((void**)&keep, (size_t)bytes) == hipSuccess) dst = keep;
+          else (void)hipGetLastError();        // no room: compute into the scratch row as before
         }
-        RUN(ST_FULLBAND, launch_fullband_filter(dst, p->d_bank_sc, i, p->d_amps, P1, st));
+        {   // the response enters the cache only once its launch has been accepted: a failed launch must not
+            // leave an unfilled buffer behind for later executes to reuse
+          SpanGuard sg_(p, ST_FULLBAND);
+          int rc_ = sg_.rc;
+          if (!rc_) {
+            he = launch_fullband_filter(dst, p->d_bank_sc, i, p->d_amps, P1, st);
+            if (he != hipSuccess) rc_ = hip_err(he, "launch_fullband_filter");
+          }
+          if (!rc_) rc_ = sg_.end();
+          if (rc_) { if (keep) (void)hipFree(keep); return rc_; }
+        }
+        if (keep) {
+          p->hfull_cache[{i, P1}] = keep;
+          p->hfull_cache_bytes += bytes;
+        }
         h = dst;
       }
       RUN(ST_FULLBAND, launch_fullband_mul(p->d_x, h, p->d_z, P, slots, st));

@@ -163,7 +163,7 @@ int gcwt_comm_allreduce_max(gcwt_comm* c, double* value) {
   if (rc != 0) return nccl_fail("ncclAllReduce", rc);
   if (hipMemcpyAsync(value, c->d_val, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize(c->stream) != hipSuccess)
-    return cerr_(GCWT_ERR_HIP, "all-reduce did not complete");
+    return cerr_(GCWT_ERR_COMM_INCOMPLETE, "all-reduce was enqueued and did not complete");
   return GCWT_OK;
 }
 
@@ -182,7 +182,8 @@ int gcwt_comm_broadcast_bank(gcwt_comm* c, gcwt_plan* plan, int root) {
   const ncclResult_t nr = rccl().Broadcast(bank, bank, bytes, kNcclUint8, root, c->comm, st);
   if (nr != 0) return nccl_fail("ncclBroadcast", nr);
   if ((rc = gcwt_internal_refresh_bank(plan))) return rc;   // signed gain table follows the bank
-  if (hipStreamSynchronize(st) != hipSuccess) return cerr_(GCWT_ERR_HIP, "broadcast did not complete");
+  if (hipStreamSynchronize(st) != hipSuccess)
+    return cerr_(GCWT_ERR_COMM_INCOMPLETE, "broadcast was enqueued and did not complete");
   return GCWT_OK;
 }
 

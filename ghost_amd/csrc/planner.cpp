@@ -232,7 +232,7 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
 // the interpolation adds: max over bins of |G_s[k]| / peak times the interpolator's error at that
 // bin's distance from the demodulation centre.  A level whose bound exceeds interp_tol stays on
 // the FFT-per-sample kernels.
-static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
+static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp) {
   constexpr int T = kInterpTaps;
   const int B = hp->block, R = lp->decimation;
   lp->interp_q = 0;
@@ -253,6 +253,7 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
                                                            // probes below would take seconds
   // gains on the level's grid, band edges and demodulation bins
   std::vector<std::vector<double>> gains(lp->scales.size(), std::vector<double>((size_t)B));
+  std::vector<std::vector<double>> gains_all(lp->scales.size(), std::vector<double>((size_t)B));   // for the bound: every bin
   std::vector<double> genv((size_t)2 * B, 0.0);            // envelope against the distance d from the centre: index d + B
   for (size_t n = 0; n < lp->scales.size(); ++n) {
     ScalePlan& sp = hp->scales[lp->scales[n]];
@@ -265,14 +266,16 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
     const double lo_k = ((double)sp.bin_lo - 6.0) / bin_per_k + lp->band_shift;
     const double hi_k = ((double)(sp.bin_lo + sp.n_bins) + 6.0) / bin_per_k + lp->band_shift;
     for (int k = 0; k < B; ++k) {
-      g[(size_t)k] = ((double)k < lo_k || (double)k > hi_k) ? 0.0
-                     : std::fabs(exact_gain(hp->amps.data() + sp.amp_offset, sp.bin_lo, sp.n_bins, sp.length,
-                                            k - lp->band_shift, (int64_t)B * R));
+      const double ge = std::fabs(exact_gain(hp->amps.data() + sp.amp_offset, sp.bin_lo, sp.n_bins, sp.length,
+                                             k - lp->band_shift, (int64_t)B * R));
+      gains_all[n][(size_t)k] = ge;
+      g[(size_t)k] = ((double)k < lo_k || (double)k > hi_k) ? 0.0 : ge;    // the design sees the band and its skirt
       pk = std::max(pk, g[(size_t)k]);
     }
     if (!(pk > 0.0)) return;
     int klo = B, khi = -1;
     for (int k = 0; k < B; ++k) {
+      gains_all[n][(size_t)k] /= pk;
       g[(size_t)k] /= pk;
       if (g[(size_t)k] > 1e-4) { klo = std::min(klo, k); khi = std::max(khi, k); }
     }
@@ -312,17 +315,19 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
   }
   // the tables the kernel uses are float32: bound the error with what it will multiply by
   for (double& v : c) v = (double)(float)v;
-  // interpolator error against the distance d from the demodulation centre, worst over a few
-  // sub-sample positions of both parities
+  // interpolator error against the distance d from the demodulation centre, worst over the sub-sample
+  // positions of both parities: every one of them up to I = 64, 64 evenly spaced ones beyond (with a margin:
+  // round 3 probed 8 and read up to 2.3 x too low at I = 1024), at EVERY distance -- the side lobes outside the
+  // design band count with their own (tiny) gains
   std::vector<double> err((size_t)2 * B, 0.0);             // d = -B .. B-1 at index d + B
-  const int n_probe = std::min(I, 8);
+  const int n_probe = std::min(I, 64);
+  const double probe_margin = n_probe < I ? 1.25 : 1.0;
   for (int par = 0; par < 2; ++par)
     for (int pr = 0; pr < n_probe; ++pr) {
       const int rho = (int)(((int64_t)(2 * pr + 1) * I) / (2 * n_probe));
       const double tau = ((double)rho - 0.5 * par) / (double)I;
       const double* cr = c.data() + ((size_t)par * I + rho) * T;
       for (int d = -B; d < B; ++d) {
-        if (!(genv[(size_t)(d + B)] > 0.0)) continue;
         const double th = std::remainder(2.0 * M_PI * (double)d / ((double)B * q), 2.0 * M_PI);
         err[(size_t)(d + B)] = std::max(err[(size_t)(d + B)], interp_error_at(T, cr, tau, th));
       }
@@ -330,8 +335,9 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
   double bound = 0.0;
   for (size_t n = 0; n < lp->scales.size(); ++n) {
     const int kc = hp->scales[lp->scales[n]].demod_bin;
-    for (int k = 0; k < B; ++k) bound = std::max(bound, gains[n][(size_t)k] * err[(size_t)(k - kc + B)]);
+    for (int k = 0; k < B; ++k) bound = std::max(bound, gains_all[n][(size_t)k] * err[(size_t)(k - kc + B)]);
   }
+  bound *= probe_margin;
   lp->interp_err = bound;
   lp->interp_alpha = alpha;
   if (!(bound <= hp->interp_tol)) return;
@@ -339,6 +345,53 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
   lp->interp_factor = I;
   lp->coef_offset = (int64_t)hp->interp_coef.size();
   for (double v : c) hp->interp_coef.push_back((float)v);
+}
+
+// The same levels come back with every plan of a recording (ContinuousWaveletTransform.transform() makes one per
+// call) and a level's design -- the gains on 256 bins of every scale, the fit, the bound over every sub-sample
+// position -- is most of a plan's host time (20 of 29 ms for the headline grid): the whole outcome is kept,
+// process-wide, keyed by everything it depends on.
+namespace {
+struct InterpDesign {
+  int q, factor;
+  double alpha, err;
+  std::vector<int> demod;
+  std::vector<float> coef;       // empty when the level is not interpolated
+};
+}  // namespace
+
+static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
+  static std::mutex mu;
+  static std::map<std::vector<double>, InterpDesign> cache;
+  std::vector<double> key{(double)hp->block, (double)lp->decimation, (double)lp->band_shift, (double)hp->prm.out_mode,
+                          hp->prm.gamma, hp->prm.beta, (double)hp->prm.wavelet_flags, hp->interp_tol,
+                          (double)option_or("interp_min_r", 16), (double)option_or("interp_q", 2)};
+  for (int sidx : lp->scales) { key.push_back(hp->scales[sidx].omega); key.push_back((double)hp->scales[sidx].length); }
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+      const InterpDesign& d = it->second;
+      lp->interp_q = d.coef.empty() ? 0 : d.q;
+      lp->interp_factor = d.factor;
+      lp->interp_alpha = d.alpha;
+      lp->interp_err = d.err;
+      for (size_t n = 0; n < lp->scales.size() && n < d.demod.size(); ++n) hp->scales[lp->scales[n]].demod_bin = d.demod[n];
+      if (!d.coef.empty()) {
+        lp->coef_offset = (int64_t)hp->interp_coef.size();
+        hp->interp_coef.insert(hp->interp_coef.end(), d.coef.begin(), d.coef.end());
+      }
+      return;
+    }
+  }
+  const size_t before = hp->interp_coef.size();
+  plan_interp_level_uncached(hp, lp);
+  InterpDesign d{lp->interp_q, lp->interp_factor, lp->interp_alpha, lp->interp_err, {}, {}};
+  for (int sidx : lp->scales) d.demod.push_back(hp->scales[sidx].demod_bin);
+  if (lp->interp_q > 0) d.coef.assign(hp->interp_coef.begin() + (std::ptrdiff_t)before, hp->interp_coef.end());
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache.size() >= 256) cache.clear();
+  cache.emplace(std::move(key), std::move(d));
 }
 
 static int64_t next_pow2(int64_t v) {
@@ -518,6 +571,23 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       if (!changed) break;
     }
     if (!moved) break;
+  }
+  // A decimation whose band is shifted (it holds scales with a two-sided band) goes through k_synth7 only, which
+  // parks at most 256 scales of a level: what is beyond that takes the exact full-band (or time-domain) path
+  // instead of failing the plan.
+  {
+    std::map<int, std::vector<int>> by_r;
+    for (int i = 0; i < prm.n_freqs; ++i)
+      if (hp->scales[i].method == GCWT_SCALE_SPECTRAL) by_r[hp->scales[i].decimation].push_back(i);
+    for (auto& kv : by_r) {
+      bool shifted = false;
+      for (int i : kv.second) shifted = shifted || hp->scales[i].theta_neg > 0.0;
+      if (!shifted) continue;
+      for (size_t n = 256; n < kv.second.size(); ++n) {
+        ScalePlan& sp = hp->scales[kv.second[n]];
+        sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
+      }
+    }
   }
   // A decimation that only a few scales reach is folded into the next lower one: every
   // workgroup of a level pays a prologue worth about three scales of its walk (7.8 us against

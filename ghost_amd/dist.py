@@ -82,7 +82,17 @@ def pin_to_device_numa(device, sysfs="/sys"):
             cpus = parse_cpulist(fh.read()) & set(os.sched_getaffinity(0))
         if not cpus:
             return None, 0
-        os.sched_setaffinity(0, cpus)
+        # every thread of the process (the HIP runtime's helpers exist already by the time a rank knows its
+        # device): sched_setaffinity(0, ...) alone would move the calling thread only
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")]
+        except OSError:
+            tids = [0]
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, cpus)
+            except OSError:
+                pass                                  # a thread that ended meanwhile
         return node, len(cpus)
     except Exception:
         return None, 0
@@ -197,29 +207,36 @@ class Comm:
         self._seq += 1
         stem = os.path.join(self.dir, "%s_%06d" % (tag, self._seq))
         _publish("%s.%d" % (stem, self.rank), repr(float(value)).encode())
-        vals = [float(_wait_for("%s.%d" % (stem, r), self.timeout)) for r in range(self.world)]
+        timeout = getattr(self, "_fallback_timeout", None) or self.timeout
+        self._fallback_timeout = None                # (after an RCCL enqueue failure: the first operation only)
+        vals = [float(_wait_for("%s.%d" % (stem, r), timeout)) for r in range(self.world)]
         return min(vals) if negate else max(vals)
 
     # -- interface ------------------------------------------------------------
     def _rccl_failed(self, what, err):
-        """An RCCL call failed after set-up.  Only an error raised when the collective is
-        ENQUEUED (GCWT_ERR_COMM: bad communicator, library state) is the same on every rank, so
-        only then is the operation served from the file backend instead -- with a short
-        time-out, so that a rank whose peers did not fail exits instead of waiting.  A
-        collective that was enqueued and did not complete means a peer is gone: the
-        communicator is aborted (never destroyed: that would wait for the peer) and the error
-        goes to the caller, whose process ends non-zero so that the launcher stops the rest."""
-        from ._lib import ERR_COMM
+        """An RCCL-backed call failed after set-up.  Three cases, told apart by the library's code:
+        * GCWT_ERR_COMM -- the collective could not be ENQUEUED (bad communicator, library state): the same on
+          every rank, so the operation is served from the file backend instead; the first fall-back operation
+          runs with a short time-out, so that a rank whose peers did not fail exits instead of waiting;
+        * GCWT_ERR_COMM_INCOMPLETE -- it was enqueued and did not complete: a peer is gone.  The communicator
+          is aborted (never destroyed: that would wait for the peer) and the error goes to the caller, whose
+          process ends non-zero so that the launcher stops the rest;
+        * anything else (a local HIP error or a refused argument from the plan's upload) is this rank's own
+          failure: re-raised as it is, after the communicator is aborted so that nothing waits on it."""
+        from ._lib import ERR_COMM, ERR_COMM_INCOMPLETE
         self.rccl_error = "%s: %s" % (what, err)
-        symmetric = getattr(err, "code", None) == ERR_COMM
+        code = getattr(err, "code", None)
         try:
             self._drop_rccl(abort=True)
         except Exception:
             self._handle = None
         self.backend = "file"
-        self.timeout = min(self.timeout, 20.0)
-        if not symmetric:
+        if code == ERR_COMM:
+            self._fallback_timeout = min(self.timeout, 20.0)     # for the first file operation only
+            return
+        if code == ERR_COMM_INCOMPLETE:
             raise RuntimeError("RCCL %s did not complete (%s): a peer rank is gone" % (what, err))
+        raise err
 
     def barrier(self):
         if self.world == 1:

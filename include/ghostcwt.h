@@ -36,7 +36,11 @@ typedef enum {
   GCWT_ERR_NO_DEVICE = -3,   /* no HIP device / HIP runtime failure at init       */
   GCWT_ERR_HIP = -4,         /* a HIP call failed; text in gcwt_last_error()      */
   GCWT_ERR_NOMEM = -5,
-  GCWT_ERR_COMM = -6         /* RCCL unavailable or a collective failed           */
+  GCWT_ERR_COMM = -6,        /* RCCL unavailable, or a collective could not be ENQUEUED (bad
+                                communicator / library state: the same on every rank)          */
+  GCWT_ERR_COMM_INCOMPLETE = -7 /* a collective was enqueued and did not complete: a peer rank
+                                is gone (or the device failed under it); the communicator is
+                                unusable                                                       */
 } gcwt_status;
 
 /* What transform() keeps per coefficient.  The reference keeps abs() only

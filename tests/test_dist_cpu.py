@@ -164,8 +164,10 @@ def test_rccl_failure_after_setup(tmp_path, monkeypatch):
     take the run down: the operation is served by the file backend, the communicator is aborted
     -- never destroyed, which would wait for work in flight -- and the reason is kept (bench.py
     prints it as config.rccl_error).  A collective that was enqueued and did not complete
-    (GCWT_ERR_HIP) means a peer is gone: the communicator is aborted and the error is raised,
-    so that the rank exits non-zero and the launcher stops the others."""
+    (GCWT_ERR_COMM_INCOMPLETE) means a peer is gone: the communicator is aborted and the error is
+    raised, so that the rank exits non-zero and the launcher stops the others.  Any other code is the
+    rank's own failure (a HIP error while the plan uploads, say): re-raised as it is, not reported as
+    a lost peer; and the short time-out of the fall-back applies to its first operation only."""
     import threading
     import ghost_amd._lib as _lib
     from ghost_amd.dist import Comm
@@ -209,10 +211,18 @@ def test_rccl_failure_after_setup(tmp_path, monkeypatch):
         assert "barrier" in err and "unhandled system error" in err
     assert Broken.aborted == 2 and Broken.destroyed == 0
     # a collective that did not complete: no fall-back, the rank gives up
-    Broken.code = _lib.ERR_HIP
+    Broken.code = _lib.ERR_COMM_INCOMPLETE
     lone = Comm.__new__(Comm)
-    lone.rank, lone.world, lone.timeout, lone.dir, lone._seq = 0, 2, 5.0, str(tmp_path), 0
+    lone.rank, lone.world, lone.timeout, lone.dir, lone._seq = 0, 2, 500.0, str(tmp_path), 0
     lone._handle, lone.backend, lone.rccl_error = object(), "rccl", None
     with pytest.raises(RuntimeError, match="peer rank is gone"):
         lone.barrier()
-    assert lone._handle is None and Broken.aborted == 3 and lone.timeout <= 20.0
+    assert lone._handle is None and Broken.aborted == 3
+    assert lone.timeout == 500.0                     # the ranks' own time-out is never shortened for good
+    # a local failure is reported as what it is
+    Broken.code = _lib.ERR_HIP
+    lone._handle, lone.backend = object(), "rccl"
+    with pytest.raises(Exception) as ei:
+        lone.barrier()
+    assert "peer rank" not in str(ei.value) and getattr(ei.value, "code", None) == _lib.ERR_HIP
+    assert Broken.aborted == 4

@@ -148,6 +148,7 @@ def test_seeded_random_layouts_against_oracle():
     samples), several epochs with gaps, sampling rates, mixed direct/spectral scales, every
     output mode, forced time blocks."""
     rng = np.random.default_rng(20261003)
+    ran = 0
     for case in range(12):
         fs = float(rng.choice([250.0, 1000.0, 2000.0, 30000.0]))
         n_ch = int(rng.integers(1, 5))
@@ -185,6 +186,8 @@ def test_seeded_random_layouts_against_oracle():
         scale[scale == 0] = 1.0
         err = (np.abs(got - ref) / scale).max()
         assert err < (2 * TOL if output == "power" else TOL), (case, fs, n, eb, f, output, err)
+        ran += 1
+    assert ran >= 10, "only %d of 12 random layouts were accepted by the planner" % ran
 
 
 def test_batched_epochs_against_oracle():
