@@ -532,3 +532,76 @@ def test_output_adapter():
         output_numpy_or_asa(None, d, output_type="pandas")
     with pytest.raises(ModuleNotFoundError):       # nelpy is not installed here
         output_numpy_or_asa(FakeASA(np.zeros((1, 10)), 10.0, [10]), d, output_type="asa")
+
+
+def test_low_cut_lies_below_every_gain():
+    """precision = high: every decimation cuts its slice of the spectrum below `low_cut` -- the planner promises
+    that every scale reading that x_R answers with less than 2e-8 of its peak anywhere below it (checked here on
+    the exact response, between the planner's own probe points too), that heavy-tailed wavelets (side lobes above
+    that floor down to zero frequency) get no cut, and that precision = 'fast' has none."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd._lib import lib, check
+    import ctypes as C
+    f = np.geomspace(200.0, 2.0, 100)
+    p = CwtPlan(1000000, 1, 1000.0, f)
+    si, levels = p.scale_info(), p.debug_levels()
+    assert all(lv["low_cut"] > 0 for lv in levels)
+    om = 2 * np.pi * f / 1000.0
+    assert np.all(si["theta_lo"] > 0.2 * om) and np.all(si["theta_lo"] < 0.35 * om)
+    b = 1 << 24
+    for lv in levels:
+        members = np.flatnonzero(si["decimation"] == lv["decimation"])
+        assert lv["low_cut"] <= si["theta_lo"][members].min() * (1 + 1e-12)
+        a = np.unique(np.round(np.linspace(0, lv["low_cut"], 301) * b / (2 * np.pi)).astype(np.int64))
+        a = a[a * 2 * np.pi / b <= lv["low_cut"]]
+        for i in (members[0], members[-1]):
+            g = np.zeros(a.size)
+            check(lib.gcwt_debug_exact_gain(p._handle, int(i), a.ctypes.data_as(C.POINTER(C.c_int64)), b, a.size,
+                                            g.ctypes.data_as(C.POINTER(C.c_double))))
+            assert np.abs(g).max() <= 2.5e-8 * 2.0, (lv["decimation"], i, np.abs(g).max())   # peak gain is 2
+    heavy = CwtPlan(1000000, 1, 1000.0, f, gamma=3, beta=4)
+    assert all(lv["low_cut"] == 0 for lv in heavy.debug_levels()) and not heavy.scale_info()["theta_lo"].any()
+    fast = CwtPlan(1000000, 1, 1000.0, f, precision="fast")
+    assert all(lv["low_cut"] == 0 for lv in fast.debug_levels())
+    with pytest.raises(ValueError):
+        CwtPlan(1000, 1, 1000.0, [100.0], precision="double")
+
+
+def test_named_options_replace_the_environment(monkeypatch):
+    """The product library reads no GHOSTCWT_* variable beyond its two budgets: kernel and layout choices are
+    named options (gcwt_debug_set_option), accuracy-changing ones exist in the measure build only, unknown names
+    are refused, and an old caller's struct (garbage in the new fields) is told so."""
+    import subprocess
+    from ghost_amd import _lib
+    from ghost_amd.engine import CwtPlan, set_option
+    from ghost_amd._lib import GhostCwtError
+    f = np.geomspace(190.0, 3.0, 41)
+    n0 = CwtPlan(30000, 1, 1000.0, f).info["n_levels"]
+    monkeypatch.setenv("GHOSTCWT_SPLIT_LEVELS", "1")             # the environment alone changes nothing ...
+    assert CwtPlan(30000, 1, 1000.0, f).info["n_levels"] == n0
+    try:
+        set_option("split_levels", 1)                            # ... the named option does
+        assert CwtPlan(30000, 1, 1000.0, f).info["n_levels"] > n0
+    finally:
+        set_option("split_levels", None)
+    assert CwtPlan(30000, 1, 1000.0, f).info["n_levels"] == n0
+    with pytest.raises(GhostCwtError):
+        set_option("no_such_switch", 1)
+    if not _lib.lib.gcwt_debug_measure_build():
+        for name in ("halo_margin", "interp_q", "interp_min_r", "prune_inputs", "synth_drop_stores"):
+            with pytest.raises(GhostCwtError) as ei:
+                set_option(name, 0)
+            assert ei.value.code == _lib.ERR_UNSUPPORTED
+        names = subprocess.run(["strings", _lib.LIB_PATH], capture_output=True, text=True).stdout
+        assert len([l for l in names.splitlines() if l.startswith("GHOSTCWT_") and len(l) > 9]) == 0
+    p = _lib.Params()
+    p.n_samples, p.n_channels, p.n_freqs, p.fs, p.gamma, p.beta = 1000, 1, 1, 1000.0, 3.0, 20.0
+    fr = (C_double * 1)(100.0)
+    p.freqs_hz = fr
+    p.reserved0 = 7
+    h = C_void_p()
+    assert _lib.lib.gcwt_plan_create(C_byref(h), C_byref(p)) == _lib.ERR_INVALID
+    assert b"reserved0" in _lib.lib.gcwt_last_error()
+
+
+from ctypes import byref as C_byref, c_double as C_double, c_void_p as C_void_p   # noqa: E402

@@ -21,7 +21,23 @@ for case in range(n_cases):
     if os.environ.get("SOAK_BIG"):             # long recordings too: FFT lengths up to 2^22, time blocks
         sizes += [400000, 1100000, 2500000]
     n = int(rng.choice(sizes))
-    x = (rng.standard_normal((n_ch, n)) * rng.uniform(0.1, 50) + rng.uniform(-100, 100, (n_ch, 1))).astype(np.float32)
+    x = rng.standard_normal((n_ch, n)) * rng.uniform(0.1, 50)
+    # round 4: half of the cases are recordings with steep spectra, mains interference or drift (white noise is the
+    # easy case for float32 transforms: ghost_amd/synthetic.py: SPECTRUM_CLASSES)
+    kind = "white"
+    if rng.random() < 0.5 and n >= 500:
+        kind = str(rng.choice(["brown", "f3", "line", "drift"]))
+        t = np.arange(n) / fs
+        for c in range(n_ch):
+            if kind in ("brown", "f3"):
+                spec = np.fft.rfft(x[c])
+                k = np.maximum(np.arange(spec.size, dtype=np.float64), 1.0)
+                x[c] = np.fft.irfft(spec / k ** (1.0 if kind == "brown" else 1.5), n=n)
+            elif kind == "line":
+                x[c] += rng.uniform(10, 100) * x[c].std() * np.sin(2 * np.pi * rng.uniform(0.01, 0.4) * fs * t + c)
+            else:
+                x[c] += rng.uniform(100, 1000) * x[c].std() * np.sin(2 * np.pi * rng.uniform(0.1, 3.0) * t / (n / fs) + c)
+    x = (x + rng.uniform(-100, 100, (n_ch, 1)) * x.std()).astype(np.float32)
     k = int(rng.integers(0, 7))
     cuts = np.sort(rng.choice(np.arange(1, n), size=min(n - 1, k), replace=False)) if n > 8 else np.array([], int)
     edges = [0, *cuts.tolist(), n]
@@ -62,8 +78,8 @@ for case in range(n_cases):
     same = np.array_equal(blk, got[:, :, a:a + ln])
     si = p.scale_info()
     tol = 2 * TOL if output == "power" else TOL
-    print("case %2d: fs %7.0f ch %d n %6d ep %d g,b %g,%4g scales %d R<=%5d direct %d full %d segs %3d %-9s err %.2e block %s" %
-          (case, fs, n_ch, n, len(eb), gamma, beta, f.size, si["decimation"].max(), int((si["method"] == 1).sum()),
+    print("case %2d: %-5s fs %7.0f ch %d n %6d ep %d g,b %g,%4g scales %d R<=%5d direct %d full %d segs %3d %-9s err %.2e block %s" %
+          (case, kind, fs, n_ch, n, len(eb), gamma, beta, f.size, si["decimation"].max(), int((si["method"] == 1).sum()),
            int((si["method"] == 2).sum()), len(p.segments()), output, err, "ok" if same else "DIFFERS"), flush=True)
     if os.environ.get("SOAK_DETAIL") and err / (tol / TOL) > float(os.environ["SOAK_DETAIL"]):   # per scale: where the error sits
         e_s = (np.abs(got - ref) / scale).max(axis=(0, 2))
