@@ -437,7 +437,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   if (any_fft) {
     // one workspace slot per (segment of a batch, channel)
     const int64_t slots = C * hp.max_batch;
-    if ((rc = dev_alloc(&p->d_x, (size_t)(slots * hp.max_p)))) return bail(rc);
+    if ((rc = dev_alloc(&p->d_x, (size_t)(slots * hp.max_p_store)))) return bail(rc);
     if (p->high_precision && p->fast_fft) {
       // rows 0 .. P1/2 of the intermediate (all of them when full-band scales read the whole spectrum)
       for (const EpochPlan& ep : hp.epochs) {
@@ -756,8 +756,10 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     if (nb == 0) continue;
     sin.n_channels = sout.n_channels = C;
     const int slots = C * nb;
-    const int64_t P = ep.p;
-    const int P1 = ep.p1;
+    // P, P1: the STORED spectrum (rows of 4096 bins); Pt: the segment's true FFT length.  They differ in long mode
+    // only (planner.h, EpochPlan::long_a: Pt = A P, the spectrum's low half combined from A interleaved transforms)
+    const int64_t P = ep.p_store, Pt = ep.p;
+    const int P1 = ep.p1, A = ep.long_a;
     // The input is real, so rows k1 and P1 - k1 of the k1-major spectrum mirror each other:
     // the fast path builds rows 0 .. P1/2 only and writes the rest as their reflections.
     // Full-band scales read every bin, so a plan that has any builds the whole spectrum.
@@ -766,10 +768,14 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     // forward FFT, pass A: FFT over n1 (stride 4096) of x[4096 n1 + n2], twiddle W_P^{-n2 k1}
     if (p->d_y) {
       // precision = high: both passes in float64, the spectrum rounded to float32 per bin (fwd64.hip)
-      RUN(ST_FWD, launch_fwd64_cols(dx, p->d_y, P1, N, p->y_stride, P, p->d_tw64, p->d_sums, inv_n, sin, nb,
-                                    rows_a, st));
-      RUN(ST_FWD, launch_fwd64_rows(p->d_y, p->d_x, rows_a, p->y_stride, P, p->d_tw64, slots,
-                                    hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0, st));
+      for (int a = 0; a < A; ++a) {
+        RUN(ST_FWD, launch_fwd64_cols(dx, p->d_y, P1, N, p->y_stride, P, p->d_tw64, p->d_sums, inv_n, sin, nb,
+                                      rows_a, st, A, a));
+        RUN(ST_FWD, launch_fwd64_rows(p->d_y, p->d_x, rows_a, p->y_stride, P, p->d_tw64, slots,
+                                      hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0, st, a, A, Pt));
+      }
+    } else if (A > 1) {
+      return set_err(GCWT_ERR_UNSUPPORTED, "internal: long mode without the float64 forward transform");
     } else {
     RUN(ST_FWD, launch_fft_cols_batch(dx, p->d_x, P1, kRowLen, N, P, P1 > 1 ? P : 0, p->d_tw4096,
                                       fast_fft ? p->d_tw256 : nullptr, p->d_sums, inv_n, sin, nb, st,
@@ -819,7 +825,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       hipStream_t ls = st;
       RowTaper taper;                      // precision = high: the slice loses what lies below every scale's band
       if (p->high_precision && lp.taper_hi > 0.0 && lp.band_shift == 0) {
-        const double k1 = lp.taper_hi * (double)P / (2.0 * M_PI), k0 = 0.5 * k1;
+        const double k1 = lp.taper_hi * (double)Pt / (2.0 * M_PI), k0 = 0.5 * k1;
         if (k1 - k0 >= 1.0) { taper.p1 = P1; taper.k0 = (float)k0; taper.inv_width = (float)(1.0 / (k1 - k0)); }
       }
       if (side) {                          // level (and whoever shares its x_R) -> its own stream
@@ -834,8 +840,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       }
       if (lp.xr_owner != (int)l) {
         // x_R of this decimation was made for the level that owns it (an earlier one)
-      } else if (lp.decimation <= kMaxTwoPassDecimation) {
-        const int Q = kRowLen / lp.decimation;
+      } else if (lp.decimation / A <= kMaxTwoPassDecimation) {
+        const int Q = kRowLen * A / lp.decimation;        // M = P1 Q samples: decimation R / A of the stored spectrum
         const float2* src = p->d_x;
         int64_t src_row = kRowLen, src_cstride = P;
         if (lp.band_shift > 0) {
@@ -861,7 +867,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         const int q = (int)(el.m / n1);
         RUN(ST_DECIM, launch_level_small(p->d_x, xr, n1, q, kRowLen, P, hp.max_xr, p->d_tw4096, slots, ls, taper));
       }
-      const float scale = (float)(1.0 / ((double)hp.block * (double)P));
+      const float scale = (float)(1.0 / ((double)hp.block * (double)Pt));
       const LevelKernel lk = level_kernel(p, lp);
       if (lk == LK_SYNTH16 || (lk == LK_SYNTH7 && !fused_blocks))     // the kernels that read XB
         RUN(ST_BLOCK, launch_block_fft(xr, p->d_xb + el.xb_offset, el.m, lp.hop, lp.halo, el.blk_lo,
@@ -908,7 +914,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       ai.row_len = row_len;
       ai.xr = p->d_xr;
       ai.xr_cstride = hp.max_xr;
-      ai.xb_scale = (float)(1.0 / ((double)hp.block * (double)P));
+      ai.xb_scale = (float)(1.0 / ((double)hp.block * (double)Pt));
       ai.n_scales = S;
       // Which index runs fastest in the grid decides what is in flight together: the same few items
       // of every channel, or many items of one channel.  Measured (profiles/r03_synth_study.md 12): with
@@ -961,7 +967,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       if (fused_blocks) {
         a7.xr = p->d_xr;
         a7.xr_cstride = hp.max_xr;
-        a7.xb_scale = (float)(1.0 / ((double)hp.block * (double)P));
+        a7.xb_scale = (float)(1.0 / ((double)hp.block * (double)Pt));
       }
 #ifdef GCWT_MEASURE
       if (p->synth_kernel == 8 && !wide)
@@ -1356,8 +1362,8 @@ int gcwt_debug_fetch(gcwt_plan* p, int what, int channel, int epoch, int level, 
   const float2* src = nullptr;
   int64_t n = 0;
   if (what == GCWT_DEBUG_SPECTRUM) {
-    src = p->d_x + slot * ep.p;
-    n = ep.p;
+    src = p->d_x + slot * ep.p_store;
+    n = ep.p_store;
   } else {
     if (level < 0 || level >= (int)hp.levels.size()) return set_err(GCWT_ERR_INVALID, "level out of range");
     if (what == GCWT_DEBUG_DECIMATED) {

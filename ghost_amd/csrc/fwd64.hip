@@ -199,7 +199,8 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
                                                            int lg_p, const cd* __restrict__ tw_hi,
                                                            const cd* __restrict__ tw_lo,
                                                            const double* __restrict__ sums, double inv_n,
-                                                           const SegIn segs, int rows_out) {
+                                                           const SegIn segs, int rows_out, int in_stride, int in_offset) {
+  // in_stride A, in_offset a: the transform of the subsequence x[A n + a] (long mode: planner.h, EpochPlan::long_a)
   constexpr int q = 1 << LQ, len = 256 * q, np = q / 2;
   static_assert(q == 2 || q == 4, "two or four subsequences");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
   for (int p = 0; p < np; ++p) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int na = (q * (t + 16 * j) + 2 * p) * ld + col0 + s, nb = na + ld;
+      const int na = ((q * (t + 16 * j) + 2 * p) * ld + col0 + s) * in_stride + in_offset, nb = na + ld * in_stride;
       const float xa = x[min(max(na, n_lead), top)], xb = x[min(max(nb, n_lead), top)];   // clamped
       v[j] = make_double2(na >= n_lead && na < n_valid ? (double)xa - mean : 0.0,
                           nb >= n_lead && nb < n_valid ? (double)xb - mean : 0.0);
@@ -325,9 +326,12 @@ __global__ void __launch_bounds__(256) k_fwd64_cols_small(const float* __restric
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int dpad(int i) { return i + (i >> 4); }
 
+// comb_n > 1 (long mode): this is subsequence comb_a of comb_n; every output bin k is multiplied by W_pt^(a k),
+// pt = 2^lg_pt the true FFT length, and added to what the earlier subsequences left (a = 0 stores).
 __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, float2* __restrict__ out,
                                                     int64_t in_cstride, int64_t out_cstride,
-                                                    const cd* __restrict__ tw_hi, int out_len, int mirror) {
+                                                    const cd* __restrict__ tw_hi, int out_len, int mirror,
+                                                    int comb_a, int comb_n, int lg_pt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* const ex_re = reinterpret_cast<double*>(smem);
   double* const ex_im = ex_re + 16 * kDCol;
@@ -357,6 +361,20 @@ __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, f
 #pragma unroll
   for (int ka = 0; ka < 16; ++ka) {
     const int idx = kb + 256 * ka;
+    if (comb_n > 1) {                    // (long mode implies the reflected layout: mirror = P1)
+      const cd* tw_lo = tw_hi + 4096;
+      int drow, didx;
+      cd v2 = u[ka];
+      if (idx < kRowLenDev / 2) { drow = row; didx = idx; }
+      else if (row > 0 && 2 * row < mirror) { drow = mirror - row; didx = kRowLenDev - 1 - idx; v2 = dconj(v2); }
+      else continue;
+      const int64_t kdest = (int64_t)drow + (int64_t)mirror * didx;
+      v2 = dmul(v2, d_phase(tw_hi, tw_lo, (int64_t)comb_a * kdest, lg_pt));
+      float2* dst = o + (int64_t)drow * kRowLenDev + didx;
+      if (comb_a == 0) *dst = make_float2((float)v2.x, (float)v2.y);
+      else { const float2 old = *dst; *dst = make_float2((float)((double)old.x + v2.x), (float)((double)old.y + v2.y)); }
+      continue;
+    }
     const float2 val = make_float2((float)u[ka].x, (float)u[ka].y);
     if (mirror == 0) {
       if (256 * ka < out_len) o[(int64_t)row * kRowLenDev + idx] = val;
@@ -396,12 +414,15 @@ void fwd64_fill_tables(double2* host) {
 
 hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cstride, int64_t y_cstride,
                              int64_t p, const double2* tables, const double* sums, double inv_n,
-                             const SegIn& segs, int n_segments, int rows_out, hipStream_t st) {
+                             const SegIn& segs, int n_segments, int rows_out, hipStream_t st, int in_stride,
+                             int in_offset) {
   const int slots = segs.n_channels * n_segments, ld = kRowLenDev, lg_p = ilog2_64(p);
   const cd* tw_hi = tables;
   const cd* tw_lo = tables + 4096;
   if (lg_p > 24 || ((int64_t)p1 * kRowLenDev) != p || rows_out < 1 || rows_out > p1 ||
       (int64_t)rows_out * kRowLenDev > y_cstride) return hipErrorInvalidValue;     // y holds rows_out rows per slot
+  if (in_stride < 1 || in_offset < 0 || in_offset >= in_stride || (in_stride > 1 && p1 != 512 && p1 != 1024))
+    return hipErrorInvalidValue;                     // strided input: the 2^21 / 2^22-point kernels only (long mode)
   hipError_t e;
   if (p1 == 256) {
     if ((e = allow_lds(k_fwd64_cols256_real2, kFwd64Lds)) != hipSuccess) return e;
@@ -410,12 +431,12 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
   } else if (p1 == 512) {
     if ((e = allow_lds(k_fwd64_colsq_real2<1>, kFwd64Lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_fwd64_colsq_real2<1>, dim3(ld / 16, slots), dim3(256), kFwd64Lds, st, in, y, ld,
-                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out);
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out, in_stride, in_offset);
   } else if (p1 == 1024) {
     const size_t lds = kFwd64Lds + 256 * 17 * sizeof(cd);
     if ((e = allow_lds(k_fwd64_colsq_real2<2>, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_fwd64_colsq_real2<2>, dim3(ld / 16, slots), dim3(256), lds, st, in, y, ld,
-                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out);
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out, in_stride, in_offset);
   } else if (p1 >= 1 && p1 <= 128) {
     const size_t lds = (size_t)p1 * 16 * sizeof(cd);
     hipLaunchKernelGGL(k_fwd64_cols_small, dim3(ld / 16, slots), dim3(256), lds, st, in, y, p1, ilog2_64(p1), ld,
@@ -427,11 +448,13 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
 }
 
 hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
-                             const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st) {
+                             const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st,
+                             int comb_a, int comb_n, int64_t p_true) {
+  if (comb_n > 1 && (mirror == 0 || comb_a < 0 || comb_a >= comb_n || ilog2_64(p_true) > 24)) return hipErrorInvalidValue;
   hipError_t e = allow_lds(k_fwd64_rows, kFwd64Lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fwd64_rows, dim3(n_rows, n_slots), dim3(256), kFwd64Lds, st, y, x, y_cstride, x_cstride,
-                     tables, out_len, mirror);
+                     tables, out_len, mirror, comb_a, comb_n, comb_n > 1 ? ilog2_64(p_true) : 0);
   return hipGetLastError();
 }
 

@@ -226,9 +226,12 @@ hipError_t launch_fft_rows(int sign, const float2* in, float2* out, int len, int
 void fwd64_fill_tables(double2* host);
 hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cstride, int64_t y_cstride,
                              int64_t p, const double2* tables, const double* sums, double inv_n,
-                             const SegIn& segs, int n_segments, int rows_out, hipStream_t st);
+                             const SegIn& segs, int n_segments, int rows_out, hipStream_t st, int in_stride = 1,
+                             int in_offset = 0);
+// comb_n > 1 (long mode): subsequence comb_a of comb_n, accumulated into x with the twiddle W_p_true^(a k)
 hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
-                             const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st);
+                             const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st,
+                             int comb_a = 0, int comb_n = 1, int64_t p_true = 0);
 // shifted band of a level: Xs[k1][j2] = X[k1 + P1 (j2 - u2)] from the positive half of a real signal's
 // k1-major spectrum (kernels.hip: k_shift_gather)
 hipError_t launch_shift_gather(const float2* x, float2* xs, int p1, int q, int u2, int64_t x_row,

@@ -480,8 +480,19 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   // the longest kernel that goes through an FFT: two rounds (a candidate that turns out not
   // to fit its block moves to the other paths and may shorten the FFTs).
   hp->max_fft_log2 = prm.max_fft_log2 == 0 ? 22 : prm.max_fft_log2;
-  if (hp->max_fft_log2 < 12 || hp->max_fft_log2 > 22)
-    return fail(GCWT_ERR_INVALID, "max_fft_log2 must be 0 or 12..22");
+  if (hp->max_fft_log2 < 12 || hp->max_fft_log2 > kMaxFftLog2)
+    return fail(GCWT_ERR_INVALID, "max_fft_log2 must be 0 or 12..24");
+  if (prm.max_fft_log2 == 0) {
+    // The default stays at 2^22 unless the longest kernel that goes through an FFT does not leave a time block of
+    // that length a quarter of it as its core: then 2^23 / 2^24 (long mode), so that every frequency the
+    // reference's compute_freq_bounds permits runs (morse.py:93-106: 0.116 Hz for 18e6 samples at 30 kHz)
+    int64_t lmax0 = 1;
+    for (const ScalePlan& sp : hp->scales)
+      if (sp.method != GCWT_SCALE_DIRECT) lmax0 = std::max(lmax0, sp.length);
+    while (hp->max_fft_log2 < kMaxFftLog2 &&
+           ((((int64_t)1 << hp->max_fft_log2) - 2 * (lmax0 / 2 + 2) - 64) & ~(int64_t)63) < ((int64_t)1 << hp->max_fft_log2) / 4)
+      ++hp->max_fft_log2;
+  }
   const int64_t pmax = (int64_t)1 << hp->max_fft_log2;
   auto fft_of = [&](int64_t e0, int64_t e1, int64_t lmax) {
     return std::max<int64_t>(kRowLen, next_pow2(e1 - (e0 & ~(int64_t)63) + lmax));
@@ -651,9 +662,13 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       ep.lead = std::max<int64_t>(0, e0 - ep.start);
       ep.stop = in1; ep.ne = in1 - ep.start;
       ep.core0 = c0; ep.core1 = c1; ep.epoch = e;
-      ep.p = p; ep.p1 = (int)(p / kRowLen);
+      ep.p = p;
+      ep.long_a = (int)std::max<int64_t>(1, p >> 22);
+      ep.p_store = p / ep.long_a;
+      ep.p1 = (int)(ep.p_store / kRowLen);
       pmin = std::min(pmin, p);
       hp->max_p = std::max(hp->max_p, p);
+      hp->max_p_store = std::max(hp->max_p_store, ep.p_store);
       hp->epochs.push_back(ep);
     };
     const int64_t whole = std::max<int64_t>(kRowLen, next_pow2(e1 - (e0 & ~(int64_t)63) + lmax_spec));
@@ -770,6 +785,22 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       for (LevelPlan& lp : hp->levels) plan_interp_level(hp, &lp);
   }
 
+  // long mode (FFT lengths 2^23, 2^24): what the combined low half of the spectrum can serve
+  for (const EpochPlan& ep : hp->epochs) {
+    if (ep.long_a == 1) continue;
+    if (!hp->high_precision)
+      return fail(GCWT_ERR_UNSUPPORTED, "FFT lengths above 2^22 (kernels of millions of taps) need precision = high");
+    if (hp->n_fullband > 0)
+      return fail(GCWT_ERR_UNSUPPORTED, "FFT lengths above 2^22 cannot serve full-band scales (heavy-tailed wavelet at very low frequencies)");
+    for (const LevelPlan& lp : hp->levels) {
+      const int64_t m = ep.p / lp.decimation;
+      if (lp.band_shift > 0 || lp.decimation < 2 * ep.long_a ||
+          (lp.decimation / ep.long_a > kMaxTwoPassDecimation && m > 8192))
+        return fail(GCWT_ERR_UNSUPPORTED,
+                    "FFT lengths above 2^22 need every decimation level at R >= 2 * (FFT length / 2^22): the plan mixes "
+                    "kernels of millions of taps with scales near Nyquist (split the frequency list in two plans)");
+    }
+  }
   // per-segment block ranges of every level
   for (EpochPlan& ep : hp->epochs) {
     ep.lv.resize(hp->levels.size());
@@ -842,7 +873,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     first += count;
   }
 
-  hp->workspace_bytes = 8 * C * hp->max_batch * (hp->max_p + hp->max_xr + hp->max_xb)   // X, x_R, XB
+  hp->workspace_bytes = 8 * C * hp->max_batch * (hp->max_p_store + hp->max_xr + hp->max_xb)   // X, x_R, XB
                         + (hp->n_fullband > 0 ? 8 * (C * hp->max_batch + 1) * hp->max_p : 0)  // Z, H
                         + 8 * (int64_t)hp->amps.size()
                         + 8 * (int64_t)prm.n_freqs * B                  // bank

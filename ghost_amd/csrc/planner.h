@@ -18,7 +18,8 @@
 namespace gcwt {
 
 constexpr int kRowLen = 4096;      // row length of the two-pass big FFT (P = P1 * 4096)
-constexpr int kMaxP1 = 1024;       // P <= 2^22
+constexpr int kMaxP1 = 1024;       // a stored spectrum has at most 2^22 bins (longer FFTs: EpochPlan::long_a)
+constexpr int kMaxFftLog2 = 24;    // longest FFT of a segment; above 2^22 in "long mode" (EpochPlan::long_a)
 constexpr int kMaxDecimation = 16384;
 constexpr int kMaxBatch = 16;                // segments per launch set (kernels.h: kSegBatch)
 constexpr int kMaxTwoPassDecimation = 256;   // above it the level IFFT uses the small-size kernel
@@ -100,7 +101,14 @@ struct EpochPlan {
   int64_t lead = 0;                // leading samples of the segment that lie before the epoch (zero)
   int epoch = 0;
   int64_t p = 0;                   // FFT length of this epoch
-  int p1 = 0;                      // p = p1 * kRowLen
+  int p1 = 0;                      // p_store = p1 * kRowLen rows of the stored spectrum
+  // Long mode (round 4): a segment whose FFT is longer than 2^22 (a kernel of millions of taps: below 0.13 Hz at
+  // 30 kHz) is transformed as long_a = p / 2^22 interleaved subsequences x[A n + a], each through the two-pass
+  // FFT of p_store = p / A points, combined bin by bin: X[k] = sum_a W_p^(a k) X_a[k] for k < p_store / 2 -- the
+  // only bins a plan reads whose levels all have R >= 2 A.  Everything after the forward transform sees a
+  // spectrum of p_store bins in the usual k1-major layout and levels of decimation R / A of it.
+  int long_a = 1;
+  int64_t p_store = 0;
   std::vector<EpochLevel> lv;      // one per HostPlan::levels; shared by the segment's batch
   std::vector<SynthItem> items;
   int64_t xr_total = 0, xb_total = 0;  // per-channel complex elements
@@ -134,6 +142,7 @@ struct HostPlan {
   int64_t direct_total = 0;        // complex elements of all direct kernels
   int64_t level_twiddle_total = 0;
   int64_t max_p = 0, max_xr = 0, max_xb = 0;
+  int64_t max_p_store = 0;         // largest stored spectrum (= max_p unless a segment is in long mode)
   std::vector<float> interp_coef;  // interpolator coefficients of every interpolated level
   double interp_tol = 2e-7;        // largest interp_err a level may have and still be interpolated
   int max_fft_log2 = 22;

@@ -88,8 +88,10 @@ typedef struct {
   int32_t block;               /* decimated block length B; 0 = default (256)     */
   double band_eps;             /* response the fast path may ignore outside a scale's
                                   band, relative to the peak; 0 = 2e-7             */
-  int32_t max_fft_log2;        /* longest FFT the plan may use, 12..22; 0 = 22.  Epochs
-                                  that need more are cut into overlapping time blocks  */
+  int32_t max_fft_log2;        /* longest FFT the plan may use, 12..24; 0 = 22, or 23 / 24 when the
+                                  longest kernel does not fit time blocks of 2^22 samples (below
+                                  0.13 Hz at 30 kHz).  Epochs that need more are cut into overlapping
+                                  time blocks                                                          */
   int32_t wavelet_flags;       /* 0 = what transform() uses: first wavelet, 'bandpass'
                                   (morse.py:84-91).  Bits 0-7: order k of the orthogonal
                                   family (0 = first; morseutils.py:181-196); bit 8: 'energy'

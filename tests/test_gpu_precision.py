@@ -114,3 +114,57 @@ def test_config5_block_on_a_steep_spectrum():
     print("config-5 block, brown + offset: worst %.2e" % worst)
     assert worst < TOL
     p.close()
+
+
+def test_lowest_frequency_the_reference_permits_at_30_khz():
+    """`Morse.compute_freq_bounds` (morse.py:93-106) allows 0.1162 Hz for a 10-minute epoch at 30 kHz: a kernel of
+    3.59 million taps.  Time blocks of 2^22 samples cannot hold it (round 3: UNSUPPORTED below 0.13 Hz); the plan
+    now takes FFTs of 2^23 points in long mode -- the low half of each block's spectrum combined from two
+    interleaved 2^22-point float64 transforms -- and every level works at R / 2 of the stored spectrum.  Rows
+    across a seam between time blocks against the oracle, 500 Hz .. 0.1165 Hz in one plan."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp_channel
+    fs, n = 30000.0, 18000000
+    lo, _ = orc.morse_freq_bounds(n)
+    f_floor = float(orc.rad_to_hz(lo, fs))
+    assert 0.116 < f_floor < 0.1165
+    f = np.array([500.0, 60.0, 1.0, 0.13, f_floor * 1.0005])
+    x = lfp_channel(n, fs, channel=5)
+    p = CwtPlan(n, 1, fs, f, output="amplitude")
+    segs = p.segments()
+    assert len(segs) >= 2 and all(s[2] == 1 << 23 for s in segs) and p.info["n_spectral"] == 5
+    lengths = p.scale_info()["length"]
+    assert lengths[-1] > 3500000
+    seam = segs[1][0]
+    a, ln = seam - 60000, 120000
+    got = p.execute_block(x[None], a, ln)[0]
+    om = orc.hz_to_rad(f, fs)
+    xc = x.astype(np.float64)
+    xc -= xc.mean()
+    worst = 0.0
+    for sc in range(f.size):
+        L = int(lengths[sc])
+        psi, _ = orc.morse_kernel(L, om[sc])
+        w0, w1 = max(0, a - L), min(n, a + ln + L)
+        ref = np.abs(orc.overlap_add_convolve(xc[w0:w1], psi)[a - w0:a - w0 + ln])
+        e = float(np.abs(got[sc] - ref).max() / ref.max())
+        print("%.4f Hz, L = %d: %.2e" % (f[sc], L, e))
+        worst = max(worst, e)
+    assert worst < TOL
+    p.close()
+    # the same with FFTs of 2^24 points (four interleaved transforms per block), bit-compatible planning: the first
+    # and the last scale again, across that plan's own seam
+    p4 = CwtPlan(n, 1, fs, f, output="amplitude", max_fft_log2=24)
+    segs4 = p4.segments()
+    assert len(segs4) == 2 and all(s[2] == 1 << 24 for s in segs4)
+    a4 = segs4[1][0] - 60000
+    got4 = p4.execute_block(x[None], a4, ln)[0]
+    for sc in (0, f.size - 1):
+        L = int(lengths[sc])
+        psi, _ = orc.morse_kernel(L, om[sc])
+        w0, w1 = max(0, a4 - L), min(n, a4 + ln + L)
+        ref = np.abs(orc.overlap_add_convolve(xc[w0:w1], psi)[a4 - w0:a4 - w0 + ln])
+        e = float(np.abs(got4[sc] - ref).max() / ref.max())
+        print("2^24: %.4f Hz: %.2e" % (f[sc], e))
+        assert e < TOL
+    p4.close()

@@ -567,6 +567,30 @@ def test_low_cut_lies_below_every_gain():
         CwtPlan(1000, 1, 1000.0, [100.0], precision="double")
 
 
+def test_long_mode_planning():
+    """Kernels of millions of taps (below 0.13 Hz at 30 kHz, down to the reference's own floor, morse.py:93-106): the
+    default plan moves to FFTs of 2^23 / 2^24 points by itself, keeps 2^22 for everything that fits it, and says why
+    when a plan cannot be served that way."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd._lib import GhostCwtError
+    fs, n = 30000.0, 18000000
+    ordinary = CwtPlan(n, 1, fs, np.geomspace(500.0, 1.0, 20))
+    assert all(s[2] == 1 << 22 for s in ordinary.segments())                   # config 5 is untouched
+    deep = CwtPlan(n, 1, fs, np.array([500.0, 1.0, 0.1165]))
+    assert all(s[2] == 1 << 23 for s in deep.segments()) and deep.info["fft_length"] == 1 << 23
+    segs = deep.segments()
+    assert segs[0][0] == 0 and segs[-1][1] == n and all(a[1] == b[0] for a, b in zip(segs[:-1], segs[1:]))
+    assert deep.scale_info()["length"][-1] > 3500000 and deep.info["n_spectral"] == 3
+    forced = CwtPlan(n, 1, fs, np.array([500.0, 0.1165]), max_fft_log2=24)
+    assert all(s[2] == 1 << 24 for s in forced.segments())
+    with pytest.raises(GhostCwtError, match="precision = high"):
+        CwtPlan(n, 1, fs, np.array([500.0, 0.1165]), precision="fast")
+    with pytest.raises(GhostCwtError, match="R >= 2"):                           # a scale at R = 4 beside a 3.6 M-tap kernel
+        CwtPlan(n, 1, fs, np.array([3000.0, 0.1165]), max_fft_log2=24)
+    with pytest.raises(GhostCwtError):
+        CwtPlan(n, 1, fs, np.array([500.0]), max_fft_log2=25)
+
+
 def test_named_options_replace_the_environment(monkeypatch):
     """The product library reads no GHOSTCWT_* variable beyond its two budgets: kernel and layout choices are
     named options (gcwt_debug_set_option), accuracy-changing ones exist in the measure build only, unknown names
