@@ -25,8 +25,8 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-enum { FIR8, FIR8C, FIR6, FIR8NS, FIR6NS, ST32, ST16, FIR6C, FIR4C, N_MODES };
-static const char* kNames[N_MODES] = {"fir8", "fir8c", "fir6", "fir8ns", "fir6ns", "st32", "st16", "fir6c", "fir4c"};
+enum { FIR8, FIR8C, FIR6, FIR8NS, FIR6NS, ST32, ST16, FIR6C, FIR4C, MFMA8, MFMA8NS, ST4, N_MODES };
+static const char* kNames[N_MODES] = {"fir8", "fir8c", "fir6", "fir8ns", "fir6ns", "st32", "st16", "fir6c", "fir4c", "mfma8", "mfma8ns", "st4"};
 
 // acc += z * c.x  /  acc += z * c.y   (complex z, real coefficient broadcast to both halves)
 __device__ __forceinline__ void fma_lo(v2f& acc, v2f z, v2f c) {
@@ -106,6 +106,83 @@ __global__ void __launch_bounds__(512, 4) k_run(float* out, float* sink, int ite
   if (blockIdx.x == 7 && tid == 0) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
 }
 
+// Round 4: the same 8-tap polyphase FIR on the matrix pipe.  Out[m][rho] = sum_j z[m + j] c_rho[j] for 32 intervals m
+// x 32 sub-sample positions rho is a 32 x 8 (Hankel of z) by 8 x 32 (coefficients) product: four
+// v_mfma_f32_32x32x2_f32 for the real parts and four for the imaginary parts per 1024 outputs of a wave (full fp32
+// arithmetic; the fp32 matrix rate equals the packed-vector rate, but it is another pipe: the vector pipe keeps |.|,
+// the LDS reads and the stores).  A lane ends up with column rho = lane % 32 and 16 intervals: a store instruction
+// writes two 128-byte runs (dword stores), like k_synth7.
+//   mfma8   with stores    mfma8ns  without    st4  only those stores
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) k_run_mfma(float* out, float* sink, int iters, long long* clk) {
+  constexpr bool kStore = MODE != MFMA8NS;
+  constexpr bool kFir = MODE != ST4;
+  __shared__ __attribute__((aligned(16))) v2f z[kZ + 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < kZ + 64; i += 512) z[i] = (v2f){1e-3f * (i & 63), 1e-3f};
+  // B operand: coefficient c[rho][2 i + k], rho = lane % 32, k = lane / 32, one register per instruction
+  float cb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cb[i] = 0.1f + 0.01f * (lane & 31) - 0.01f * (2 * i + (lane >> 5));
+  char* const base = reinterpret_cast<char*>(sink) + (size_t)blockIdx.x * (4u << 20);
+  float acc_keep = 0.f;
+  __syncthreads();
+  const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+    // this wave's 32 intervals of the iteration: 8 waves x 32 = 256 intervals x 32 positions = 8192 outputs = 32 KB
+    const int m0 = ((it * 8 + wave) * 32) & (kZ - 1);
+    v16f are, aim;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { are[v] = 0.f; aim[v] = 0.f; }
+    if (kFir) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const v2f a = z[m0 + (lane & 31) + 2 * i + (lane >> 5)];         // A[m][k] = z[m + 2 i + k]
+        are = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, cb[i], are, 0, 0, 0);
+        aim = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, cb[i], aim, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) are[v] = 1.f + v + tid;
+    }
+    // lane: column rho = lane % 32, rows (intervals) 8 (v / 4) + 4 (lane / 32) + v % 4; sample = 32 interval + rho
+    float* const dst = reinterpret_cast<float*>(base + ((size_t)(it & 127) * 8 + wave) * 4096);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const float r = kFir ? __builtin_amdgcn_sqrtf(__builtin_fmaf(aim[v], aim[v], are[v] * are[v])) : are[v];
+      const int row = 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+      if (kStore) __builtin_nontemporal_store(r, dst + 32 * row + (lane & 31));
+      else acc_keep += r;
+    }
+  }
+  const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (acc_keep == 123.456f) out[0] = acc_keep;
+  if (blockIdx.x == 7 && tid == 0) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
+}
+
+template <int MODE>
+void drive_mfma(double seconds, float* out, float* sink, long long* clk, int grid) {
+  const int iters = 2048;
+  hipLaunchKernelGGL((k_run_mfma<MODE>), dim3(grid), dim3(512), 0, 0, out, sink, 10, clk);
+  CK(hipDeviceSynchronize());
+  const auto t0 = std::chrono::steady_clock::now();
+  long launches = 0;
+  double el = 0;
+  do {
+    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL((k_run_mfma<MODE>), dim3(grid), dim3(512), 0, 0, out, sink, iters, clk);
+    CK(hipDeviceSynchronize());
+    launches += 4;
+    el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  } while (el < seconds);
+  long long h[2];
+  CK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
+  const double per_iter_us = el * 1e6 / ((double)launches * iters);
+  const double bytes = (double)grid * 8 * 4096;          // 8 waves x 1024 outputs x 4 B per workgroup and iteration
+  printf("%-7s %.2f s, %.3f us per iteration (16 samples per lane), clock %.3f GHz, %.2f TB/s\n",
+         kNames[MODE], el, per_iter_us, (double)h[0] / ((double)h[1] * 10.0), bytes / per_iter_us / 1e6);
+}
+
 template <int MODE>
 void drive(double seconds, float* out, float* sink, long long* clk, int grid) {
   const int iters = 2048;
@@ -139,6 +216,8 @@ int main(int argc, char** argv) {
   if (!strcmp(mode, "idle")) { printf("idle\n"); fflush(stdout); std::this_thread::sleep_for(std::chrono::duration<double>(seconds)); return 0; }
 #define CASE(M) if (!strcmp(mode, kNames[M])) { drive<M>(seconds, out, sink, clk, grid); return 0; }
   CASE(FIR8) CASE(FIR8C) CASE(FIR6) CASE(FIR8NS) CASE(FIR6NS) CASE(ST32) CASE(ST16) CASE(FIR6C) CASE(FIR4C)
+#define CASEM(M) if (!strcmp(mode, kNames[M])) { drive_mfma<M>(seconds, out, sink, clk, grid); return 0; }
+  CASEM(MFMA8) CASEM(MFMA8NS) CASEM(ST4)
   printf("unknown mode %s\n", mode);
   return 1;
 }
