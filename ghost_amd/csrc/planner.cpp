@@ -200,6 +200,12 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
     while (m < m_stop && env(m) <= low) ++m;
     sp->theta_lo = sp->theta_neg > 0.0 ? 0.0 : 2.0 * M_PI * (double)m / (double)L;
   }
+  // A kernel that answers above low_tol all the way down to zero frequency gets no low cut, so whatever a recording
+  // carries down there reaches the block convolution -- and the tails a block halo would cut off (support_tol is an
+  // energy figure: right for a white input) answer to it in full: 8.5e-6 on Morse(6, 13.2) with a drift of 10 x the
+  // recording's spread, in float64 (round 4's soak).  Such kernels keep their whole length (three more decimated
+  // samples of halo for that one; the default wavelet, whose levels are cut, is not concerned).
+  if (hp.high_precision && !(sp->theta_lo > 0.0)) { sp->support = 0.5 * (double)L; return; }
 
   // |psi(centre + t)|^2 = |(1/L) sum_j A_j e^{i theta_j t}|^2, same on both sides (A real);
   // total energy (1/L) sum A_j^2 (Parseval).  Walk in from t = L/2 until the tails hold

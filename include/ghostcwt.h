@@ -107,9 +107,10 @@ typedef struct {
 /* The reference computes in float64 (transforms.py:142-143, convolution.py:68-77).  HIGH (the
  * default): x - mean and the forward FFT of every epoch in float64, and every decimation level cuts
  * its slice of the spectrum to zero below the band of its scales (where every gain is under 2e-8 of
- * its peak) before the float32 stages: a band of the recording 100 x below the rest (1/f^3
- * backgrounds, mains interference, drift, offsets) still meets 1e-5.  FAST: float32 throughout
- * (rounds 1-3), for recordings whose spectrum is within ~10 x of flat across the analysed range. */
+ * its peak) before the float32 stages: content BELOW the analysed bands (drift, offsets, 1/f^n
+ * backgrounds) up to ~1000 x the quietest band still meets 1e-5 (FAST: ~65 x).  Interference INSIDE a
+ * level's band (a mains line between its scales) is good to ~65 x in both (profiles/r04_dynamic_range.md).
+ * FAST: float32 throughout (rounds 1-3). */
 typedef enum {
   GCWT_PRECISION_DEFAULT = 0,
   GCWT_PRECISION_FAST = 1,

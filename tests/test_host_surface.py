@@ -267,8 +267,10 @@ def test_planner_rejects_bad_requests():
             CwtPlan(args["n_samples"], 1, args["fs"], args["freqs"], gamma=args["gamma"],
                     epoch_bounds=args["bounds"])
         assert e.value.code == _lib.ERR_INVALID
+    # a 3.2 M-tap kernel: refused until round 4, FFTs of 2^23 points (long mode) since
+    assert CwtPlan(1 << 20, 1, 30000.0, [0.13]).segments()[0][2] == 1 << 23
     with pytest.raises(GhostCwtError) as e:
-        CwtPlan(1 << 20, 1, 30000.0, [0.13])            # 3.2 M-tap kernel: no room for time blocks
+        CwtPlan(1 << 20, 1, 30000.0, [0.02])            # 21 M taps: no room for time blocks even at 2^24
     assert e.value.code == _lib.ERR_UNSUPPORTED
 
 
