@@ -1,0 +1,64 @@
+"""Rewrites the generated fragments of DESIGN.md -- the paragraphs between `<!-- gen:NAME -->` and `<!-- /gen -->` and the
+tracked-numbers block -- from the round's tracked evidence under profiles/, so that the text and the files cannot drift
+(tests/test_docs.py checks the block).  Usage: python tools/design_numbers.py [r04]"""
+import json, os, re, sys
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+j = json.loads(open(os.path.join(root, "profiles", rnd + "_bench.json")).read().strip().splitlines()[-1])
+j5 = json.loads(open(os.path.join(root, "profiles", rnd + "_bench_config5.json")).read().strip().splitlines()[-1])
+tr = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+rl, st, cx = j["roofline"], j["stages_ms"], j["other_modes"]["complex"]
+c2, c5 = j["other_configs"]["config2"], j["other_configs"]["config5"]
+stats = {}
+import csv
+for row in csv.DictReader(open(os.path.join(root, "profiles", rnd + "_kernel_stats.csv"))):
+    stats[row["Name"].split("(")[0].replace("void ", "")] = (int(row["Calls"]), float(row["AverageNs"]) / 1e6)
+ki, k7 = stats["gcwt::k_synthi<0>"], stats["gcwt::k_synth7<0, 32, false>"]
+gen = {}
+gen["headline"] = (
+    "**Round 4** (`profiles/%s_bench.json`, `tools/prof_round.sh %s`; the synthesis kernels are unchanged, the front end is\n"
+    "float64): synthesis %.2f ms from HIP events (k_synthi %.2f + k_synth7 %.2f) = %.2f TB/s = **%.4f** of the 8 TB/s peak;\n"
+    "rocprofv3 of the same command (`profiles/%s_kernel_stats.csv`, %d launches each): %.3f + %.3f = %.2f ms.  Whole step\n"
+    "%.2f ms = %.0f Msamples/s = %.3f of the peak on algorithmic bytes (forward FFT %.2f ms in float64, level passes %.2f,\n"
+    "mean %.2f).  PMC traffic of both kernels %.2f GB per step = %.2f x the algorithmic bytes (`profiles/traffic.json`, %s).\n"
+    "Complex output, same run: %.2f ms per launch, %.2f ms per step, %.0f Msamples/s, checked %.1e."
+    % (rnd, rnd, rl["kernel_ms"], rl["kernels"]["k_synthi"]["ms"], rl["kernels"]["k_synth7"]["ms"], rl["achieved"] / 1e3, rl["frac"],
+       rnd, ki[0], ki[1], k7[1], ki[1] + k7[1], j["ms_per_step"], j["value"], j["whole_job_frac_of_hbm_peak"], st["fwd_fft_ms"],
+       st["decimate_ms"], st["mean_ms"], rl["traffic"] / 1e9, rl["traffic"] / rl["algorithmic_bytes"], tr["round"],
+       cx["kernel_ms"], cx["ms_per_step"], cx["value"], cx["worst_rel_err"]))
+gen["config5"] = (
+    "Round 4 (`profiles/%s_bench_config5.json`, float64 front end): %.1f ms per step = %.0f Msamples/s, synthesis %.1f ms =\n"
+    "**%.3f** of the HBM peak, forward FFT %.1f ms (5.1 in float32: `k_fwd64_colsq_real2<2>` holds one workgroup per CU),\n"
+    "checked %.1e; the same configuration as a leg of the driver's default run (`other_configs.config5` of\n"
+    "`profiles/%s_bench.json`, 3 steps, another moment on the same box): %.1f ms, %.3f."
+    % (rnd, j5["ms_per_step"], j5["value"], j5["stages_ms"]["synth_ms"], j5["roofline"]["frac"], j5["stages_ms"]["fwd_fft_ms"],
+       j5["check"]["worst_rel_err"], rnd, c5["ms_per_step"], c5["roofline"]["frac"]))
+gen["ledger4"] = (
+    "config 2 device-resident %.3f ms (%.0f Msamples/s) and `transform()` end to end %.0f ms float64 / %.0f ms float32, "
+    "config 5 as a child process (3 steps + its check): %.1f ms, frac %.3f"
+    % (c2["device_resident"]["device_ms"], c2["device_resident"]["value"], c2["transform_end_to_end"]["float64"]["ms_per_call"],
+       c2["transform_end_to_end"]["float32"]["ms_per_call"], c5["ms_per_step"], c5["roofline"]["frac"]))
+gen["ledger2"] = "`roofline.frac` %.4f in the tracked run" % rl["frac"]
+b = "profiles/%s_bench.json" % rnd
+b5 = "profiles/%s_bench_config5.json" % rnd
+rows = [(b, "value", "%.2f" % j["value"]), (b, "ms_per_step", "%.4f" % j["ms_per_step"]), (b, "roofline.frac", "%.4f" % rl["frac"]),
+        (b, "roofline.kernel_ms", "%.4f" % rl["kernel_ms"]), (b, "roofline.kernels.k_synthi.ms", "%.4f" % rl["kernels"]["k_synthi"]["ms"]),
+        (b, "roofline.kernels.k_synth7.ms", "%.4f" % rl["kernels"]["k_synth7"]["ms"]), (b, "roofline.traffic", "%d" % rl["traffic"]),
+        (b, "stages_ms.fwd_fft_ms", "%.4f" % st["fwd_fft_ms"]), (b, "other_modes.complex.ms_per_step", "%.4f" % cx["ms_per_step"]),
+        (b, "other_modes.complex.value", "%.2f" % cx["value"]),
+        (b, "other_configs.config2.device_resident.device_ms", "%.4f" % c2["device_resident"]["device_ms"]),
+        (b, "other_configs.config5.ms_per_step", "%.4f" % c5["ms_per_step"]),
+        (b, "other_configs.config5.roofline.frac", "%.4f" % c5["roofline"]["frac"]), (b, "cpu_baseline.value", "%.4f" % j["cpu_baseline"]["value"]),
+        (b5, "ms_per_step", "%.4f" % j5["ms_per_step"]), (b5, "value", "%.2f" % j5["value"]), (b5, "roofline.frac", "%.4f" % j5["roofline"]["frac"]),
+        ("profiles/traffic.json", "k_synth_hbm_bytes_per_launch", "%d" % tr["k_synth_hbm_bytes_per_launch"])]
+path = os.path.join(root, "DESIGN.md")
+s = open(path).read()
+for name, text in gen.items():
+    pat = re.compile(r"(<!-- gen:%s -->).*?(<!-- /gen -->)" % re.escape(name), re.S)
+    assert pat.search(s), "DESIGN.md has no generated fragment " + name
+    s = pat.sub(lambda m: m.group(1) + text + m.group(2), s)
+blk = re.compile(r"(<!-- tracked-numbers %s:[^>]*-->\s*```\n).*?(```)" % rnd, re.S)
+assert blk.search(s)
+s = blk.sub(lambda m: m.group(1) + "\n".join(" | ".join(r) for r in rows) + "\n" + m.group(2), s)
+open(path, "w").write(s)
+print("DESIGN.md: %d fragments and %d tracked numbers rewritten from profiles/%s_*" % (len(gen), len(rows), rnd))
