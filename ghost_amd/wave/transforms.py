@@ -60,6 +60,9 @@ class ContinuousWaveletTransform(WaveletTransform):
         Parameters are those of ghost/wave/transforms.py:59-107: ``timestamps``,
         ``fs``, ``freq_limits``, ``freqs``, ``voices_per_octave``, ``parallel``
         (validated, then ignored: the GPU does all scales at once), ``verbose``.
+        Beyond the reference: ``multichannel``, ``output`` ('amplitude', 'power', 'complex'), ``dtype``,
+        ``device`` and ``precision`` ('high', the default: the forward FFT in float64 like the reference's
+        arithmetic, transforms.py:142-143; 'fast': float32 throughout).
         """
         if multichannel is None:
             multichannel = False
@@ -84,7 +87,7 @@ class ContinuousWaveletTransform(WaveletTransform):
 
     def _run(self, data, *, squeeze, timestamps=None, fs=None, freq_limits=None, freqs=None,
              voices_per_octave=None, parallel=None, verbose=None, output=None, dtype=None,
-             device=None, **kwargs):
+             device=None, precision=None, **kwargs):
         self.fs = fs                        # validates (transforms.py:109)
         self._time = timestamps
 
@@ -146,14 +149,17 @@ class ContinuousWaveletTransform(WaveletTransform):
         self._wavelet.fs = self._fs                            # transforms.py:179
 
         from ..engine import CwtPlan   # needs the built library; no CPU fallback
+        if precision not in (None, "high", "fast"):
+            raise ValueError("'precision' must be 'high' (default: the reference's float64 dynamic range in "
+                             "front of the float32 synthesis) or 'fast' (float32 throughout)")
         key = (n_samples, n_channels, float(self._fs), f.tobytes(), float(self._wavelet.gamma),
-               float(self._wavelet.beta), epoch_bounds.tobytes(), output, int(device))
+               float(self._wavelet.beta), epoch_bounds.tobytes(), output, int(device), precision)
         if self._plan is None or self._plan_key != key:
             if self._plan is not None:
                 self._plan.close()
             self._plan = CwtPlan(n_samples, n_channels, self._fs, f, gamma=self._wavelet.gamma,
                                  beta=self._wavelet.beta, epoch_bounds=epoch_bounds,
-                                 output=output, device=device)
+                                 output=output, device=device, precision=precision)
             self._plan_key = key
         self._plan.set_profiling(bool(verbose))
         start_time = time.time()

@@ -193,3 +193,22 @@ def test_lowest_frequency_the_reference_permits_at_30_khz():
         print("2^24: %.4f Hz: %.2e" % (f[sc], e))
         assert e < TOL
     p4.close()
+
+
+def test_public_call_on_a_steep_spectrum():
+    """`ContinuousWaveletTransform.transform()` as a user of the reference calls it, on a 1/f^3 recording with an
+    offset: the float64 `amplitude` against the oracle over the grid the call builds itself (time-domain scales at the
+    top included); `precision='fast'` is accepted, and anything else is a ValueError before any work."""
+    from ghost_amd.synthetic import power_law_noise
+    from ghost_amd.wave import ContinuousWaveletTransform
+    fs, n = 1000.0, 200000
+    x = (power_law_noise(n, 3.0, 17) + 12.5).astype(np.float32)
+    cwt = ContinuousWaveletTransform()
+    cwt.transform(x, fs=fs, freq_limits=[2, 380], voices_per_octave=4)
+    f = cwt.frequencies
+    ref = orc.cwt_amplitude(x.astype(np.float64), fs, f, n_threads=8)
+    assert cwt.amplitude.dtype == np.float64 and rel_err(cwt.amplitude, ref).max() < 2e-6
+    cwt.transform(x, fs=fs, freq_limits=[2, 380], voices_per_octave=4, precision="fast")
+    assert rel_err(cwt.amplitude, ref).max() > 5e-6            # the float32 front end: what the default avoids
+    with pytest.raises(ValueError):
+        cwt.transform(x, fs=fs, precision="double")
