@@ -207,8 +207,11 @@ def test_public_call_on_a_steep_spectrum():
     cwt.transform(x, fs=fs, freq_limits=[2, 380], voices_per_octave=4)
     f = cwt.frequencies
     ref = orc.cwt_amplitude(x.astype(np.float64), fs, f, n_threads=8)
-    assert cwt.amplitude.dtype == np.float64 and rel_err(cwt.amplitude, ref).max() < 2e-6
+    e_high = rel_err(cwt.amplitude, ref).max()
+    assert cwt.amplitude.dtype == np.float64 and e_high < 2e-6
     cwt.transform(x, fs=fs, freq_limits=[2, 380], voices_per_octave=4, precision="fast")
-    assert rel_err(cwt.amplitude, ref).max() > 5e-6            # the float32 front end: what the default avoids
+    e_fast = rel_err(cwt.amplitude, ref).max()
+    print("public call, 1/f^3 + offset: high %.2e fast %.2e" % (e_high, e_fast))
+    assert e_fast > 3 * e_high                                 # the float32 front end: what the default avoids
     with pytest.raises(ValueError):
         cwt.transform(x, fs=fs, precision="double")
