@@ -215,3 +215,22 @@ def test_public_call_on_a_steep_spectrum():
     assert e_fast > 3 * e_high                                 # the float32 front end: what the default avoids
     with pytest.raises(ValueError):
         cwt.transform(x, fs=fs, precision="double")
+
+
+def test_steep_spectrum_goldens_from_the_reference(golden):
+    """G14: the reference's own numbers (not the oracle's) on 1/f^3 + offset, 1/f^2 and LFP + 60 Hz at 30 x:
+    complex coefficients of the inner loop and the public call's amplitude."""
+    g = golden("g14_steep.npz")
+    fs, f, cols = float(g["fs"]), g["frequencies"], g["cols"]
+    for name in g["names"]:
+        x = g["x_" + str(name)]
+        c, _ = _run(x, fs, f, "complex")
+        err = np.abs(c[:, cols] - g["complex_cols_" + str(name)]).max(axis=1) / g["rowmax_" + str(name)]
+        print("G14 %s: %.2e" % (name, err.max()))
+        assert err.max() < TOL, (name, err)
+    from ghost_amd.wave import ContinuousWaveletTransform
+    cwt = ContinuousWaveletTransform()
+    cwt.transform(g["x_f3_offset"], fs=fs, freq_limits=[9, 200], voices_per_octave=4)
+    np.testing.assert_allclose(cwt.frequencies, g["api_frequencies_f3_offset"], rtol=1e-14)
+    want = g["api_amplitude_cols_f3_offset"]
+    assert (np.abs(cwt.amplitude[:, cols] - want).max(axis=1) / want.max(axis=1)).max() < TOL
