@@ -19,7 +19,7 @@ const char* const kSelect[] = {"synth16", "synth_cols", "fuse_blocks", "slow_fft
                                "batch_bytes", "stage_floats"};
 // accuracy-changing or measurement hooks: libghostcwt_measure.so only
 const char* const kMeasureOnly[] = {"halo_margin", "interp_q", "interp_min_r", "prune_inputs", "clock_phases",
-                                    "synth_kernel", "synth_drop_stores", "clock_probe"};
+                                    "synth_kernel", "synth_drop_stores", "clock_probe", "synthi_pad_kb"};
 // the two budgets the product library also takes from the environment
 const char* const kEnvBudgets[] = {"batch_bytes", "stage_floats"};
 

@@ -30,6 +30,7 @@
 
 #include "interp.h"
 #include "kernels.h"
+#include "options.h"
 #include "synth_math.h"
 
 #ifndef GCWT_STORE_AUX
@@ -370,10 +371,19 @@ hipError_t launch_synthi(int mode, const SynthiArgs& a, int n_items, int n_chann
   }
   if ((a.channels_fastest ? n_items : n_channels) > 65535) return hipErrorInvalidValue;
   const dim3 grid = a.channels_fastest ? dim3(n_channels, n_items) : dim3(n_items, n_channels), block(kThreadsI);
+  // measure build only (option synthi_pad_kb): unused LDS on top of the kernel's own, i.e. fewer workgroups per CU --
+  // how the launch time goes with occupancy (profiles/r04_store_study.md 5)
+  int lds = kLdsBytes;
+  if (kMeasureBuild && option_is_set("synthi_pad_kb")) {
+    lds += 1024 * (int)option_or("synthi_pad_kb", 0);
+    hipError_t e = hipFuncSetAttribute((const void*)k_synthi<GCWT_OUT_AMPLITUDE_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_synthi<GCWT_OUT_POWER_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+  }
   if (mode == GCWT_OUT_AMPLITUDE_F32)
-    hipLaunchKernelGGL((k_synthi<GCWT_OUT_AMPLITUDE_F32>), grid, block, kLdsBytes, st, a);
+    hipLaunchKernelGGL((k_synthi<GCWT_OUT_AMPLITUDE_F32>), grid, block, lds, st, a);
   else
-    hipLaunchKernelGGL((k_synthi<GCWT_OUT_POWER_F32>), grid, block, kLdsBytes, st, a);
+    hipLaunchKernelGGL((k_synthi<GCWT_OUT_POWER_F32>), grid, block, lds, st, a);
   return hipGetLastError();
 }
 

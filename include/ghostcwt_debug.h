@@ -21,7 +21,7 @@ enum {
  * "interp_grid", "interp_lgnb", "synth_streams", "merge_levels", "split_levels" (all compute the same
  * rows; the tests compare them) and the budgets "batch_bytes", "stage_floats".  Options that change
  * accuracy or exist for measurements ("halo_margin", "interp_q", "interp_min_r", "prune_inputs",
- * "clock_phases", "synth_kernel", "synth_drop_stores", "clock_probe") are refused with
+ * "clock_phases", "synth_kernel", "synth_drop_stores", "clock_probe", "synthi_pad_kb") are refused with
  * GCWT_ERR_UNSUPPORTED by the product library: libghostcwt_measure.so takes them.  clear != 0 returns
  * the option to its default.  Process-wide; not part of the drop-in surface. */
 int gcwt_debug_set_option(const char* name, int64_t value, int clear);
