@@ -747,6 +747,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       sin.x_off[nb] = m.start;
       sin.n_valid[nb] = m.ne;
       sin.n_lead[nb] = m.lead;
+      sin.ramp_lo[nb] = m.ramp_lo;
+      sin.ramp_hi[nb] = m.ramp_hi;
       sout.seg_col[nb] = m.start - r0;
       sout.w_lo[nb] = w_lo;
       sout.w_hi[nb] = w_hi;

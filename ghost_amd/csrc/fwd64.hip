@@ -109,6 +109,17 @@ __device__ __forceinline__ cd d_phase(const cd* __restrict__ tw_hi, const cd* __
   return dmul(tw_hi[m >> 12], tw_lo[m & 4095]);
 }
 
+// weight of segment sample n: 1, except on the faded edges of a time block (kernels.h: SegIn::ramp_lo / ramp_hi;
+// planner.h: EpochPlan::ramp_*): the C2 "smootherstep" 10 t^3 - 15 t^4 + 6 t^5 over the ramp
+__device__ __forceinline__ double seg_weight(int n, int n_valid, int ramp_lo, int ramp_hi) {
+  double t;
+  if (n < ramp_lo) t = (double)n / (double)ramp_lo;
+  else if (n >= n_valid - ramp_hi) t = (double)(n_valid - n) / (double)ramp_hi;
+  else return 1.0;
+  t = fmax(t, 0.0);
+  return t * t * t * (10.0 + t * (6.0 * t - 15.0));
+}
+
 __device__ __forceinline__ void d_fill_twl(cd* twl, const cd* __restrict__ tw_hi, int tid) {
   twl[tid] = tw_hi[((((tid & 15) * (tid >> 4)) & 255)) << 4];            // W256^(-t j) at [j][t]
 }
@@ -137,6 +148,7 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
   // (segment-local sample indices are below P <= 2^24: 32-bit arithmetic, a third of the kernel's instructions
   // were 64-bit clamps and compares)
   const int n_valid = (int)segs.n_valid[g], n_lead = (int)segs.n_lead[g];
+  const int ramp_lo = (int)segs.ramp_lo[g], ramp_hi = (int)segs.ramp_hi[g];
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
   const double mean = sums[ch] * inv_n;      // transforms.py:142-143: float64 copy minus the global mean
   const int s = tid & 15, t = tid >> 4;
@@ -160,8 +172,8 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int n = (t + 16 * j) * ld + col0 + 2 * s;
-      v[j] = make_double2(n >= n_lead && n < n_valid ? (double)ra[j] - mean : 0.0,
-                          n + 1 >= n_lead && n + 1 < n_valid ? (double)rb[j] - mean : 0.0);
+      v[j] = make_double2(n >= n_lead && n < n_valid ? ((double)ra[j] - mean) * seg_weight(n, n_valid, ramp_lo, ramp_hi) : 0.0,
+                          n + 1 >= n_lead && n + 1 < n_valid ? ((double)rb[j] - mean) * seg_weight(n + 1, n_valid, ramp_lo, ramp_hi) : 0.0);
     }
     if (it + 1 < n_tiles) fetch(col0 + 32);          // in flight during this tile's transform
     d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
@@ -214,6 +226,7 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
   d_fill_twl(twl, tw_hi, tid);
   const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
   const int n_valid = (int)segs.n_valid[g], n_lead = (int)segs.n_lead[g];      // below P <= 2^24
+  const int ramp_lo = (int)segs.ramp_lo[g], ramp_hi = (int)segs.ramp_hi[g];
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
   const double mean = sums[ch] * inv_n;
   const int top = n_valid > 0 ? n_valid - 1 : 0;
@@ -224,8 +237,8 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
     for (int j = 0; j < 16; ++j) {
       const int na = ((q * (t + 16 * j) + 2 * p) * ld + col0 + s) * in_stride + in_offset, nb = na + ld * in_stride;
       const float xa = x[min(max(na, n_lead), top)], xb = x[min(max(nb, n_lead), top)];   // clamped
-      v[j] = make_double2(na >= n_lead && na < n_valid ? (double)xa - mean : 0.0,
-                          nb >= n_lead && nb < n_valid ? (double)xb - mean : 0.0);
+      v[j] = make_double2(na >= n_lead && na < n_valid ? ((double)xa - mean) * seg_weight(na, n_valid, ramp_lo, ramp_hi) : 0.0,
+                          nb >= n_lead && nb < n_valid ? ((double)xb - mean) * seg_weight(nb, n_valid, ramp_lo, ramp_hi) : 0.0);
     }
     __syncthreads();                      // twiddle table written / previous exchange read
     d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
@@ -283,12 +296,13 @@ __global__ void __launch_bounds__(256) k_fwd64_cols_small(const float* __restric
   const int c = blockIdx.y, col0 = blockIdx.x * 16, total = len * 16;
   const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
   const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
+  const int ramp_lo = (int)segs.ramp_lo[g], ramp_hi = (int)segs.ramp_hi[g];
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
   const double mean = sums[ch] * inv_n;
   for (int e = threadIdx.x; e < total; e += 256) {
     const int i = e >> 4, cc = e & 15;
     const int64_t n = (int64_t)i * ld + col0 + cc;
-    buf[e] = make_double2(n >= n_lead && n < n_valid ? (double)x[n] - mean : 0.0, 0.0);
+    buf[e] = make_double2(n >= n_lead && n < n_valid ? ((double)x[n] - mean) * seg_weight((int)n, (int)n_valid, ramp_lo, ramp_hi) : 0.0, 0.0);
   }
   __syncthreads();
   const int half_total = 16 * (len >> 1);

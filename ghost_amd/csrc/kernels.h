@@ -53,6 +53,9 @@ struct SegIn {                       // forward column pass: where the segment's
   int64_t x_off[kSegBatch];          // offset of segment sample 0 inside a channel's row
   int64_t n_valid[kSegBatch];        // segment-local samples [n_lead, n_valid) exist, the
   int64_t n_lead[kSegBatch];         //   rest read as zero
+  // precision = high, time blocks of a long epoch: the block's own edges (not the epoch's) are faded over ramp_lo /
+  // ramp_hi samples beyond the halo its outputs reach (planner.h: EpochPlan::ramp_*); 0: a hard edge
+  int64_t ramp_lo[kSegBatch], ramp_hi[kSegBatch];
   int32_t n_channels, pad;
 };
 struct SegOut {                      // synthesis: where the segment's results go

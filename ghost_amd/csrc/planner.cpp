@@ -400,6 +400,12 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
   cache.emplace(std::move(key), std::move(d));
 }
 
+// samples over which a time block's own edges fade out beyond the halo (precision = high): a quarter of the halo, i.e.
+// an eighth of the longest kernel -- (2 pi / (theta T))^3 of a hard cut's leakage at theta: 1e-10 at the top of config
+// 5's grid, 0.2 at its lowest scale, whose band holds most of a steep recording's power anyway; config 5 keeps its five
+// blocks of 2^22 samples per 18e6 (half the halo would make it six)
+static int64_t block_ramp(int64_t halo_s) { return (halo_s / 4 + 63) & ~(int64_t)63; }
+
 static int64_t next_pow2(int64_t v) {
   int64_t p = 1;
   while (p < v) p <<= 1;
@@ -495,8 +501,9 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     int64_t lmax0 = 1;
     for (const ScalePlan& sp : hp->scales)
       if (sp.method != GCWT_SCALE_DIRECT) lmax0 = std::max(lmax0, sp.length);
+    const int64_t halo0 = lmax0 / 2 + 2, ramp0 = hp->high_precision ? block_ramp(halo0) : 0;
     while (hp->max_fft_log2 < kMaxFftLog2 &&
-           ((((int64_t)1 << hp->max_fft_log2) - 2 * (lmax0 / 2 + 2) - 64) & ~(int64_t)63) < ((int64_t)1 << hp->max_fft_log2) / 4)
+           ((((int64_t)1 << hp->max_fft_log2) - 2 * halo0 - 2 * ramp0 - 64) & ~(int64_t)63) < ((int64_t)1 << hp->max_fft_log2) / 4)
       ++hp->max_fft_log2;
   }
   const int64_t pmax = (int64_t)1 << hp->max_fft_log2;
@@ -662,9 +669,12 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   int64_t pmin = INT64_MAX;
   for (int e = 0; e < n_ep; ++e) {
     const int64_t e0 = hp->bounds[2 * e], e1 = hp->bounds[2 * e + 1];
-    auto add = [&](int64_t in0, int64_t in1, int64_t c0, int64_t c1, int64_t p) {
+    auto add = [&](int64_t in0, int64_t in1, int64_t c0, int64_t c1, int64_t p, int64_t unit0 = -1, int64_t unit1 = -1) {
       EpochPlan ep;
       ep.start = in0 & ~(int64_t)63;            // aligned; samples before the epoch read as zero
+      // [unit0, unit1): where the block's input keeps its full weight (time blocks with ramps); the rest fades out
+      if (unit0 > in0) ep.ramp_lo = unit0 - ep.start;
+      if (unit1 >= 0 && unit1 < in1) ep.ramp_hi = in1 - unit1;
       ep.lead = std::max<int64_t>(0, e0 - ep.start);
       ep.stop = in1; ep.ne = in1 - ep.start;
       ep.core0 = c0; ep.core1 = c1; ep.epoch = e;
@@ -685,13 +695,17 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     // time blocks: every output sample needs the input within (L-1)/2 of it; block
     // boundaries sit on multiples of 64 samples of the recording
     const int64_t halo_s = lmax_spec / 2 + 2;
-    const int64_t core_len = (pmax - 2 * halo_s - 64) & ~(int64_t)63;
+    const int64_t ramp = hp->high_precision ? block_ramp(halo_s) : 0;       // EpochPlan::ramp_lo / ramp_hi
+    const int64_t core_len = (pmax - 2 * halo_s - 2 * ramp - 64) & ~(int64_t)63;
     if (core_len < pmax / 4)
       return fail(GCWT_ERR_UNSUPPORTED,
                   "longest wavelet is too long for time blocks of 2^max_fft_log2 samples");
     for (int64_t c0 = e0; c0 < e1;) {
       const int64_t c1 = std::min(e1, (c0 + core_len) & ~(int64_t)63);
-      add(std::max(e0, c0 - halo_s), std::min(e1, c1 + halo_s), c0, c1, pmax);
+      // a side that would reach past the epoch's own end stops there: that edge is the recording's, and stays hard
+      const int64_t u0 = c0 - halo_s, u1 = c1 + halo_s;
+      const int64_t in0 = u0 - ramp > e0 ? u0 - ramp : e0, in1 = u1 + ramp < e1 ? u1 + ramp : e1;
+      add(in0, in1, c0, c1, pmax, in0 > e0 ? u0 : -1, in1 < e1 ? u1 : -1);
       c0 = c1;
     }
   }

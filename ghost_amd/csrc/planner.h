@@ -99,6 +99,13 @@ struct EpochPlan {
   int64_t start = 0, stop = 0, ne = 0;
   int64_t core0 = 0, core1 = 0;
   int64_t lead = 0;                // leading samples of the segment that lie before the epoch (zero)
+  // Time blocks, precision = high: a block cut out of a long epoch ends where the recording does not, and a hard cut
+  // leaks whatever the recording carries at low frequencies into every bin of the block's spectrum (1/k) -- exact
+  // arithmetic cancels it in the block's core, the float32 level and block stages do not: 2.9e-4 on a 1/f^3 recording
+  // at config 5's geometry (round 4).  The block's input is therefore extended beyond the halo its outputs reach by a
+  // ramp on each side that is not an edge of the epoch, and faded to zero there (C2 "smootherstep"): ramp_lo / ramp_hi
+  // segment samples at its start / end carry the weight; the core's outputs never see them.
+  int64_t ramp_lo = 0, ramp_hi = 0;
   int epoch = 0;
   int64_t p = 0;                   // FFT length of this epoch
   int p1 = 0;                      // p_store = p1 * kRowLen rows of the stored spectrum

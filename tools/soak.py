@@ -21,26 +21,6 @@ for case in range(n_cases):
     if os.environ.get("SOAK_BIG"):             # long recordings too: FFT lengths up to 2^22, time blocks
         sizes += [400000, 1100000, 2500000]
     n = int(rng.choice(sizes))
-    x = rng.standard_normal((n_ch, n)) * rng.uniform(0.1, 50)
-    # round 4: half of the cases are recordings with steep spectra, mains interference or drift (white noise is the
-    # easy case for float32 transforms: ghost_amd/synthetic.py: SPECTRUM_CLASSES), kept inside the measured envelope
-    # (profiles/r04_dynamic_range.md: below the bands D ~ 1000, inside a level's band D ~ 65; a narrow scale holds
-    # 0.05 - 0.3 of a white recording's std, so the line is 1 - 3 x and the drift 10 - 40 x the std; SOAK_WILD=1: 10 x those)
-    kind = "white"
-    wild = 10.0 if os.environ.get("SOAK_WILD") else 1.0
-    if rng.random() < 0.5 and n >= 500:
-        kind = str(rng.choice(["brown", "f3", "line", "drift"]))
-        t = np.arange(n) / fs
-        for c in range(n_ch):
-            if kind in ("brown", "f3"):
-                spec = np.fft.rfft(x[c])
-                k = np.maximum(np.arange(spec.size, dtype=np.float64), 1.0)
-                x[c] = np.fft.irfft(spec / k ** (1.0 if kind == "brown" else 1.5), n=n)
-            elif kind == "line":
-                x[c] += wild * rng.uniform(1, 3) * x[c].std() * np.sin(2 * np.pi * rng.uniform(0.01, 0.4) * fs * t + c)
-            else:
-                x[c] += wild * rng.uniform(10, 40) * x[c].std() * np.sin(2 * np.pi * rng.uniform(0.1, 3.0) * t / (n / fs) + c)
-    x = (x + rng.uniform(-100, 100, (n_ch, 1)) * x.std()).astype(np.float32)
     k = int(rng.integers(0, 7))
     cuts = np.sort(rng.choice(np.arange(1, n), size=min(n - 1, k), replace=False)) if n > 8 else np.array([], int)
     edges = [0, *cuts.tolist(), n]
@@ -59,6 +39,29 @@ for case in range(n_cases):
         gamma = float(rng.choice([1.0, 2.0, 3.0, 4.0, 6.0]))
         beta = float(np.round(np.exp(rng.uniform(np.log(1.5), np.log(80.0))), 1))
         kw.update(gamma=gamma, beta=beta)
+    x = rng.standard_normal((n_ch, n)) * rng.uniform(0.1, 50)
+    # round 4: half of the cases are recordings with steep spectra, mains interference or drift (white noise is the
+    # easy case for float32 transforms: ghost_amd/synthetic.py: SPECTRUM_CLASSES), kept inside the measured envelope
+    # (profiles/r04_dynamic_range.md: below the bands D ~ 1000, inside a level's band D ~ 65; a narrow scale holds
+    # 0.05 - 0.3 of a white recording's std, so the line is 1 - 3 x and the drift 10 - 40 x the std; SOAK_WILD=1: 10 x those)
+    kind = "white"
+    # wavelets other than the default one mostly get no low cut (their kernels answer above 2e-8 down to zero frequency):
+    # float32's envelope, so their backgrounds are pink .. 1/f^1.5 instead of 1/f^2 .. 1/f^3
+    tilt = 1.0 if (gamma, beta) == (3.0, 20.0) else 0.5
+    wild = 10.0 if os.environ.get("SOAK_WILD") else 1.0
+    if rng.random() < 0.5 and n >= 500:
+        kind = str(rng.choice(["brown", "f3", "line", "drift"]))
+        t = np.arange(n) / fs
+        for c in range(n_ch):
+            if kind in ("brown", "f3"):
+                spec = np.fft.rfft(x[c])
+                kk = np.maximum(np.arange(spec.size, dtype=np.float64), 1.0)
+                x[c] = np.fft.irfft(spec / kk ** ((1.0 if kind == "brown" else 1.5) * tilt), n=n)
+            elif kind == "line":
+                x[c] += wild * rng.uniform(1, 3) * x[c].std() * np.sin(2 * np.pi * rng.uniform(0.01, 0.4) * fs * t + c)
+            else:
+                x[c] += wild * rng.uniform(10, 40) * x[c].std() * np.sin(2 * np.pi * rng.uniform(0.1, 3.0) * t / (n / fs) + c)
+    x = (x + rng.uniform(-100, 100, (n_ch, 1)) * x.std()).astype(np.float32)
     if rng.random() < 0.35:
         kw["max_fft_log2"] = int(rng.choice([12, 13, 14, 16] + ([20, 21, 22] if os.environ.get("SOAK_BIG") else [])))
     try:
