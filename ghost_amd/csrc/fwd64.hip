@@ -110,11 +110,27 @@ __device__ __forceinline__ cd d_phase(const cd* __restrict__ tw_hi, const cd* __
 }
 
 // weight of segment sample n: 1, except on the faded edges of a time block (kernels.h: SegIn::ramp_lo / ramp_hi;
-// planner.h: EpochPlan::ramp_*): the C2 "smootherstep" 10 t^3 - 15 t^4 + 6 t^5 over the ramp
-__device__ __forceinline__ double seg_weight(int n, int n_valid, int ramp_lo, int ramp_hi) {
+// planner.h: EpochPlan::ramp_*): the C2 "smootherstep" 10 t^3 - 15 t^4 + 6 t^5 over the ramp.  The ramps are a per cent
+// of a block: callers test `seg_in_ramp` for the whole wave first (one vote) and only then pay for the weights --
+// evaluated for every sample the polynomial made the 2^22-point pass 42 % slower.
+struct SegRamp {
+  int lo, hi_start, n_valid;      // samples [0, lo) and [hi_start, n_valid) are faded
+  double inv_lo, inv_hi;
+};
+__device__ __forceinline__ SegRamp seg_ramp(const SegIn& segs, int g) {
+  SegRamp r;
+  r.lo = (int)segs.ramp_lo[g];
+  r.n_valid = (int)segs.n_valid[g];
+  r.hi_start = r.n_valid - (int)segs.ramp_hi[g];
+  r.inv_lo = r.lo > 0 ? 1.0 / (double)r.lo : 0.0;
+  r.inv_hi = segs.ramp_hi[g] > 0 ? 1.0 / (double)segs.ramp_hi[g] : 0.0;
+  return r;
+}
+__device__ __forceinline__ bool seg_in_ramp(const SegRamp& r, int n) { return n < r.lo || n >= r.hi_start; }
+__device__ __forceinline__ double seg_weight(const SegRamp& r, int n) {
   double t;
-  if (n < ramp_lo) t = (double)n / (double)ramp_lo;
-  else if (n >= n_valid - ramp_hi) t = (double)(n_valid - n) / (double)ramp_hi;
+  if (n < r.lo) t = (double)n * r.inv_lo;
+  else if (n >= r.hi_start) t = (double)(r.n_valid - n) * r.inv_hi;
   else return 1.0;
   t = fmax(t, 0.0);
   return t * t * t * (10.0 + t * (6.0 * t - 15.0));
@@ -148,7 +164,7 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
   // (segment-local sample indices are below P <= 2^24: 32-bit arithmetic, a third of the kernel's instructions
   // were 64-bit clamps and compares)
   const int n_valid = (int)segs.n_valid[g], n_lead = (int)segs.n_lead[g];
-  const int ramp_lo = (int)segs.ramp_lo[g], ramp_hi = (int)segs.ramp_hi[g];
+  const SegRamp ramp = seg_ramp(segs, g);
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
   const double mean = sums[ch] * inv_n;      // transforms.py:142-143: float64 copy minus the global mean
   const int s = tid & 15, t = tid >> 4;
@@ -172,8 +188,10 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int n = (t + 16 * j) * ld + col0 + 2 * s;
-      v[j] = make_double2(n >= n_lead && n < n_valid ? ((double)ra[j] - mean) * seg_weight(n, n_valid, ramp_lo, ramp_hi) : 0.0,
-                          n + 1 >= n_lead && n + 1 < n_valid ? ((double)rb[j] - mean) * seg_weight(n + 1, n_valid, ramp_lo, ramp_hi) : 0.0);
+      v[j] = make_double2(n >= n_lead && n < n_valid ? (double)ra[j] - mean : 0.0,
+                          n + 1 >= n_lead && n + 1 < n_valid ? (double)rb[j] - mean : 0.0);
+      if (__any(seg_in_ramp(ramp, n) || seg_in_ramp(ramp, n + 1)))      // wave-uniform: the ramps are rare
+        v[j] = make_double2(v[j].x * seg_weight(ramp, n), v[j].y * seg_weight(ramp, n + 1));
     }
     if (it + 1 < n_tiles) fetch(col0 + 32);          // in flight during this tile's transform
     d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
@@ -226,7 +244,7 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
   d_fill_twl(twl, tw_hi, tid);
   const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
   const int n_valid = (int)segs.n_valid[g], n_lead = (int)segs.n_lead[g];      // below P <= 2^24
-  const int ramp_lo = (int)segs.ramp_lo[g], ramp_hi = (int)segs.ramp_hi[g];
+  const SegRamp ramp = seg_ramp(segs, g);
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
   const double mean = sums[ch] * inv_n;
   const int top = n_valid > 0 ? n_valid - 1 : 0;
@@ -237,8 +255,16 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
     for (int j = 0; j < 16; ++j) {
       const int na = ((q * (t + 16 * j) + 2 * p) * ld + col0 + s) * in_stride + in_offset, nb = na + ld * in_stride;
       const float xa = x[min(max(na, n_lead), top)], xb = x[min(max(nb, n_lead), top)];   // clamped
-      v[j] = make_double2(na >= n_lead && na < n_valid ? ((double)xa - mean) * seg_weight(na, n_valid, ramp_lo, ramp_hi) : 0.0,
-                          nb >= n_lead && nb < n_valid ? ((double)xb - mean) * seg_weight(nb, n_valid, ramp_lo, ramp_hi) : 0.0);
+      v[j] = make_double2(na >= n_lead && na < n_valid ? (double)xa - mean : 0.0,
+                          nb >= n_lead && nb < n_valid ? (double)xb - mean : 0.0);
+    }
+    // the faded edges of a time block, after every load has been used (a branch between the loads would stop the
+    // compiler from issuing them together: +40 % on this one-wave-per-SIMD kernel): wave-uniform per row, rare
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int na = ((q * (t + 16 * j) + 2 * p) * ld + col0 + s) * in_stride + in_offset, nb = na + ld * in_stride;
+      if (__any(seg_in_ramp(ramp, na) || seg_in_ramp(ramp, nb)))
+        v[j] = make_double2(v[j].x * seg_weight(ramp, na), v[j].y * seg_weight(ramp, nb));
     }
     __syncthreads();                      // twiddle table written / previous exchange read
     d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
@@ -296,13 +322,13 @@ __global__ void __launch_bounds__(256) k_fwd64_cols_small(const float* __restric
   const int c = blockIdx.y, col0 = blockIdx.x * 16, total = len * 16;
   const int g = c / segs.n_channels, ch = c - g * segs.n_channels;
   const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
-  const int ramp_lo = (int)segs.ramp_lo[g], ramp_hi = (int)segs.ramp_hi[g];
+  const SegRamp ramp = seg_ramp(segs, g);
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
   const double mean = sums[ch] * inv_n;
   for (int e = threadIdx.x; e < total; e += 256) {
     const int i = e >> 4, cc = e & 15;
     const int64_t n = (int64_t)i * ld + col0 + cc;
-    buf[e] = make_double2(n >= n_lead && n < n_valid ? ((double)x[n] - mean) * seg_weight((int)n, (int)n_valid, ramp_lo, ramp_hi) : 0.0, 0.0);
+    buf[e] = make_double2(n >= n_lead && n < n_valid ? ((double)x[n] - mean) * seg_weight(ramp, (int)n) : 0.0, 0.0);
   }
   __syncthreads();
   const int half_total = 16 * (len >> 1);
