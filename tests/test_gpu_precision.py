@@ -234,3 +234,27 @@ def test_steep_spectrum_goldens_from_the_reference(golden):
     np.testing.assert_allclose(cwt.frequencies, g["api_frequencies_f3_offset"], rtol=1e-14)
     want = g["api_amplitude_cols_f3_offset"]
     assert (np.abs(cwt.amplitude[:, cols] - want).max(axis=1) / want.max(axis=1)).max() < TOL
+
+
+def test_time_blocks_on_a_steep_spectrum():
+    """A time block cut out of a long epoch ends where the recording does not: a hard cut leaks the recording's low
+    frequencies into every bin of the block's spectrum, exact arithmetic cancels it in the block's core, float32 level
+    and block stages do not (round 4's soak: 1.85e-5 on this layout).  A block's own edges are faded out beyond the
+    halo (planner.h: EpochPlan::ramp_*): 1/f^3 with an offset, six forced blocks of 2^16 samples, kernels of up to
+    35 750 taps -- more than half a block -- whole rows against the oracle; and the seams are where they were."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import power_law_noise
+    fs, n = 200.0, 150000
+    f = np.array([0.3731629600443409, 0.07811499331930137])
+    x = (power_law_noise(n, 3.0, 23) * 4.0 - 55.0).astype(np.float32)
+    p = CwtPlan(n, 1, fs, f, output="complex", max_fft_log2=16)
+    segs = p.segments()
+    assert len(segs) >= 5 and segs[0][0] == 0 and segs[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(segs[:-1], segs[1:]))
+    got = p.execute(x[None])[0]
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f)
+    err = rel_err(got, ref)
+    print("1/f^3, %d blocks of 2^16: %s" % (len(segs), err))
+    assert err.max() < 0.5 * TOL
+    # and a recording with a flat spectrum is unchanged by the faded edges: the streamed blocks equal the whole call
+    assert np.array_equal(p.execute_block(x[None], segs[2][0] - 1000, 5000)[0], got[:, segs[2][0] - 1000:segs[2][0] + 4000])
