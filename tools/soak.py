@@ -21,6 +21,9 @@ for case in range(n_cases):
     if os.environ.get("SOAK_BIG"):             # long recordings too: FFT lengths up to 2^22, time blocks
         sizes += [400000, 1100000, 2500000]
     n = int(rng.choice(sizes))
+    long_mode = bool(os.environ.get("SOAK_LONG"))    # kernels of millions of taps: FFT lengths 2^23 / 2^24 (long mode)
+    if long_mode:
+        fs, n_ch, n = 30000.0, 1, int(rng.choice([5000000, 9000000, 14000000]))
     k = int(rng.integers(0, 7))
     cuts = np.sort(rng.choice(np.arange(1, n), size=min(n - 1, k), replace=False)) if n > 8 else np.array([], int)
     edges = [0, *cuts.tolist(), n]
@@ -32,10 +35,14 @@ for case in range(n_cases):
     hi = 0.47 * fs
     ns = int(rng.integers(1, 9))
     f = np.sort(np.exp(rng.uniform(np.log(lo), np.log(hi), ns)))[::-1] if lo < hi else np.array([0.4 * fs])
+    if long_mode:                                     # one epoch, a scale near the reference's floor, the rest at R >= 8
+        eb = [[0, n]]
+        floor_hz = float(orc.rad_to_hz(orc.morse_freq_bounds(n)[0], fs))
+        f = np.sort(np.concatenate([[floor_hz * rng.uniform(1.001, 1.3)], np.exp(rng.uniform(np.log(0.5), np.log(900.0), 2))]))[::-1]
     output = ["complex", "amplitude", "power"][int(rng.integers(0, 3))]
     kw = dict(epoch_bounds=eb, output=output)
     gamma, beta = 3.0, 20.0
-    if rng.random() < 0.5:       # other Morse wavelets: light tails (fast path) and heavy ones
+    if rng.random() < 0.5 and not long_mode:       # other Morse wavelets: light tails (fast path) and heavy ones
         gamma = float(rng.choice([1.0, 2.0, 3.0, 4.0, 6.0]))
         beta = float(np.round(np.exp(rng.uniform(np.log(1.5), np.log(80.0))), 1))
         kw.update(gamma=gamma, beta=beta)
@@ -62,8 +69,10 @@ for case in range(n_cases):
             else:
                 x[c] += wild * rng.uniform(10, 40) * x[c].std() * np.sin(2 * np.pi * rng.uniform(0.1, 3.0) * t / (n / fs) + c)
     x = (x + rng.uniform(-100, 100, (n_ch, 1)) * x.std()).astype(np.float32)
-    if rng.random() < 0.35:
+    if rng.random() < 0.35 and not long_mode:
         kw["max_fft_log2"] = int(rng.choice([12, 13, 14, 16] + ([20, 21, 22] if os.environ.get("SOAK_BIG") else [])))
+    if long_mode and rng.random() < 0.5:
+        kw["max_fft_log2"] = 24
     try:
         p = CwtPlan(n, n_ch, fs, f, **kw)
     except Exception as e:
