@@ -1,8 +1,10 @@
 """Stage times of BASELINE config 5 per GPU (48 ch x 18e6 @ 30 kHz x 200 scales, streamed) as
 bench.py --config 5 runs it, without the checks: C5_REPS passes, min / median."""
 import sys, os, ctypes; sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
 import numpy as np
 from ghost_amd.engine import CwtPlan, DeviceBuffer
+from _opts import apply_env_options; apply_env_options()
 from ghost_amd.synthetic import lfp
 fs, N, S = 30000.0, int(os.environ.get("C5_N", "18000000")), 200
 C, group = int(os.environ.get("C5_C", "48")), int(os.environ.get("C5_GROUP", "24"))

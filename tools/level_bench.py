@@ -1,7 +1,9 @@
 """Synthesis throughput per decimation level: 16 scales inside one level each."""
 import sys, os; sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
 import numpy as np
 from ghost_amd.engine import CwtPlan, DeviceBuffer
+from _opts import apply_env_options; apply_env_options()
 from ghost_amd.synthetic import lfp
 fs = float(os.environ.get("LB_FS", "1000")); N = int(os.environ.get("LB_N", "1000000")); C = int(os.environ.get("LB_C", "64"))
 x = lfp(2, N, fs); x = np.tile(x, (C // 2 + 1, 1))[:C]

@@ -2,8 +2,10 @@
 workgroup's prologue (block spectra, twiddles) is amortised over a long scale walk.
 LL_S scales (default 96), LL_R levels."""
 import sys, os; sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
 import numpy as np
 from ghost_amd.engine import CwtPlan, DeviceBuffer
+from _opts import apply_env_options; apply_env_options()
 from ghost_amd.synthetic import lfp
 fs = 1000.0; N = 1000000; C = int(os.environ.get("LL_C", "32")); S = int(os.environ.get("LL_S", "96"))
 x = lfp(2, N, fs); x = np.tile(x, (C // 2 + 1, 1))[:C]

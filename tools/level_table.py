@@ -3,8 +3,10 @@ which kernel makes it, ms per launch, GB/s of result rows, and package power / s
 sysfs while the level is run for LT_SECONDS (bench.py's PowerSampler: no HIP call in the thread).
 GHOSTCWT_INTERP=0 gives the FFT-per-sample kernel for every level (A/B on the same box)."""
 import sys, os, time; sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
 import numpy as np
 from ghost_amd.engine import CwtPlan, DeviceBuffer
+from _opts import apply_env_options; apply_env_options()
 from ghost_amd.synthetic import lfp
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench_mod", "bench.py")

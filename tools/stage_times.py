@@ -1,6 +1,8 @@
 import sys, time, os; sys.path.insert(0,'.')
+sys.path.insert(0, 'tools')
 import numpy as np
 from ghost_amd.engine import CwtPlan, DeviceBuffer
+from _opts import apply_env_options; apply_env_options()
 from ghost_amd.synthetic import lfp
 fs=1000.; N=1000000; S=100; C=int(os.environ.get("QB_C","128")); reps=int(os.environ.get("QB_REPS","10"))
 f=np.geomspace(200,2,S)

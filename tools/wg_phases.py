@@ -6,8 +6,10 @@ samples parked in LDS, block spectra exchanged, spectra done, scale loop starts,
 The probe's own waits and atomics slow the kernel (R = 2: 1.4 -> 1.9 ms); read the marks relative to
 each other."""
 import sys, os, ctypes; sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
 import numpy as np
 from ghost_amd.engine import CwtPlan, DeviceBuffer
+from _opts import apply_env_options; apply_env_options()
 from ghost_amd.synthetic import lfp
 from ghost_amd._lib import lib, check
 fs, N, C = 1000.0, 1000000, 128
