@@ -2,8 +2,8 @@
 // plan requests -- layouts, sampling rates, wavelets, epochs, forced time blocks -- under
 // AddressSanitizer and UBSan on the CPU (GPU sanitizers are not available on this pool).
 //   cd ghost_amd/csrc && g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer \
-//     -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I. -I../../include ../../tools/plan_fuzz.cpp planner.cpp \
-//     -o /tmp/plan_fuzz && /tmp/plan_fuzz        (6 000 requests, 11 s; last run: clean)
+//     -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I. -I../../include ../../tools/plan_fuzz.cpp planner.cpp options.cpp \
+//     -o /tmp/plan_fuzz && /tmp/plan_fuzz        (6 000 requests incl. long mode and all precisions, 3 min; round 4: clean)
 #include "planner.h"
 #include <cstdio>
 #include <random>
@@ -17,8 +17,8 @@ int main() {
     const double fss[] = {200.0, 1000.0, 1250.0, 30000.0};
     prm.fs = fss[rng() % 4];
     prm.n_channels = 1 + (int)(rng() % 4);
-    const int64_t ns[] = {17, 500, 4096, 4097, 10000, 33333, 70000, 150000, 1000000, 5000000};
-    prm.n_samples = ns[rng() % 10];
+    const int64_t ns[] = {17, 500, 4096, 4097, 10000, 33333, 70000, 150000, 1000000, 5000000, 18000000};
+    prm.n_samples = ns[rng() % 11];
     { const double gs[] = {1, 2, 3, 4, 6}; prm.gamma = gs[rng() % 5]; }
     prm.beta = 1.5 + (double)(rng() % 800) / 10.0;
     if (rng() % 2) { prm.gamma = 3; prm.beta = 20; }
@@ -39,8 +39,10 @@ int main() {
     if (eb.empty()) { eb = {0, prm.n_samples}; }
     prm.n_epochs = (int)eb.size() / 2; prm.epoch_bounds = eb.data();
     prm.out_mode = (int)(rng() % 3);
-    const int mf[] = {0, 0, 12, 13, 14, 16, 21};
-    prm.max_fft_log2 = mf[rng() % 7];
+    const int mf[] = {0, 0, 12, 13, 14, 16, 21, 23, 24};          // 23 / 24: long mode (round 4)
+    prm.max_fft_log2 = mf[rng() % 9];
+    prm.precision = (int)(rng() % 3);                              // default / fast / high: low cut, ramps, full support
+    if (rng() % 8 == 0) prm.support_tol = 1e-7;
     gcwt::HostPlan hp;
     std::string err;
     const int rc = gcwt::build_host_plan(prm, &hp, &err);
