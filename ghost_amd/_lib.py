@@ -9,14 +9,14 @@ import os
 
 __all__ = ["lib", "GhostCwtError", "check", "Params", "PlanInfo", "Timings", "LIB_PATH",
            "OUT_AMPLITUDE", "OUT_POWER", "OUT_COMPLEX", "X_ON_DEVICE", "OUT_ON_DEVICE", "OUT_F64",
-           "SCALE_SPECTRAL", "SCALE_DIRECT", "SCALE_FULLBAND", "ERR_INVALID", "ERR_UNSUPPORTED", "ERR_NO_DEVICE"]
+           "SCALE_SPECTRAL", "SCALE_DIRECT", "SCALE_FULLBAND", "SCALE_BLOCKCONV", "ERR_INVALID", "ERR_UNSUPPORTED", "ERR_NO_DEVICE"]
 
 LIB_PATH = os.environ.get("GHOSTCWT_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "libghostcwt.so")
 
 OUT_AMPLITUDE, OUT_POWER, OUT_COMPLEX = 0, 1, 2
 X_ON_DEVICE, OUT_ON_DEVICE, REUSE_MEANS, OUT_F64 = 1, 2, 4, 8
-SCALE_SPECTRAL, SCALE_DIRECT, SCALE_FULLBAND = 0, 1, 2
+SCALE_SPECTRAL, SCALE_DIRECT, SCALE_FULLBAND, SCALE_BLOCKCONV = 0, 1, 2, 3
 WAVELET_ENERGY = 0x100
 ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_COMM, ERR_COMM_INCOMPLETE = -1, -2, -3, -4, -5, -6, -7
 COMM_ID_BYTES = 128
@@ -42,14 +42,15 @@ class PlanInfo(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("n_levels", C.c_int32), ("n_spectral", C.c_int32),
                 ("n_direct", C.c_int32), ("block", C.c_int32), ("max_decimation", C.c_int32),
                 ("fft_length", C.c_int64), ("workspace_bytes", C.c_int64),
-                ("out_bytes", C.c_int64), ("n_fullband", C.c_int32), ("n_interp", C.c_int32)]
+                ("out_bytes", C.c_int64), ("n_fullband", C.c_int32), ("n_interp", C.c_int32),
+                ("n_blockconv", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Timings(C.Structure):
     _fields_ = [("mean_ms", C.c_float), ("fwd_fft_ms", C.c_float), ("decimate_ms", C.c_float),
                 ("block_fft_ms", C.c_float), ("synth_ms", C.c_float), ("direct_ms", C.c_float),
                 ("total_ms", C.c_float), ("synth_launches", C.c_int32), ("fullband_ms", C.c_float),
-                ("interp_ms", C.c_float)]
+                ("interp_ms", C.c_float), ("blockconv_ms", C.c_float)]
 
 
 def _load():

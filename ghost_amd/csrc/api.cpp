@@ -77,7 +77,7 @@ struct EpochDev {
 // gcwt_plan_info.workspace_bytes
 constexpr int64_t kFullbandCacheBytes = (int64_t)4 << 30;
 
-enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_FULLBAND, ST_INTERP, ST_COUNT };
+enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_FULLBAND, ST_INTERP, ST_BLOCKCONV, ST_COUNT };
 
 }  // namespace
 
@@ -126,8 +126,9 @@ struct gcwt_plan {
   double* d_amps = nullptr;   // kept spectrum samples A_j of every scale (planner.h: amps)
   float2* d_xs = nullptr;     // [C][xs_stride] shifted slice of the spectrum of the level in hand (levels with a
   int64_t xs_stride = 0;      //   band shift: heavy-tailed wavelets); xs_stride = the largest such level's M
-  float2* d_z = nullptr;      // [C][max_p]   full-band scales: spectrum * response, then its IFFT
-  float2* d_hfull = nullptr;  // [max_p]      full-band response of the scale in hand (when the cache below is full)
+  float2* d_z = nullptr;      // [2][slots][max_p]  full-band scales, two at a time: row-transformed spectrum * response
+  int64_t z_half = 0;         //              elements between the pair's two halves
+  float2* d_hfull = nullptr;  // [2][max_p]   full-band responses of the scales in hand (when the cache below is full)
   // Full-band responses are an O(n_bins P) fp64 evaluation each: computed once per (scale, FFT
   // length) and kept on the device while they fit 4 GiB, reused by every later batch and execute.
   std::map<std::pair<int, int>, float2*> hfull_cache;
@@ -142,6 +143,9 @@ struct gcwt_plan {
   float* d_interp_coef = nullptr;   // interpolator coefficients of the interpolated levels
   BankScale* d_bank_sc = nullptr;
   DirectScale* d_direct_sc = nullptr;
+  float2* d_bc_h = nullptr;       // [n_blockconv][4096]  block convolution: responses, in HostPlan::bc_order
+  int32_t* d_bc_rows = nullptr;   // [n_blockconv]        their output rows
+  float2* d_bc_x = nullptr;       // [bc_chunk_blocks][C][4096]  spectra of the blocks in hand
   std::vector<EpochDev> ep_dev;
   int64_t max_direct_len = 0;
   // staging for host-side callers
@@ -181,7 +185,7 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
   fr(p->d_y); fr(p->d_tw64); fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_xs); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_gain_lv); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_psi_tail); fr(p->d_psi_lit); fr(p->d_tw4096);
-  fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc);
+  fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc); fr(p->d_bc_h); fr(p->d_bc_rows); fr(p->d_bc_x);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
   for (auto& kv : p->hfull_cache) (void)hipFree(kv.second);
@@ -343,8 +347,10 @@ int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info) {
   info->abi_version = GCWT_ABI_VERSION;
   info->n_levels = (int32_t)hp.levels.size();
   info->n_direct = hp.n_direct;
-  info->n_spectral = (int32_t)hp.scales.size() - hp.n_direct - hp.n_fullband;
+  info->n_spectral = (int32_t)hp.scales.size() - hp.n_direct - hp.n_fullband - hp.n_blockconv;
   info->n_fullband = hp.n_fullband;
+  info->n_blockconv = hp.n_blockconv;
+  info->reserved = 0;
   info->n_interp = 0;
   for (const auto& l : hp.levels)
     if (level_kernel(plan, l) == LK_INTERP) info->n_interp += (int32_t)l.scales.size();
@@ -433,7 +439,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   auto bail = [&](int code) { free_dev(p); return code; };
   bool he_sync_tables = false;
 
-  const bool any_fft = hp.n_direct < S;   // spectral or full-band scales: they share X
+  const bool any_fft = hp.n_direct + hp.n_blockconv < S;   // spectral or full-band scales: they share X
   if (any_fft) {
     // one workspace slot per (segment of a batch, channel)
     const int64_t slots = C * hp.max_batch;
@@ -458,8 +464,10 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     // one slice buffer per stream the level passes run on (run_pipeline: three streams)
     if (p->xs_stride > 0 && (rc = dev_alloc(&p->d_xs, (size_t)(3 * slots * p->xs_stride)))) return bail(rc);
     if (hp.n_fullband > 0) {
-      if ((rc = dev_alloc(&p->d_z, (size_t)(slots * hp.max_p)))) return bail(rc);
-      if ((rc = dev_alloc(&p->d_hfull, (size_t)hp.max_p))) return bail(rc);
+      const int pairs = hp.n_fullband > 1 ? 2 : 1;      // two scales share a pass over X
+      p->z_half = slots * hp.max_p;
+      if ((rc = dev_alloc(&p->d_z, (size_t)(pairs * p->z_half)))) return bail(rc);
+      if ((rc = dev_alloc(&p->d_hfull, (size_t)(pairs * hp.max_p)))) return bail(rc);
     }
   }
   if (he_sync_tables && hipStreamSynchronize(p->stream) != hipSuccess)      // the host table went out of scope
@@ -519,6 +527,18 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   }
   if ((rc = upload_vec(&p->d_bank_sc, bsc, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_direct_sc, dsc, p->stream))) return bail(rc);
+  if (hp.n_blockconv > 0) {
+    std::vector<int32_t> rows(hp.bc_order.begin(), hp.bc_order.end());
+    if ((rc = upload_vec(&p->d_bc_rows, rows, p->stream))) return bail(rc);
+    if ((rc = dev_alloc(&p->d_bc_h, (size_t)hp.n_blockconv * kRowLen))) return bail(rc);
+    if ((rc = dev_alloc(&p->d_bc_x, (size_t)(hp.bc_chunk_blocks * C) * kRowLen))) return bail(rc);
+    if (!p->d_tw64) {
+      std::vector<double2> tw(8192);
+      fwd64_fill_tables(tw.data());
+      if ((rc = upload_vec(&p->d_tw64, tw, p->stream))) return bail(rc);
+      HIP_TRY(hipStreamSynchronize(p->stream));       // `tw` goes out of scope
+    }
+  }
 
   std::vector<int32_t> scale_list, scale_aux;
   std::vector<int> scale_off(hp.levels.size());
@@ -674,6 +694,10 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   he = launch_build_direct(p->d_psi, p->d_direct_sc, hp.n_direct, p->max_direct_len, p->d_amps, p->d_psi_tail,
                            p->d_psi_lit, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_direct"));
+  for (int k = 0; k < hp.n_blockconv; ++k) {      // H on the 4096-point grid of a block, over 4096 (exact.hip)
+    he = launch_fullband_filter(p->d_bc_h + (int64_t)k * kRowLen, p->d_bank_sc, hp.bc_order[k], p->d_amps, 1, p->stream);
+    if (he != hipSuccess) return bail(hip_err(he, "blockconv responses"));
+  }
   he = hipStreamSynchronize(p->stream);  // host vectors above go out of scope
   if (he != hipSuccess) return bail(hip_err(he, "plan upload"));
   p->uploaded = true;
@@ -729,7 +753,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     }
   }
 
-  const bool any_fft = hp.n_direct < S;
+  const bool any_fft = hp.n_direct + hp.n_blockconv < S;
   const bool fast_fft = p->fast_fft;
   for (size_t e0 = 0; any_fft && e0 < hp.epochs.size();) {
     // one batch: segments e0 .. e0 + count - 1 share the FFT length and the level grids;
@@ -987,46 +1011,62 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       if (he != hipSuccess) return hip_err(he, "synthesis join");
     }
     if (p->profiling && !hp.levels.empty()) p->last.synth_launches++;
-    // full-band scales: W = IFFT_P(X H_s), one scale at a time for every slot of the batch
-    for (int i = 0; i < S && hp.n_fullband > 0; ++i) {
-      if (hp.scales[i].method != GCWT_SCALE_FULLBAND) continue;
-      const float2* h = nullptr;
+    // full-band scales: W = IFFT_P(X H_s) for every slot of the batch, two scales per pass over X
+    auto response = [&](int i, int scratch, const float2** h_out) -> int {
       const auto cached = p->hfull_cache.find({i, P1});
-      if (cached != p->hfull_cache.end()) {
-        h = cached->second;
-      } else {
-        float2* dst = p->d_hfull;
-        float2* keep = nullptr;
-        const int64_t bytes = (int64_t)sizeof(float2) * P;
-        if (p->hfull_cache_bytes + bytes <= kFullbandCacheBytes) {
-          if (hipMalloc((void**)&keep, (size_t)bytes) == hipSuccess) dst = keep;
-          else (void)hipGetLastError();        // no room: compute into the scratch row as before
-        }
-        {   // the response enters the cache only once its launch has been accepted: a failed launch must not
-            // leave an unfilled buffer behind for later executes to reuse
-          SpanGuard sg_(p, ST_FULLBAND);
-          int rc_ = sg_.rc;
-          if (!rc_) {
-            he = launch_fullband_filter(dst, p->d_bank_sc, i, p->d_amps, P1, st);
-            if (he != hipSuccess) rc_ = hip_err(he, "launch_fullband_filter");
-          }
-          if (!rc_) rc_ = sg_.end();
-          if (rc_) { if (keep) (void)hipFree(keep); return rc_; }
-        }
-        if (keep) {
-          p->hfull_cache[{i, P1}] = keep;
-          p->hfull_cache_bytes += bytes;
-        }
-        h = dst;
+      if (cached != p->hfull_cache.end()) { *h_out = cached->second; return GCWT_OK; }
+      float2* dst = p->d_hfull + (int64_t)scratch * hp.max_p;
+      float2* keep = nullptr;
+      const int64_t bytes = (int64_t)sizeof(float2) * P;
+      if (p->hfull_cache_bytes + bytes <= kFullbandCacheBytes) {
+        if (hipMalloc((void**)&keep, (size_t)bytes) == hipSuccess) dst = keep;
+        else (void)hipGetLastError();        // no room: compute into the scratch row as before
       }
-      RUN(ST_FULLBAND, launch_fullband_mul(p->d_x, h, p->d_z, P, slots, st));
-      // inverse: rows over k2 with the W_P^(k1 n2) twiddle, then columns over k1 -> natural order
-      RUN(ST_FULLBAND, launch_fft_rows(+1, p->d_z, p->d_z, kRowLen, P1, kRowLen, kRowLen, P, P,
-                                       P1 > 1 ? P : 0, p->d_tw4096, p->d_tw256, 1.0f, slots, st));
-      if (P1 > 1)
-        RUN(ST_FULLBAND, launch_fft_cols(+1, false, p->d_z, p->d_z, P1, kRowLen, P, P, 0, p->d_tw4096,
-                                         p->d_tw256, p->d_sums, inv_n, 0, slots, st));
-      RUN(ST_FULLBAND, launch_fullband_store(mode, p->d_z, dout, P, i, S, row_len, sout, nb, st));
+      {   // the response enters the cache only once its launch has been accepted: a failed launch must not
+          // leave an unfilled buffer behind for later executes to reuse
+        SpanGuard sg_(p, ST_FULLBAND);
+        int rc_ = sg_.rc;
+        if (!rc_) {
+          he = launch_fullband_filter(dst, p->d_bank_sc, i, p->d_amps, P1, st);
+          if (he != hipSuccess) rc_ = hip_err(he, "launch_fullband_filter");
+        }
+        if (!rc_) rc_ = sg_.end();
+        if (rc_) { if (keep) (void)hipFree(keep); return rc_; }
+      }
+      if (keep) {
+        p->hfull_cache[{i, P1}] = keep;
+        p->hfull_cache_bytes += bytes;
+      }
+      *h_out = dst;
+      return GCWT_OK;
+    };
+    for (int i = 0; i < S && hp.n_fullband > 0;) {
+      int pair[2], np = 0;
+      for (; i < S && np < 2; ++i)
+        if (hp.scales[i].method == GCWT_SCALE_FULLBAND) pair[np++] = i;
+      if (np == 0) break;
+      const float2* h[2] = {nullptr, nullptr};
+      float2* z[2] = {p->d_z, np > 1 ? p->d_z + p->z_half : nullptr};
+      for (int k = 0; k < np; ++k) {
+        const int rc_ = response(pair[k], k, &h[k]);
+        if (rc_) return rc_;
+      }
+      // inverse: rows over k2 of the products X H with the W_P^(k1 n2) twiddle, then columns over k1 ->
+      // natural order; the usual FFT lengths store from the column pass's registers (3.2 GB of traffic per
+      // scale at the headline shape; product, two passes and a store kernel moved 8)
+      RUN(ST_FULLBAND, launch_fullband_rows(p->d_x, h[0], h[1], z[0], z[1], P1, P, P, p->d_tw4096, p->d_tw256,
+                                            slots, st, (int)option_or("fullband_group", 0)));
+      for (int k = 0; k < np; ++k) {
+        if (fullband_cols_fused(P1)) {
+          RUN(ST_FULLBAND, launch_fullband_cols(mode, z[k], dout, P1, P, p->d_tw4096, p->d_tw256, pair[k], S,
+                                                row_len, sout, slots, st));
+        } else {
+          if (P1 > 1)
+            RUN(ST_FULLBAND, launch_fft_cols(+1, false, z[k], z[k], P1, kRowLen, P, P, 0, p->d_tw4096,
+                                             p->d_tw256, p->d_sums, inv_n, 0, slots, st));
+          RUN(ST_FULLBAND, launch_fullband_store(mode, z[k], dout, P, pair[k], S, row_len, sout, nb, st));
+        }
+      }
     }
   }
   if (hp.n_direct > 0) {
@@ -1053,6 +1093,46 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     }
     int rc_ = flush();
     if (rc_) return rc_;
+  }
+  if (hp.n_blockconv > 0) {
+    // block convolution: per group of scales, per batch of epochs, per chunk of blocks -- the blocks' spectra,
+    // then every scale of the group from them
+    for (const HostPlan::BcGroup& g : hp.bc_groups) {
+      BcBlocks bl{};
+      bl.n_channels = C;
+      bl.hop = g.hop;
+      bl.back = g.back;
+      int ne = 0;
+      auto flush = [&]() -> int {
+        bl.n_epochs = ne;
+        const int total = ne > 0 ? bl.blk_first[ne] : 0;
+        for (int b0 = 0; b0 < total; b0 += (int)hp.bc_chunk_blocks) {
+          const int nblk = (int)std::min<int64_t>(hp.bc_chunk_blocks, total - b0);
+          RUN(ST_BLOCKCONV, launch_bc_forward(dx, p->d_bc_x, bl, b0, nblk, N, p->d_tw64, p->d_sums, inv_n, st));
+          RUN(ST_BLOCKCONV, launch_bc_scales(mode, p->d_bc_x, dout, p->d_bc_h + (int64_t)g.first * kRowLen,
+                                             p->d_bc_rows + g.first, g.count, p->d_tw4096, p->d_tw256, bl, b0, nblk,
+                                             S, r0, row_len, st));
+        }
+        ne = 0;
+        return GCWT_OK;
+      };
+      for (size_t i = 0; i + 1 < hp.bounds.size(); i += 2) {
+        const int64_t e0 = hp.bounds[i], e1 = hp.bounds[i + 1];
+        const int64_t g_lo = std::max(e0, r0), g_hi = std::min(e1, r1);
+        if (g_hi <= g_lo) continue;
+        const int64_t blocks = (g_hi - 1) / g.hop - g_lo / g.hop + 1;
+        if (ne > 0 && (int64_t)bl.blk_first[ne] + blocks > (1 << 30)) { int rc_ = flush(); if (rc_) return rc_; }
+        if (ne == 0) bl.blk_first[0] = 0;
+        bl.epoch_start[ne] = e0;
+        bl.epoch_stop[ne] = e1;
+        bl.g_lo[ne] = g_lo;
+        bl.g_hi[ne] = g_hi;
+        bl.blk_first[ne + 1] = bl.blk_first[ne] + (int32_t)blocks;
+        if (++ne == kSegBatch) { int rc_ = flush(); if (rc_) return rc_; }
+      }
+      int rc_ = flush();
+      if (rc_) return rc_;
+    }
   }
 #undef RUN
   return GCWT_OK;
@@ -1157,6 +1237,7 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
     p->last.interp_ms = acc[ST_INTERP];
     p->last.direct_ms = acc[ST_DIRECT];
     p->last.fullband_ms = acc[ST_FULLBAND];
+    p->last.blockconv_ms = acc[ST_BLOCKCONV];
     p->have_timings = true;
   }
   return GCWT_OK;

@@ -427,6 +427,54 @@ __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, f
 }
 
 // ---------------------------------------------------------------------------
+// Block convolution, forward half (kernels.h: BcBlocks): the 4096-point transform of one block of one channel,
+// pass B's arithmetic on the recording itself -- x - mean in float64, zero outside the epoch -- rounded to
+// float32 per bin like the spectrum of the segment transforms.  grid (blocks, channels), dynamic LDS kFwd64Lds
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bc_forward(const float* __restrict__ x, float2* __restrict__ xb,
+                                                    const BcBlocks bl, int blk0, int64_t n_samples,
+                                                    const cd* __restrict__ tw_hi, const double* __restrict__ sums,
+                                                    double inv_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* const ex_re = reinterpret_cast<double*>(smem);
+  double* const ex_im = ex_re + 16 * kDCol;
+  cd* const buf = reinterpret_cast<cd*>(smem);
+  cd* const twl = reinterpret_cast<cd*>(smem + 2 * kDPlaneBytes);
+  const int tid = threadIdx.x, a = tid & 15, t = tid >> 4, ch = blockIdx.y;
+  const int blk = blk0 + blockIdx.x;
+  int e = 0;
+  while (e + 1 < bl.n_epochs && blk >= bl.blk_first[e + 1]) ++e;
+  const int64_t q = bl.g_lo[e] / bl.hop + (blk - bl.blk_first[e]);
+  const int64_t in0 = q * bl.hop - bl.back, e0 = bl.epoch_start[e], e1 = bl.epoch_stop[e];
+  const float* xc = x + (int64_t)ch * n_samples;
+  const double mean = sums[ch] * inv_n;
+  d_fill_twl(twl, tw_hi, tid);
+  cd v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t n = in0 + 16 * (t + 16 * j) + a;
+    const float xv = xc[min(max(n, e0), e1 - 1)];       // clamped: no branch around the load
+    v[j] = make_double2(n >= e0 && n < e1 ? (double)xv - mean : 0.0, 0.0);
+  }
+  __syncthreads();
+  d_fft256(v, twl + t, ex_re + a * kDCol, ex_im + a * kDCol, t);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int kb = t + 16 * j;
+    buf[dpad(16 * kb + a)] = dmul(v[j], tw_hi[(kb * a) & 4095]);
+  }
+  __syncthreads();
+  cd u[16];
+#pragma unroll
+  for (int aa = 0; aa < 16; ++aa) u[aa] = buf[dpad(16 * tid + aa)];
+  d_dft16(u);
+  float2* o = xb + ((int64_t)blockIdx.x * bl.n_channels + ch) * kRowLenDev;
+#pragma unroll
+  for (int ka = 0; ka < 16; ++ka) o[tid + 256 * ka] = make_float2((float)u[ka].x, (float)u[ka].y);
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 static int ilog2_64(int64_t v) { int l = 0; while (((int64_t)1 << l) < v) ++l; return l; }
@@ -495,6 +543,19 @@ hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fwd64_rows, dim3(n_rows, n_slots), dim3(256), kFwd64Lds, st, y, x, y_cstride, x_cstride,
                      tables, out_len, mirror, comb_a, comb_n, comb_n > 1 ? ilog2_64(p_true) : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_bc_forward(const float* x, float2* xb, const BcBlocks& bl, int blk0, int nblk, int64_t n_samples,
+                             const double2* tables, const double* sums, double inv_n, hipStream_t st) {
+  if (nblk <= 0) return hipSuccess;
+  if (bl.n_epochs < 1 || bl.n_epochs > kSegBatch || bl.hop < 1 || bl.n_channels < 1 || bl.n_channels > 65535 ||
+      blk0 < 0 || blk0 + nblk > bl.blk_first[bl.n_epochs])
+    return hipErrorInvalidValue;
+  hipError_t e = allow_lds(k_bc_forward, kFwd64Lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_bc_forward, dim3(nblk, bl.n_channels), dim3(256), kFwd64Lds, st, x, xb, bl, blk0, n_samples,
+                     tables, sums, inv_n);
   return hipGetLastError();
 }
 

@@ -197,6 +197,14 @@ hipError_t launch_fullband_filter(float2* h, const BankScale* sc, int scale, con
                                   int p1, hipStream_t st);
 hipError_t launch_fullband_mul(const float2* x, const float2* h, float2* z, int64_t p, int n_slots,
                                hipStream_t st);
+// the fused passes: rows of X * H for one or two scales (h1, z1 may be null) (pass 1), columns + crop + |.| + store (pass 2; p1 = 256, 512, 1024)
+hipError_t launch_fullband_rows(const float2* x, const float2* h0, const float2* h1, float2* z0, float2* z1,
+                                int p1, int64_t x_cstride, int64_t z_cstride, const float2* tw4096,
+                                const float2* tw256, int n_slots, hipStream_t st, int group = 0);
+bool fullband_cols_fused(int p1);
+hipError_t launch_fullband_cols(int mode, const float2* z, float* out, int p1, int64_t z_cstride,
+                                const float2* tw4096, const float2* tw256, int scale, int n_scales,
+                                int64_t row_len, const SegOut& seg, int n_slots, hipStream_t st);
 hipError_t launch_fullband_store(int mode, const float2* y, float* out, int64_t p, int scale,
                                  int n_scales, int64_t row_len, const SegOut& seg, int n_segments,
                                  hipStream_t st);
@@ -255,6 +263,27 @@ hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi
                          const DirectScale* sc, int n_direct, const double* sums, double inv_n,
                          int64_t n_samples, int n_scales, const DirectEpochs& eps, int n_epochs,
                          int64_t col0, int64_t row_len, int64_t max_len, const float2* tail, hipStream_t st);
+// Block convolution (overlap-save; blockconv.hip describes the path): the blocks of up to kSegBatch epochs that
+// one launch handles.  Blocks are `hop` samples long and aligned to multiples of `hop` in recording time; block
+// q of an epoch produces samples [q hop, (q + 1) hop) cut to [g_lo, g_hi) from the 4096 recording samples that
+// start at q hop - back (those outside [epoch_start, epoch_stop) read as zero).
+struct BcBlocks {
+  int64_t epoch_start[kSegBatch], epoch_stop[kSegBatch];
+  int64_t g_lo[kSegBatch], g_hi[kSegBatch];     // samples of the recording to produce
+  int32_t blk_first[kSegBatch + 1];             // blocks of epoch e: [blk_first[e], blk_first[e + 1])
+  int32_t n_channels, n_epochs;
+  int32_t hop, back;
+};
+// spectra of the blocks [blk0, blk0 + nblk) of every channel: float64 transform of x - mean, rounded per bin;
+// xb[(blk - blk0) * n_channels + ch][4096]
+hipError_t launch_bc_forward(const float* x, float2* xb, const BcBlocks& bl, int blk0, int nblk,
+                             int64_t n_samples, const double2* tables, const double* sums, double inv_n,
+                             hipStream_t st);
+// every scale of a group from those spectra: h[s][4096] the responses (k_fullband_filter with p1 = 1),
+// rows[s] the output rows
+hipError_t launch_bc_scales(int mode, const float2* xb, float* out, const float2* h, const int32_t* rows,
+                            int n_group_scales, const float2* tw4096, const float2* tw256, const BcBlocks& bl,
+                            int blk0, int nblk, int n_scales, int64_t col0, int64_t row_len, hipStream_t st);
 hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_t p1_stride,
                               int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,
                               int n_channels, hipStream_t st, RowTaper taper = RowTaper());

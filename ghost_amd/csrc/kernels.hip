@@ -788,6 +788,227 @@ __global__ void __launch_bounds__(256, 2) k_fft_colsq(const void* __restrict__ i
   }
 }
 
+// ---- the full-band path's two fused passes (exact.hip describes the path) -------------------------------
+// Pass 1: Z_s = IFFT rows of (X * H_s) for one or two scales: the 4096-point inverse row pass of
+// rows_fast_body<+1, 4> with the product folded into its loads; a row of X is read once for both scales.
+// grid (slots * P1): workgroup id -> (row % group, slot, row / group), so that the workgroups that run together
+// share `group` rows of H (32 KB each, L2) without all of them reading the same offset of 8 MB-strided slots
+__global__ void __launch_bounds__(256, 2) k_fullband_rows(const cf* __restrict__ in, const cf* __restrict__ h0,
+                                                       const cf* __restrict__ h1, cf* __restrict__ z0,
+                                                       cf* __restrict__ z1, int64_t in_cstride,
+                                                       int64_t out_cstride, int64_t tw_n,
+                                                       const cf* __restrict__ tw4096,
+                                                       const cf* __restrict__ tw256, int n_slots, int group) {
+  __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
+  float* const ex_re = reinterpret_cast<float*>(buf);
+  float* const ex_im = ex_re + 16 * kExColD;
+  __shared__ cf twl[256];
+  const int tid = threadIdx.x, a = tid & 15, t = tid >> 4;
+  const int bid = blockIdx.x, per = group * n_slots;
+  const int slot = (bid % per) / group, row = bid % group + group * (bid / per);
+  twl[tid] = tw256[(a * t) & 255];
+  const int64_t at = (int64_t)row * kRowLenDev + 16 * t + a;
+  cf xv[16], v[16];
+  {
+    const cf* xp = in + (int64_t)slot * in_cstride + at;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xv[j] = xp[256 * j];
+  }
+  cf w0 = make_float2(1.f, 0.f), st = w0;
+  if (tw_n > 0) {
+    w0 = unit_phase((int64_t)row * tid, tw_n, 1);
+    st = unit_phase((int64_t)row * 256, tw_n, 1);
+  }
+  for (int sel = 0; sel < 2; ++sel) {
+    const cf* __restrict__ h = sel ? h1 : h0;
+    if (!h) break;
+    cf* __restrict__ o = (sel ? z1 : z0) + (int64_t)slot * out_cstride + (int64_t)row * kRowLenDev;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = cmul(xv[j], h[at + 256 * j]);
+    __syncthreads();                      // twiddle table written / the buffer's last readers done
+    fft256_16t_ldstw<1>(v, twl + t, ex_re + a * kExColD, ex_im + a * kExColD, t);
+    __syncthreads();                      // the element buffer aliases the exchange planes
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int kb = t + 16 * j;
+      buf[pad32(16 * kb + a)] = cmul(v[j], tw4096_at<1>(tw4096, kb * a));
+    }
+    __syncthreads();
+    cf u[16];
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) u[aa] = buf[pad32(16 * tid + aa)];
+    dft_small<1, 16>(u);
+    cf w = w0;
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) {
+      cf val = u[ka];
+      if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
+      o[tid + 256 * ka] = val;
+    }
+  }
+}
+
+// Pass 2 stores what the column transform leaves in registers: sample n = k ld + column of the slot's
+// segment, cropped to the segment's window, as |.|, |.|^2 or the complex value, into the scale's row.
+struct FullbandSink {
+  float* out;                 // the slot's channel, the scale's row, column of segment sample 0
+  int64_t w_lo, w_hi;
+};
+
+__device__ __forceinline__ FullbandSink fullband_sink(float* out, int slot, int scale, int n_scales,
+                                                      int64_t row_len, const SegOut& seg, int elem) {
+  const int g = slot / seg.n_channels, ch = slot - g * seg.n_channels;
+  FullbandSink k;
+  k.out = out + (((int64_t)ch * n_scales + scale) * row_len + seg.seg_col[g]) * elem;
+  k.w_lo = seg.w_lo[g];
+  k.w_hi = seg.w_hi[g];
+  return k;
+}
+
+template <int MODE>
+__device__ __forceinline__ void fullband_put(const FullbandSink& k, int64_t n, cf v) {
+  if (n < k.w_lo || n >= k.w_hi) return;
+  if (MODE == GCWT_OUT_AMPLITUDE_F32) k.out[n] = sqrtf(v.x * v.x + v.y * v.y);
+  else if (MODE == GCWT_OUT_POWER_F32) k.out[n] = v.x * v.x + v.y * v.y;
+  else reinterpret_cast<cf*>(k.out)[n] = v;
+}
+
+// A tile's 16 columns are 64 bytes of an amplitude row: the tile next to it completes the 128-byte line,
+// so neighbouring tiles go to workgroups 8 apart -- the same XCD, i.e. the same L2, a dispatch round apart
+__device__ __forceinline__ int fullband_tile(int bid) { return (bid & ~15) | ((bid & 7) << 1) | ((bid >> 3) & 1); }
+
+// len = 256: k_fft_cols256<+1, false> with the store above.  grid (ld / 16, slots), ld / 16 a multiple of 16
+template <int MODE>
+__global__ void __launch_bounds__(256, 4) k_fullband_cols256(const cf* __restrict__ in, float* __restrict__ out,
+                                                          int ld, int64_t in_cstride,
+                                                          const cf* __restrict__ tw256, int scale,
+                                                          int n_scales, int64_t row_len, const SegOut seg) {
+  __shared__ float ex_re[16 * kExColD];
+  __shared__ float ex_im[16 * kExColD];
+  const int c = blockIdx.y, col0 = fullband_tile(blockIdx.x) * 16, tid = threadIdx.x;
+  const int s = tid & 15, t = tid >> 4;
+  cf tw[16], v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tw[j] = tw256[(t * j) & 255];
+  const cf* x = in + (int64_t)c * in_cstride + col0 + s;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = x[(int64_t)(t + 16 * j) * ld];
+  fft256_16t<1>(v, tw, ex_re + s * kExColD, ex_im + s * kExColD, t);
+  const FullbandSink sink = fullband_sink(out, c, scale, n_scales, row_len, seg, MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) fullband_put<MODE>(sink, (int64_t)(t + 16 * j) * ld + col0 + s, v[j]);
+}
+
+// len = 512, 1024: k_fft_colsq<+1, false, LQ> with the store above
+template <int MODE, int LQ>
+__global__ void __launch_bounds__(256, 2) k_fullband_colsq(const cf* __restrict__ in, float* __restrict__ out,
+                                                        int ld, int64_t in_cstride,
+                                                        const cf* __restrict__ tw4096,
+                                                        const cf* __restrict__ tw256, int scale, int n_scales,
+                                                        int64_t row_len, const SegOut seg) {
+  constexpr int q = 1 << LQ, len = 256 * q;
+  __shared__ float ex_re[16 * kExColD];
+  __shared__ float ex_im[16 * kExColD];
+  const int c = blockIdx.y, col0 = fullband_tile(blockIdx.x) * 16, tid = threadIdx.x;
+  const int s = tid & 15, t = tid >> 4;
+  __shared__ cf twl[256];
+  twl[tid] = tw256[((tid & 15) * (tid >> 4)) & 255];
+  constexpr int kInLds = q == 4 ? 1 : 0, kInReg = q - 1 - kInLds;
+  __shared__ cf park[kInLds ? 16 * 256 : 1];
+  cf v[16], u[kInReg * 16];
+  const cf* x = in + (int64_t)c * in_cstride + col0 + s;
+#pragma unroll
+  for (int a = 0; a < q; ++a) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = x[(int64_t)(q * (t + 16 * j) + a) * ld];
+    __syncthreads();
+    fft256_16t_ldstw<1>(v, twl + t, ex_re + s * kExColD, ex_im + s * kExColD, t);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int kb = t + 16 * j;
+      const cf val = cmul(v[j], tw4096_at<1>(tw4096, a * kb * (kRowLenDev / len)));
+      if (a < kInLds) park[j * 256 + tid] = val;
+      else if (a < q - 1) u[(a < q - 1 ? a - kInLds : 0) * 16 + j] = val;
+      else v[j] = val;
+    }
+  }
+  const FullbandSink sink = fullband_sink(out, c, scale, n_scales, row_len, seg, MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    cf w[q];
+#pragma unroll
+    for (int a = 0; a < q - 1; ++a) w[a] = a < kInLds ? park[j * 256 + tid] : u[(a < kInLds ? 0 : a - kInLds) * 16 + j];
+    w[q - 1] = v[j];
+    dft_small<1, q>(w);
+#pragma unroll
+    for (int ka = 0; ka < q; ++ka)
+      fullband_put<MODE>(sink, (int64_t)(t + 16 * j + 256 * ka) * ld + col0 + s, w[ka]);
+  }
+}
+
+// ---- block convolution, the scales (kernels.h: BcBlocks; fwd64.hip: k_bc_forward makes the block spectra) ----
+// One workgroup per (block, channel): the block's spectrum stays in registers while the group's scales go by --
+// product with the scale's response (32 KB, L2: every workgroup reads the same ones), 4096-point inverse FFT
+// (the arithmetic of k_fullband_rows), and the block's `hop` samples of the scale's row straight from the
+// registers of the last DFT16, 256 consecutive samples per store.  HBM sees the spectrum once and the result.
+// The loop wants 212 registers: two workgroups per CU (at three, 168 registers, it spilt 33 of them and took
+// 57 ms where this takes 37: 128 ch x 1e6 x 83 scales).  grid (blocks * channels)
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb, float* __restrict__ out,
+                                                   const cf* __restrict__ h, const int32_t* __restrict__ rows,
+                                                   int n_group_scales, const cf* __restrict__ tw4096,
+                                                   const cf* __restrict__ tw256, const BcBlocks bl, int blk0,
+                                                   int n_scales, int64_t col0, int64_t row_len) {
+  constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
+  float* const ex_re = reinterpret_cast<float*>(buf);
+  float* const ex_im = ex_re + 16 * kExColD;
+  __shared__ cf twl[256];
+  const int tid = threadIdx.x, a = tid & 15, t = tid >> 4;
+  const int ch = blockIdx.x % bl.n_channels, lb = blockIdx.x / bl.n_channels, blk = blk0 + lb;
+  int e = 0;
+  while (e + 1 < bl.n_epochs && blk >= bl.blk_first[e + 1]) ++e;
+  const int64_t n0 = (bl.g_lo[e] / bl.hop + (blk - bl.blk_first[e])) * bl.hop;
+  const int64_t lo = max(n0, bl.g_lo[e]), hi = min(n0 + bl.hop, bl.g_hi[e]);
+  // sample n of the recording is element n - (n0 - back) of the block: this thread's are tid + 256 ka
+  const int first = (int)(lo - n0) + bl.back - tid, last = (int)(hi - n0) + bl.back - tid;   // first <= 256 ka < last
+  twl[tid] = tw256[(a * t) & 255];
+  const int at = 16 * t + a;
+  cf xv[16], v[16];
+  {
+    const cf* xp = xb + ((int64_t)lb * bl.n_channels + ch) * kRowLenDev + at;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xv[j] = xp[256 * j];
+  }
+  float* const o0 = out + ((int64_t)ch * n_scales * row_len + (n0 - bl.back + tid - col0)) * kElem;
+  for (int s = 0; s < n_group_scales; ++s) {
+    const cf* __restrict__ hs = h + (int64_t)s * kRowLenDev + at;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = cmul(xv[j], hs[256 * j]);
+    __syncthreads();                      // twiddle table written / the buffer's last readers done
+    fft256_16t_ldstw<1>(v, twl + t, ex_re + a * kExColD, ex_im + a * kExColD, t);
+    __syncthreads();                      // the element buffer aliases the exchange planes
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int kb = t + 16 * j;
+      buf[pad32(16 * kb + a)] = cmul(v[j], tw4096_at<1>(tw4096, kb * a));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) v[aa] = buf[pad32(16 * tid + aa)];
+    dft_small<1, 16>(v);
+    float* const o = o0 + (int64_t)rows[s] * row_len * kElem;
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) {
+      if (256 * ka < first || 256 * ka >= last) continue;
+      const cf w = v[ka];
+      if (MODE == GCWT_OUT_AMPLITUDE_F32) o[256 * ka] = sqrtf(w.x * w.x + w.y * w.y);
+      else if (MODE == GCWT_OUT_POWER_F32) o[256 * ka] = w.x * w.x + w.y * w.y;
+      else reinterpret_cast<cf*>(o)[256 * ka] = w;
+    }
+  }
+}
+
 // Forward column pass for REAL input and len = 256 q (q = 2, 4): the q interleaved subsequences of
 // a column are real, so two of them share one FFT256 -- z = x_{2p} + i x_{2p+1}, split again with
 // Z[kb] +- conj(Z[256 - kb]) -- before the W_len^(a kb) twiddles and the DFT_q: half the transforms
@@ -1600,6 +1821,67 @@ hipError_t launch_fft_rows(int sign, const cf* in, cf* out, int len, int64_t n_r
                        in_cstride, out_cstride, tw_n, tw4096, scale, (int)n_rows, taper);
   GCWT_LAUNCH_CHECK();
   return hipSuccess;
+}
+
+hipError_t launch_fullband_rows(const cf* x, const cf* h0, const cf* h1, cf* z0, cf* z1, int p1,
+                                int64_t x_cstride, int64_t z_cstride, const cf* tw4096, const cf* tw256,
+                                int n_slots, hipStream_t st, int group) {
+  if (p1 < 1 || !tw4096 || !tw256 || !h0 || !z0 || (h1 && !z1)) return hipErrorInvalidValue;
+  if ((int64_t)n_slots * p1 > 0x7fffffff) return hipErrorInvalidValue;
+  const int64_t p = (int64_t)p1 * kRowLenDev;
+  if (group < 1 || group > p1 || p1 % group) group = p1 < 32 ? p1 : 32;   // p1 is a power of two
+  hipLaunchKernelGGL(k_fullband_rows, dim3((unsigned)(n_slots * p1)), dim3(256), 0, st, x, h0, h1, z0, z1,
+                     x_cstride, z_cstride, p1 > 1 ? p : 0, tw4096, tw256, n_slots, group);
+  return hipGetLastError();
+}
+
+bool fullband_cols_fused(int p1) { return p1 == 256 || p1 == 512 || p1 == 1024; }
+
+template <int MODE>
+static void launch_fullband_cols_mode(const cf* z, float* out, int p1, int64_t z_cstride, const cf* tw4096,
+                                      const cf* tw256, int scale, int n_scales, int64_t row_len,
+                                      const SegOut& seg, int n_slots, hipStream_t st) {
+  const dim3 grid(kRowLenDev / 16, n_slots), block(256);
+  if (p1 == 256)
+    hipLaunchKernelGGL((k_fullband_cols256<MODE>), grid, block, 0, st, z, out, kRowLenDev, z_cstride, tw256,
+                       scale, n_scales, row_len, seg);
+  else if (p1 == 512)
+    hipLaunchKernelGGL((k_fullband_colsq<MODE, 1>), grid, block, 0, st, z, out, kRowLenDev, z_cstride, tw4096,
+                       tw256, scale, n_scales, row_len, seg);
+  else
+    hipLaunchKernelGGL((k_fullband_colsq<MODE, 2>), grid, block, 0, st, z, out, kRowLenDev, z_cstride, tw4096,
+                       tw256, scale, n_scales, row_len, seg);
+}
+
+hipError_t launch_fullband_cols(int mode, const cf* z, float* out, int p1, int64_t z_cstride, const cf* tw4096,
+                                const cf* tw256, int scale, int n_scales, int64_t row_len, const SegOut& seg,
+                                int n_slots, hipStream_t st) {
+  if (!fullband_cols_fused(p1) || !tw4096 || !tw256) return hipErrorInvalidValue;
+  if (mode == GCWT_OUT_AMPLITUDE_F32)
+    launch_fullband_cols_mode<GCWT_OUT_AMPLITUDE_F32>(z, out, p1, z_cstride, tw4096, tw256, scale, n_scales, row_len, seg, n_slots, st);
+  else if (mode == GCWT_OUT_POWER_F32)
+    launch_fullband_cols_mode<GCWT_OUT_POWER_F32>(z, out, p1, z_cstride, tw4096, tw256, scale, n_scales, row_len, seg, n_slots, st);
+  else
+    launch_fullband_cols_mode<GCWT_OUT_COMPLEX_C64>(z, out, p1, z_cstride, tw4096, tw256, scale, n_scales, row_len, seg, n_slots, st);
+  return hipGetLastError();
+}
+
+hipError_t launch_bc_scales(int mode, const cf* xb, float* out, const cf* h, const int32_t* rows,
+                            int n_group_scales, const cf* tw4096, const cf* tw256, const BcBlocks& bl, int blk0,
+                            int nblk, int n_scales, int64_t col0, int64_t row_len, hipStream_t st) {
+  if (nblk <= 0 || n_group_scales <= 0) return hipSuccess;
+  if (bl.n_epochs < 1 || bl.n_epochs > kSegBatch || bl.hop < 1 || bl.back < 0 || bl.hop + bl.back > kRowLenDev ||
+      blk0 < 0 || blk0 + nblk > bl.blk_first[bl.n_epochs] || (int64_t)nblk * bl.n_channels > 0x7fffffff)
+    return hipErrorInvalidValue;
+  const dim3 grid((unsigned)(nblk * bl.n_channels)), block(256);
+#define GCWT_BC(M)                                                                                        \
+  hipLaunchKernelGGL((k_bc_scales<M>), grid, block, 0, st, xb, out, h, rows, n_group_scales, tw4096, tw256, \
+                     bl, blk0, n_scales, col0, row_len)
+  if (mode == GCWT_OUT_AMPLITUDE_F32) GCWT_BC(GCWT_OUT_AMPLITUDE_F32);
+  else if (mode == GCWT_OUT_POWER_F32) GCWT_BC(GCWT_OUT_POWER_F32);
+  else GCWT_BC(GCWT_OUT_COMPLEX_C64);
+#undef GCWT_BC
+  return hipGetLastError();
 }
 
 hipError_t launch_block_fft(const cf* xr, cf* xb, int64_t m, int hop, int halo, int blk_lo, int nblk,

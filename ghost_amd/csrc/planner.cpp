@@ -16,6 +16,57 @@ namespace gcwt {
 // Decimated samples a block gives up at each edge beyond the kernel's measured support.  One is
 // structural (a phase r/R of the synthesis looks up to one decimated sample past its block
 // position); the second is slack.  Option halo_margin overrides (measure build only).
+// The three ways to convolve with a kernel no decimated band holds, by its length (planner.h)
+static int exact_method(const HostPlan& hp, int64_t length) {
+  if (length <= hp.direct_max_len) return GCWT_SCALE_DIRECT;
+  if (length <= hp.blockconv_max_len) return GCWT_SCALE_BLOCKCONV;
+  return GCWT_SCALE_FULLBAND;
+}
+static bool uses_segment_fft(int method) { return method == GCWT_SCALE_SPECTRAL || method == GCWT_SCALE_FULLBAND; }
+
+// Block convolution: the scales sorted by kernel length and cut into groups.  A group shares the spectra of its
+// blocks, so its hop is set by its longest kernel -- sample j of a 4096-sample block is good for the scale with
+// `b` taps behind the output sample and `f` ahead of it when b <= j < 4096 - f -- and a block costs one forward
+// transform (float64: about four of the others) plus one inverse per scale: the cut that minimises
+// sum (4 + scales) / hop, by dynamic programming over the sorted list.
+static void plan_blockconv(HostPlan* hp) {
+  std::vector<int>& order = hp->bc_order;
+  hp->n_blockconv = (int)order.size();
+  hp->bc_groups.clear();
+  if (order.empty()) return;
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int x, int y) { return hp->scales[x].length < hp->scales[y].length; });
+  const int n = (int)order.size();
+  for (int k = 0; k < n; ++k) hp->scales[order[k]].blockconv_index = k;
+  // the longest kernel of a run decides both sides: ahead (L - 1) / 2 taps, behind L - 1 - (L - 1) / 2, the latter
+  // rounded up to 64 so that a block's stores start on a 256-byte boundary of the row
+  auto geometry = [&](int last, int* hop, int* back) {
+    const int64_t len = hp->scales[order[last]].length;
+    const int ahead = (int)((len - 1) / 2);
+    *back = (int)(((len - 1 - ahead) + 63) & ~(int64_t)63);
+    *hop = (kRowLen - *back - ahead) & ~63;
+  };
+  const double kForward = 4.0;
+  std::vector<double> best(n + 1, 0.0);
+  std::vector<int> cut(n + 1, 0);
+  for (int end = 1; end <= n; ++end) {
+    int hop, back;
+    geometry(end - 1, &hop, &back);
+    best[end] = 1e300;
+    for (int start = 0; start < end; ++start) {
+      const double c = best[start] + (kForward + (end - start)) / (double)hop;
+      if (c < best[end]) { best[end] = c; cut[end] = start; }
+    }
+  }
+  for (int end = n; end > 0; end = cut[end]) {
+    HostPlan::BcGroup g;
+    g.first = cut[end];
+    g.count = end - cut[end];
+    geometry(end - 1, &g.hop, &g.back);
+    hp->bc_groups.insert(hp->bc_groups.begin(), g);
+  }
+}
+
 static int halo_margin() { return (int)std::max<long long>(0, option_or("halo_margin", 2)); }
 
 double morse_log_gain(double u, double gamma, double beta) {
@@ -437,6 +488,13 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   if (prm.reserved0 != 0) return fail(GCWT_ERR_INVALID, "gcwt_params.reserved0 must be 0 (caller built against an older ghostcwt.h?)");
   if (prm.precision < 0 || prm.precision > 2) return fail(GCWT_ERR_INVALID, "bad precision (0 default, 1 fast, 2 high)");
   hp->high_precision = prm.precision != GCWT_PRECISION_FAST;
+  if (option_or("blockconv", 1) != 0) {
+    hp->direct_max_len = (int)std::min<long long>(kDirectMaxLen, std::max<long long>(0, option_or("direct_max_len", kDirectDefaultLen)));
+    hp->blockconv_max_len = kBlockConvMaxLen;
+  } else {                                  // rounds 1-4: time domain up to 256 taps, full band beyond
+    hp->direct_max_len = kDirectMaxLen;
+    hp->blockconv_max_len = 0;
+  }
   hp->freqs.assign(prm.freqs_hz, prm.freqs_hz + prm.n_freqs);
   hp->out_elem_bytes = prm.out_mode == GCWT_OUT_COMPLEX_C64 ? 8 : 4;
 
@@ -485,7 +543,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     hp->max_bins = std::max(hp->max_bins, (int)sp.n_bins);
     analyse_scale(*hp, &sp, amp.data());
     sp.method = sp.band_ok ? GCWT_SCALE_SPECTRAL
-                           : (sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND);
+                           : exact_method(*hp, sp.length);
   }
 
   // Decimation of every spectral candidate needs the shortest FFT of the plan, which needs
@@ -500,7 +558,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     // reference's compute_freq_bounds permits runs (morse.py:93-106: 0.116 Hz for 18e6 samples at 30 kHz)
     int64_t lmax0 = 1;
     for (const ScalePlan& sp : hp->scales)
-      if (sp.method != GCWT_SCALE_DIRECT) lmax0 = std::max(lmax0, sp.length);
+      if (uses_segment_fft(sp.method)) lmax0 = std::max(lmax0, sp.length);
     const int64_t halo0 = lmax0 / 2 + 2, ramp0 = hp->high_precision ? block_ramp(halo0) : 0;
     while (hp->max_fft_log2 < kMaxFftLog2 &&
            ((((int64_t)1 << hp->max_fft_log2) - 2 * halo0 - 2 * ramp0 - 64) & ~(int64_t)63) < ((int64_t)1 << hp->max_fft_log2) / 4)
@@ -513,7 +571,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   auto longest_fft_kernel = [&]() {
     int64_t l = 1;
     for (const ScalePlan& sp : hp->scales)
-      if (sp.method != GCWT_SCALE_DIRECT) l = std::max(l, sp.length);
+      if (uses_segment_fft(sp.method)) l = std::max(l, sp.length);
     return l;
   };
   for (int round = 0; round < 4; ++round) {
@@ -543,7 +601,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       int halo = std::max((int)std::ceil(sp.support / (double)r) + halo_margin(), 16);
       if (r == 2) halo += halo & 1;   // keeps halo*R a multiple of 4: 16-byte aligned tile runs
       if (B - 2 * halo < 32 || (two_sided && !fits(2))) {   // does not fit the block at the largest decimation it allows
-        sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
+        sp.method = exact_method(*hp, sp.length);
         moved = true;
       }
     }
@@ -579,14 +637,14 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
         ScalePlan& sp = hp->scales[widest];
         changed = true;
         if (r == 2) {
-          sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
+          sp.method = exact_method(*hp, sp.length);
           moved = true;
         } else {
           sp.decimation = r / 2;
           int halo = std::max((int)std::ceil(sp.support / (double)(r / 2)) + halo_margin(), 16);
           if (r / 2 == 2) halo += halo & 1;
           if (B - 2 * halo < 32) {
-            sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
+            sp.method = exact_method(*hp, sp.length);
             moved = true;
           }
         }
@@ -609,7 +667,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       if (!shifted) continue;
       for (size_t n = 256; n < kv.second.size(); ++n) {
         ScalePlan& sp = hp->scales[kv.second[n]];
-        sp.method = sp.length <= kDirectMaxLen ? GCWT_SCALE_DIRECT : GCWT_SCALE_FULLBAND;
+        sp.method = exact_method(*hp, sp.length);
       }
     }
   }
@@ -662,8 +720,11 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       hp->direct_total += ((sp.length + 7 + 7) & ~(int64_t)7) + 8;   // up to 7 zero taps in front, whole groups of 8
     } else if (sp.method == GCWT_SCALE_FULLBAND) {
       sp.fullband_index = hp->n_fullband++;
+    } else if (sp.method == GCWT_SCALE_BLOCKCONV) {
+      hp->bc_order.push_back(i);
     }
   }
+  plan_blockconv(hp);
 
   // segments: one per epoch, or overlapping time blocks when an epoch needs a longer FFT
   int64_t pmin = INT64_MAX;
@@ -846,7 +907,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     EpochPlan& lead = hp->epochs[first];
     int64_t blocks = 0;
     for (size_t l = 0; l < hp->levels.size(); ++l) blocks += (int64_t)lead.lv[l].nblk * B;
-    const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks + (hp->n_fullband > 0 ? lead.p : 0));   // X + x_R (< P) + XB (+ Z), roughly
+    const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks + (hp->n_fullband > 1 ? 2 * lead.p : hp->n_fullband > 0 ? lead.p : 0));   // X + x_R (< P) + XB (+ Z), roughly
     int cap = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, budget / std::max<int64_t>(1, per_slot)));
     cap = (int)std::max<int64_t>(1, std::min<int64_t>(cap, 65535 / C));   // grid.y = segments * channels
     size_t count = 1;
@@ -893,8 +954,17 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     first += count;
   }
 
+  if (hp->n_blockconv > 0) {
+    // block spectra of every channel for as many blocks as 1 GB holds (the launches walk the recording in such
+    // chunks), never more than the finest group needs
+    int min_hop = kRowLen;
+    for (const HostPlan::BcGroup& g : hp->bc_groups) min_hop = std::min(min_hop, g.hop);
+    const int64_t most = prm.n_samples / min_hop + 2 * (int64_t)n_ep + 1;
+    hp->bc_chunk_blocks = std::max<int64_t>(1, std::min<int64_t>(most, ((int64_t)1 << 30) / (8 * kRowLen * C)));
+  }
   hp->workspace_bytes = 8 * C * hp->max_batch * (hp->max_p_store + hp->max_xr + hp->max_xb)   // X, x_R, XB
-                        + (hp->n_fullband > 0 ? 8 * (C * hp->max_batch + 1) * hp->max_p : 0)  // Z, H
+                        + 8 * kRowLen * (C * hp->bc_chunk_blocks + hp->n_blockconv)             // block spectra, responses
+                        + (hp->n_fullband > 0 ? 8 * (hp->n_fullband > 1 ? 2 : 1) * (C * hp->max_batch + 1) * hp->max_p : 0)  // Z, H
                         + 8 * (int64_t)hp->amps.size()
                         + 8 * (int64_t)prm.n_freqs * B                  // bank
                         + 8 * (hp->direct_total + hp->level_twiddle_total + kRowLen + 256)

@@ -25,8 +25,12 @@ constexpr int kMaxBatch = 16;                // segments per launch set (kernels
 constexpr int kMaxTwoPassDecimation = 256;   // above it the level IFFT uses the small-size kernel
 constexpr int kSynthCols = 16;     // columns (block, r) per batch of the 16-column kernel
 constexpr int kSynthWide = 32;      // columns per batch of the production kernel
-constexpr int kDirectMaxLen = 256;  // longest kernel the time-domain path takes (beyond it one FFT
-                                    // convolution per scale is cheaper: ~6.5 us per tap vs ~2 ms per scale at 128 ch x 1e6)
+constexpr int kDirectMaxLen = 256;  // longest kernel the time-domain path can take (k_direct's tile)
+constexpr int kDirectDefaultLen = 48;   // ... and takes by default: ~6.4 us per tap and scale at 128 ch x 1e6, against
+                                        // the block convolution's flat cost per scale
+constexpr int kBlockConvMaxLen = 2560;  // longest kernel of the block convolution: its 4096-sample blocks then still
+                                        // yield 1537 samples each; beyond it the full-band path (one FFT of the
+                                        // whole segment per scale)
 
 struct ScalePlan {
   double freq_hz = 0, omega = 0;   // omega = f / (fs/2) * pi   (transforms.py:408-410)
@@ -38,6 +42,7 @@ struct ScalePlan {
   int direct_index = -1;           // index among direct scales
   int64_t direct_offset = 0;       // offset of psi in the direct-kernel buffer (complex elems)
   int fullband_index = -1;         // index among full-band scales
+  int blockconv_index = -1;        // position in HostPlan::bc_order
   // kept spectrum samples A_j of the reference kernel that are not negligible (1e-18 of
   // the largest): bins bin_lo .. bin_lo + n_bins - 1, values HostPlan::amps[amp_offset ..]
   int32_t bin_lo = 0, n_bins = 0;
@@ -144,6 +149,15 @@ struct HostPlan {
   std::vector<EpochPlan> epochs;   // segments, in time order
   bool halo_static = true;         // every level is `fast`
   int n_direct = 0;
+  int n_blockconv = 0;
+  int direct_max_len = kDirectDefaultLen, blockconv_max_len = kBlockConvMaxLen;   // (options direct_max_len, blockconv)
+  std::vector<int> bc_order;       // block-convolution scales by kernel length
+  struct BcGroup {                 // consecutive entries of bc_order that share one set of block spectra
+    int first = 0, count = 0;
+    int hop = 0, back = 0;         // kernels.h: BcBlocks
+  };
+  std::vector<BcGroup> bc_groups;
+  int64_t bc_chunk_blocks = 0;     // blocks whose spectra the workspace holds at once (all channels)
   int n_fullband = 0;
   int max_bins = 0;                // largest n_bins
   int64_t direct_total = 0;        // complex elements of all direct kernels

@@ -58,8 +58,11 @@ typedef enum {
   GCWT_SCALE_SPECTRAL = 0, /* exact response on a decimated band, block IFFT (fast path) */
   GCWT_SCALE_DIRECT = 1,   /* literal L-tap kernel, time domain: short kernels whose
                               response reaches Nyquist           */
-  GCWT_SCALE_FULLBAND = 2  /* one FFT convolution over the whole band: kernels whose
+  GCWT_SCALE_FULLBAND = 2, /* one FFT convolution over the whole band: kernels whose
                               truncation leaks at every frequency (small beta)   */
+  GCWT_SCALE_BLOCKCONV = 3 /* the same convolution by overlap-save: 4096-sample blocks of
+                              the recording, all scales of a group per block while its
+                              spectrum sits in registers (kernels up to 2560 taps)    */
 } gcwt_scale_method;
 
 enum {
@@ -129,6 +132,8 @@ typedef struct {
   int32_t n_fullband;          /* scales on the full-band path                    */
   int32_t n_interp;            /* of n_spectral: scales made by the interpolating
                                   synthesis (amplitude / power, R >= 16)          */
+  int32_t n_blockconv;         /* scales on the block-convolution path            */
+  int32_t reserved;
 } gcwt_plan_info;
 
 /* Stage timings of the last gcwt_execute on a plan created with profiling on,
@@ -144,6 +149,7 @@ typedef struct {
   int32_t synth_launches;
   float fullband_ms;    /* full-band scales (filter, product, inverse FFT, store) */
   float interp_ms;      /* of synth_ms: the interpolating synthesis kernel        */
+  float blockconv_ms;   /* block-convolution scales (block spectra, scales)        */
 } gcwt_timings;
 
 /* Library / device ------------------------------------------------------- */

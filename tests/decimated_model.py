@@ -106,7 +106,7 @@ def cwt_decimated(x, fs, freqs_hz, epoch_bounds=None, gamma=3.0, beta=20.0, B=25
         xr_cache = {}
         for i, (om, L) in enumerate(zip(omegas, lengths)):
             method = si["method"][i]
-            if method == 1:
+            if method in (1, 3):                     # time domain / block convolution: the literal kernel
                 psi, _ = orc.morse_kernel(L, om, gamma, beta, normalization, order)
                 out[i, start:stop] = orc.overlap_add_convolve(x[start:stop], psi)
                 continue

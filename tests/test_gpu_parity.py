@@ -577,7 +577,7 @@ def test_public_api_grid(golden, tag):
     np.testing.assert_allclose(cwt.amplitude.max(axis=1), g["rowmax_" + tag], rtol=2e-5)
 
 
-def test_fullband_path_long_kernels_epochs_and_blocks():
+def test_fullband_path_long_kernels_epochs_and_blocks(option):
     """The full-band path on its own terms: kernels of thousands of taps (small beta, low
     frequencies), two epochs, several channels, forced time blocks, execute_block."""
     from ghost_amd.engine import CwtPlan
@@ -588,6 +588,7 @@ def test_fullband_path_long_kernels_epochs_and_blocks():
     f = np.array([120.0, 31.0, 7.0, 2.5, 1.2])
     eb = np.array([[100, 30000], [30011, 50000]])
     ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, eb, gamma=3, beta=3) for c in range(2)])
+    option("blockconv", 0)               # (kernels up to 2560 taps go by blocks otherwise: the tests below)
     p = CwtPlan(n, 2, fs, f, gamma=3, beta=3, epoch_bounds=eb, output="complex")
     m = p.scale_info()["method"]
     assert (m == _lib.SCALE_FULLBAND).sum() >= 3 and (m == _lib.SCALE_SPECTRAL).sum() == 0
@@ -601,6 +602,64 @@ def test_fullband_path_long_kernels_epochs_and_blocks():
     assert len(p2.segments()) > 4
     got2 = p2.execute(x)
     assert rel_err(got2, np.abs(ref[:, :4])).max() < TOL
+
+
+def test_blockconv_path_lengths_epochs_modes_and_ranges(option):
+    """The block convolution (kernels.hip: k_bc_scales; fwd64.hip: k_bc_forward): kernels of 60 .. 2400 taps in
+    several groups, three epochs (one shorter than a block, one starting mid-block), the three output modes and
+    execute_block, against the oracle's fastconv with the literal kernels (convolution.py:68-87); and the same
+    plan on the older paths (time domain / one FFT per segment) agrees."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd import _lib
+    fs, n = 1000.0, 60000
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((3, n)) + 0.2 * np.cumsum(rng.standard_normal((3, n)), axis=1) * 0.05 + 40.0).astype(np.float32)
+    f = np.array([300.0, 140.0, 61.0, 33.0, 17.0, 9.0, 4.1, 2.7])
+    eb = np.array([[70, 21000], [21013, 22500], [30000, 59990]])
+    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, eb, gamma=3, beta=3) for c in range(3)])
+    p = CwtPlan(n, 3, fs, f, gamma=3, beta=3, epoch_bounds=eb, output="complex")
+    si = p.scale_info()
+    assert (si["method"] == _lib.SCALE_BLOCKCONV).sum() >= 6 and si["length"].max() > 2000
+    assert p.info["n_blockconv"] == (si["method"] == _lib.SCALE_BLOCKCONV).sum()
+    got = p.execute(x)
+    assert rel_err(got, ref).max() < TOL
+    assert np.all(got[:, :, :70] == 0) and np.all(got[:, :, 21000:21013] == 0) and np.all(got[:, :, 22500:30000] == 0)
+    blk = p.execute_block(x, 20000, 11000)
+    np.testing.assert_array_equal(blk, got[:, :, 20000:31000])
+    for output, want in (("amplitude", np.abs(ref)), ("power", np.abs(ref) ** 2)):
+        q = CwtPlan(n, 3, fs, f, gamma=3, beta=3, epoch_bounds=eb, output=output)
+        assert rel_err(q.execute(x), want).max() < (2 * TOL if output == "power" else TOL), output
+    option("blockconv", 0)
+    old = CwtPlan(n, 3, fs, f, gamma=3, beta=3, epoch_bounds=eb, output="complex")
+    assert old.info["n_blockconv"] == 0
+    assert rel_err(old.execute(x), got).max() < 3e-6
+
+
+@pytest.mark.parametrize("n, p1", [(1000000, 256), (2000003, 512), (4000000, 1024)])
+def test_fullband_fused_passes(n, p1, option):
+    """FFT lengths 2^20 .. 2^22: the full-band path's product rides the inverse row pass and its column pass
+    crops and stores (kernels.hip: k_fullband_rows, k_fullband_cols256 / colsq).  Two epochs in one batch, the
+    three output modes, against the oracle's fastconv of the same scales (convolution.py:68-87)."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd import _lib
+    from ghost_amd.synthetic import lfp
+    option("blockconv", 0)
+    fs = 1000.0
+    x = lfp(2, n, fs, seed=n % 97)
+    f = np.array([9.0, 2.5])
+    cut = n // 3 + 5
+    eb = np.array([[0, cut], [cut + 40, n]]) if p1 == 256 else None
+    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, eb, gamma=3, beta=2) for c in range(2)])
+    for output in ("complex", "amplitude", "power"):
+        p = CwtPlan(n, 2, fs, f, gamma=3, beta=2, epoch_bounds=eb, output=output)
+        assert (p.scale_info()["method"] == _lib.SCALE_FULLBAND).all()
+        assert max(seg[2] for seg in p.segments()) == p1 * 4096
+        got = p.execute(x)
+        want = ref if output == "complex" else np.abs(ref) if output == "amplitude" else np.abs(ref) ** 2
+        assert rel_err(got, want).max() < (2 * TOL if output == "power" else TOL), output
+        if eb is not None:
+            assert np.all(got[:, :, cut:cut + 40] == 0)
+        del p, got
 
 
 def test_headline_workload_is_checked():
@@ -1034,13 +1093,14 @@ def test_split_levels_option(option):
     assert rel_err(got, oracle).max() < TOL
 
 
-def test_time_domain_kernel_every_alignment_and_edge():
+def test_time_domain_kernel_every_alignment_and_edge(option):
     """The time-domain kernel stores a scale's taps behind (7 - (L-1)//2) mod 8 zeros and works
     in groups of 8 taps, two groups per trip (csrc/kernels.hip: k_direct): lengths covering
     every residue and both parities of the group count, kernels up to the longest it takes,
     all output modes, tiles that end inside the range, and block requests whose first column
     is not a multiple of four samples (the store path without 16-byte alignment)."""
     from ghost_amd.engine import CwtPlan
+    option("direct_max_len", 256)                  # (by default kernels beyond 48 taps go by blocks)
     fs, n = 1000.0, 6200                           # three tiles of 2048 outputs + a ragged tail
     rng = np.random.default_rng(77)
     x = (rng.standard_normal((3, n)) + np.array([[0.7], [-2.0], [0.0]])).astype(np.float32)

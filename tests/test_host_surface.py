@@ -443,7 +443,8 @@ def test_planner_measures_each_wavelet():
             assert not si2["theta_neg"][m == _lib.SCALE_SPECTRAL].any() and all(l["band_shift"] == 0 for l in lv)
         elif (gamma, beta) in ((3, 4), (2, 8)):
             spec = m == _lib.SCALE_SPECTRAL
-            assert spec.sum() >= 23 and np.all(m[~spec] == _lib.SCALE_DIRECT) and ln[~spec].max() <= 256
+            assert spec.sum() >= 23 and ln[~spec].max() <= 256
+            assert np.all(m[~spec] == np.where(ln[~spec] <= 48, _lib.SCALE_DIRECT, _lib.SCALE_BLOCKCONV))
             assert np.all(si2["theta_neg"][spec] > 0) and all(l["band_shift"] > 0 for l in lv)
             # the band fits the level: [-theta_neg, theta_hi] inside [-shift, 256 - shift) bins
             for l in lv:
@@ -458,8 +459,10 @@ def test_planner_measures_each_wavelet():
                 assert by_r.setdefault(l["decimation"], l["band_shift"]) == l["band_shift"]
         else:
             assert not (m == _lib.SCALE_SPECTRAL).any(), (gamma, beta)
-            assert np.all(m[ln <= 256] == _lib.SCALE_DIRECT)
-            assert np.all(m[ln > 256] == _lib.SCALE_FULLBAND) and (ln > 256).any()
+            # by kernel length: time domain, overlap-save blocks, one FFT of the whole segment (planner.h)
+            assert np.all(m[ln <= 48] == _lib.SCALE_DIRECT)
+            assert np.all(m[(ln > 48) & (ln <= 2560)] == _lib.SCALE_BLOCKCONV) and (ln > 256).any()
+            assert np.all(m[ln > 2560] == _lib.SCALE_FULLBAND)
     # a looser tolerance is the caller's to ask for
     q = CwtPlan(65536, 1, fs, f2, gamma=2, beta=8, band_eps=1e-5)
     assert (q.scale_info()["method"] == _lib.SCALE_SPECTRAL).sum() >= 30
