@@ -146,6 +146,7 @@ struct gcwt_plan {
   float2* d_bc_h = nullptr;       // [n_blockconv][4096]  block convolution: responses, in HostPlan::bc_order
   int32_t* d_bc_rows = nullptr;   // [n_blockconv]        their output rows
   float2* d_bc_x = nullptr;       // [bc_chunk_blocks][C][4096]  spectra of the blocks in hand
+  float2* d_bc_tw = nullptr;      // [4096]               the middle twiddles in k_bc_scales' order
   std::vector<EpochDev> ep_dev;
   int64_t max_direct_len = 0;
   // staging for host-side callers
@@ -185,7 +186,7 @@ int upload_vec(T** p, const std::vector<T>& v, hipStream_t st) {
 void free_dev(gcwt_plan* p) {
   auto fr = [](auto*& q) { if (q) { (void)hipFree((void*)q); q = nullptr; } };
   fr(p->d_y); fr(p->d_tw64); fr(p->d_x); fr(p->d_xr); fr(p->d_xb); fr(p->d_xs); fr(p->d_probe); fr(p->d_amps); fr(p->d_z); fr(p->d_hfull); fr(p->d_bank); fr(p->d_gain); fr(p->d_gain_lv); fr(p->d_half_tw); fr(p->d_psi); fr(p->d_psi_tail); fr(p->d_psi_lit); fr(p->d_tw4096);
-  fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc); fr(p->d_bc_h); fr(p->d_bc_rows); fr(p->d_bc_x);
+  fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc); fr(p->d_bc_h); fr(p->d_bc_rows); fr(p->d_bc_x); fr(p->d_bc_tw);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
   for (auto& kv : p->hfull_cache) (void)hipFree(kv.second);
@@ -532,6 +533,16 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     if ((rc = upload_vec(&p->d_bc_rows, rows, p->stream))) return bail(rc);
     if ((rc = dev_alloc(&p->d_bc_h, (size_t)hp.n_blockconv * kRowLen))) return bail(rc);
     if ((rc = dev_alloc(&p->d_bc_x, (size_t)(hp.bc_chunk_blocks * C) * kRowLen))) return bail(rc);
+    std::vector<float2> twt(kRowLen);                 // the values k_fullband_rows takes from tw4096, per thread
+    for (int j = 0; j < 16; ++j)
+      for (int tid = 0; tid < 256; ++tid) {
+        const int idx = (((tid >> 4) + 16 * j) * (tid & 15)) & (kRowLen - 1);
+        float2 w = tw4096[idx & 2047];
+        if (idx & 2048) w = make_float2(-w.x, -w.y);
+        twt[256 * j + tid] = make_float2(w.x, -w.y);
+      }
+    if ((rc = upload_vec(&p->d_bc_tw, twt, p->stream))) return bail(rc);
+    HIP_TRY(hipStreamSynchronize(p->stream));         // `twt` goes out of scope
     if (!p->d_tw64) {
       std::vector<double2> tw(8192);
       fwd64_fill_tables(tw.data());
@@ -1110,7 +1121,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
           const int nblk = (int)std::min<int64_t>(hp.bc_chunk_blocks, total - b0);
           RUN(ST_BLOCKCONV, launch_bc_forward(dx, p->d_bc_x, bl, b0, nblk, N, p->d_tw64, p->d_sums, inv_n, st));
           RUN(ST_BLOCKCONV, launch_bc_scales(mode, p->d_bc_x, dout, p->d_bc_h + (int64_t)g.first * kRowLen,
-                                             p->d_bc_rows + g.first, g.count, p->d_tw4096, p->d_tw256, bl, b0, nblk,
+                                             p->d_bc_rows + g.first, g.count, p->d_bc_tw, p->d_tw256, bl, b0, nblk,
                                              S, r0, row_len, st));
         }
         ne = 0;
@@ -1364,6 +1375,21 @@ int gcwt_debug_scale_theta_lo(const gcwt_plan* p, double* theta_lo) {
   if (!p || !theta_lo) return set_err(GCWT_ERR_INVALID, "NULL argument");
   for (size_t i = 0; i < p->hp.scales.size(); ++i) theta_lo[i] = p->hp.scales[i].theta_lo;
   return GCWT_OK;
+}
+
+int gcwt_debug_blockconv_groups(const gcwt_plan* p, int32_t* first, int32_t* count, int32_t* hop, int32_t* back,
+                                int32_t* order, int max_groups) {
+  if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  const HostPlan& hp = p->hp;
+  const int n = (int)hp.bc_groups.size();
+  for (int g = 0; g < n && g < max_groups; ++g) {
+    if (first) first[g] = hp.bc_groups[g].first;
+    if (count) count[g] = hp.bc_groups[g].count;
+    if (hop) hop[g] = hp.bc_groups[g].hop;
+    if (back) back[g] = hp.bc_groups[g].back;
+  }
+  if (order) for (int k = 0; k < hp.n_blockconv; ++k) order[k] = hp.bc_order[k];
+  return n;
 }
 
 int gcwt_debug_interp_level(const gcwt_plan* p, int level, int32_t* q, int32_t* factor, double* alpha,

@@ -427,12 +427,25 @@ __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, f
 }
 
 // ---------------------------------------------------------------------------
-// Block convolution, forward half (kernels.h: BcBlocks): the 4096-point transform of one block of one channel,
+// Block convolution, forward half (kernels.h: BcBlocks): the 4096-point transforms of two blocks of one channel,
 // pass B's arithmetic on the recording itself -- x - mean in float64, zero outside the epoch -- rounded to
-// float32 per bin like the spectrum of the segment transforms.  grid (blocks, channels), dynamic LDS kFwd64Lds
+// float32 per bin like the spectrum of the segment transforms.  The blocks are real: blocks 2 i and 2 i + 1 ride
+// one transform as z = x' + i x'', and X'[k] = (Z[k] + conj Z[-k]) / 2, X''[k] = (Z[k] - conj Z[-k]) / 2i come
+// apart through LDS afterwards.  grid (ceil(blocks / 2), channels), dynamic LDS kFwd64Lds
 // ---------------------------------------------------------------------------
+struct BcWindow { int64_t in0, e0, e1; };
+__device__ __forceinline__ BcWindow bc_window(const BcBlocks& bl, int blk) {
+  int e = 0;
+  while (e + 1 < bl.n_epochs && blk >= bl.blk_first[e + 1]) ++e;
+  BcWindow w;
+  w.in0 = (bl.g_lo[e] / bl.hop + (blk - bl.blk_first[e])) * bl.hop - bl.back;
+  w.e0 = bl.epoch_start[e];
+  w.e1 = bl.epoch_stop[e];
+  return w;
+}
+
 __global__ void __launch_bounds__(256) k_bc_forward(const float* __restrict__ x, float2* __restrict__ xb,
-                                                    const BcBlocks bl, int blk0, int64_t n_samples,
+                                                    const BcBlocks bl, int blk0, int nblk, int64_t n_samples,
                                                     const cd* __restrict__ tw_hi, const double* __restrict__ sums,
                                                     double inv_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -441,20 +454,21 @@ __global__ void __launch_bounds__(256) k_bc_forward(const float* __restrict__ x,
   cd* const buf = reinterpret_cast<cd*>(smem);
   cd* const twl = reinterpret_cast<cd*>(smem + 2 * kDPlaneBytes);
   const int tid = threadIdx.x, a = tid & 15, t = tid >> 4, ch = blockIdx.y;
-  const int blk = blk0 + blockIdx.x;
-  int e = 0;
-  while (e + 1 < bl.n_epochs && blk >= bl.blk_first[e + 1]) ++e;
-  const int64_t q = bl.g_lo[e] / bl.hop + (blk - bl.blk_first[e]);
-  const int64_t in0 = q * bl.hop - bl.back, e0 = bl.epoch_start[e], e1 = bl.epoch_stop[e];
+  const int lb = 2 * blockIdx.x;
+  const bool second = lb + 1 < nblk;
+  const BcWindow w0 = bc_window(bl, blk0 + lb), w1 = bc_window(bl, blk0 + (second ? lb + 1 : lb));
   const float* xc = x + (int64_t)ch * n_samples;
   const double mean = sums[ch] * inv_n;
   d_fill_twl(twl, tw_hi, tid);
   cd v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int64_t n = in0 + 16 * (t + 16 * j) + a;
-    const float xv = xc[min(max(n, e0), e1 - 1)];       // clamped: no branch around the load
-    v[j] = make_double2(n >= e0 && n < e1 ? (double)xv - mean : 0.0, 0.0);
+    const int off = 16 * (t + 16 * j) + a;
+    const int64_t n = w0.in0 + off, m = w1.in0 + off;
+    const float xa = xc[min(max(n, w0.e0), w0.e1 - 1)];       // clamped: no branch around the loads
+    const float xm = xc[min(max(m, w1.e0), w1.e1 - 1)];
+    v[j] = make_double2(n >= w0.e0 && n < w0.e1 ? (double)xa - mean : 0.0,
+                        second && m >= w1.e0 && m < w1.e1 ? (double)xm - mean : 0.0);
   }
   __syncthreads();
   d_fft256(v, twl + t, ex_re + a * kDCol, ex_im + a * kDCol, t);
@@ -469,9 +483,19 @@ __global__ void __launch_bounds__(256) k_bc_forward(const float* __restrict__ x,
 #pragma unroll
   for (int aa = 0; aa < 16; ++aa) u[aa] = buf[dpad(16 * tid + aa)];
   d_dft16(u);
-  float2* o = xb + ((int64_t)blockIdx.x * bl.n_channels + ch) * kRowLenDev;
+  __syncthreads();                        // everyone has read the buffer: Z goes into it in natural order
 #pragma unroll
-  for (int ka = 0; ka < 16; ++ka) o[tid + 256 * ka] = make_float2((float)u[ka].x, (float)u[ka].y);
+  for (int ka = 0; ka < 16; ++ka) buf[tid + 256 * ka] = u[ka];
+  __syncthreads();
+  float2* o0 = xb + ((int64_t)lb * bl.n_channels + ch) * kRowLenDev;
+  float2* o1 = o0 + (int64_t)bl.n_channels * kRowLenDev;
+#pragma unroll
+  for (int ka = 0; ka < 16; ++ka) {
+    const int k = tid + 256 * ka;
+    const cd z = u[ka], zp = buf[(kRowLenDev - k) & (kRowLenDev - 1)];
+    o0[k] = make_float2((float)(0.5 * (z.x + zp.x)), (float)(0.5 * (z.y - zp.y)));
+    if (second) o1[k] = make_float2((float)(0.5 * (z.y + zp.y)), (float)(0.5 * (zp.x - z.x)));
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -554,8 +578,8 @@ hipError_t launch_bc_forward(const float* x, float2* xb, const BcBlocks& bl, int
     return hipErrorInvalidValue;
   hipError_t e = allow_lds(k_bc_forward, kFwd64Lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_bc_forward, dim3(nblk, bl.n_channels), dim3(256), kFwd64Lds, st, x, xb, bl, blk0, n_samples,
-                     tables, sums, inv_n);
+  hipLaunchKernelGGL(k_bc_forward, dim3((nblk + 1) / 2, bl.n_channels), dim3(256), kFwd64Lds, st, x, xb, bl, blk0,
+                     nblk, n_samples, tables, sums, inv_n);
   return hipGetLastError();
 }
 

@@ -280,9 +280,9 @@ hipError_t launch_bc_forward(const float* x, float2* xb, const BcBlocks& bl, int
                              int64_t n_samples, const double2* tables, const double* sums, double inv_n,
                              hipStream_t st);
 // every scale of a group from those spectra: h[s][4096] the responses (k_fullband_filter with p1 = 1),
-// rows[s] the output rows
+// rows[s] the output rows, twt[256 j + 16 t + a] = exp(+2 pi i (t + 16 j) a / 4096)
 hipError_t launch_bc_scales(int mode, const float2* xb, float* out, const float2* h, const int32_t* rows,
-                            int n_group_scales, const float2* tw4096, const float2* tw256, const BcBlocks& bl,
+                            int n_group_scales, const float2* twt, const float2* tw256, const BcBlocks& bl,
                             int blk0, int nblk, int n_scales, int64_t col0, int64_t row_len, hipStream_t st);
 hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_t p1_stride,
                               int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,

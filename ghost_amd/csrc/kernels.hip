@@ -956,9 +956,10 @@ __global__ void __launch_bounds__(256, 2) k_fullband_colsq(const cf* __restrict_
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb, float* __restrict__ out,
                                                    const cf* __restrict__ h, const int32_t* __restrict__ rows,
-                                                   int n_group_scales, const cf* __restrict__ tw4096,
+                                                   int n_group_scales, const cf* __restrict__ twt,
                                                    const cf* __restrict__ tw256, const BcBlocks bl, int blk0,
                                                    int n_scales, int64_t col0, int64_t row_len) {
+  // twt[256 j + tid] = W_4096^(+(t + 16 j) a): the middle twiddles as each thread meets them (coalesced, L2)
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
   float* const ex_re = reinterpret_cast<float*>(buf);
@@ -991,7 +992,7 @@ __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb,
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int kb = t + 16 * j;
-      buf[pad32(16 * kb + a)] = cmul(v[j], tw4096_at<1>(tw4096, kb * a));
+      buf[pad32(16 * kb + a)] = cmul(v[j], twt[256 * j + tid]);
     }
     __syncthreads();
 #pragma unroll
@@ -1002,7 +1003,7 @@ __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb,
     for (int ka = 0; ka < 16; ++ka) {
       if (256 * ka < first || 256 * ka >= last) continue;
       const cf w = v[ka];
-      if (MODE == GCWT_OUT_AMPLITUDE_F32) o[256 * ka] = sqrtf(w.x * w.x + w.y * w.y);
+      if (MODE == GCWT_OUT_AMPLITUDE_F32) o[256 * ka] = __builtin_amdgcn_sqrtf(w.x * w.x + w.y * w.y);
       else if (MODE == GCWT_OUT_POWER_F32) o[256 * ka] = w.x * w.x + w.y * w.y;
       else reinterpret_cast<cf*>(o)[256 * ka] = w;
     }
@@ -1867,7 +1868,7 @@ hipError_t launch_fullband_cols(int mode, const cf* z, float* out, int p1, int64
 }
 
 hipError_t launch_bc_scales(int mode, const cf* xb, float* out, const cf* h, const int32_t* rows,
-                            int n_group_scales, const cf* tw4096, const cf* tw256, const BcBlocks& bl, int blk0,
+                            int n_group_scales, const cf* twt, const cf* tw256, const BcBlocks& bl, int blk0,
                             int nblk, int n_scales, int64_t col0, int64_t row_len, hipStream_t st) {
   if (nblk <= 0 || n_group_scales <= 0) return hipSuccess;
   if (bl.n_epochs < 1 || bl.n_epochs > kSegBatch || bl.hop < 1 || bl.back < 0 || bl.hop + bl.back > kRowLenDev ||
@@ -1875,7 +1876,7 @@ hipError_t launch_bc_scales(int mode, const cf* xb, float* out, const cf* h, con
     return hipErrorInvalidValue;
   const dim3 grid((unsigned)(nblk * bl.n_channels)), block(256);
 #define GCWT_BC(M)                                                                                        \
-  hipLaunchKernelGGL((k_bc_scales<M>), grid, block, 0, st, xb, out, h, rows, n_group_scales, tw4096, tw256, \
+  hipLaunchKernelGGL((k_bc_scales<M>), grid, block, 0, st, xb, out, h, rows, n_group_scales, twt, tw256, \
                      bl, blk0, n_scales, col0, row_len)
   if (mode == GCWT_OUT_AMPLITUDE_F32) GCWT_BC(GCWT_OUT_AMPLITUDE_F32);
   else if (mode == GCWT_OUT_POWER_F32) GCWT_BC(GCWT_OUT_POWER_F32);

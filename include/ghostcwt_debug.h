@@ -37,6 +37,11 @@ int gcwt_debug_level_band_shift(const gcwt_plan* plan, int level, int32_t* shift
  * which its exact response stays under 2e-8 of its peak. */
 int gcwt_debug_level_low_cut(const gcwt_plan* plan, int level, double* theta_cut);
 int gcwt_debug_scale_theta_lo(const gcwt_plan* plan, double* theta_lo);
+/* Block convolution (GCWT_SCALE_BLOCKCONV): the scales in order of kernel length (`order`, n_blockconv entries)
+ * and the groups of consecutive entries that share the spectra of their blocks: blocks of `hop` output
+ * samples from the 4096 recording samples that start `back` before them.  Returns the number of groups. */
+int gcwt_debug_blockconv_groups(const gcwt_plan* plan, int32_t* first, int32_t* count, int32_t* hop,
+                                int32_t* back, int32_t* order, int max_groups);
 /* Segments of equal FFT length are launched together: first segment and size of the batch
  * that `segment` belongs to. */
 int gcwt_debug_batch_of(const gcwt_plan* plan, int segment, int32_t* first, int32_t* count);

@@ -468,6 +468,38 @@ def test_planner_measures_each_wavelet():
     assert (q.scale_info()["method"] == _lib.SCALE_SPECTRAL).sum() >= 30
 
 
+def test_blockconv_planning():
+    """Kernels no decimated band holds, by length: time domain up to 48 taps, overlap-save blocks up to 2560, one
+    FFT per segment beyond (planner.h).  The block scales are grouped by length; every scale of a group is whole
+    inside the group's window: `back` samples before an output sample, hop + ahead <= 4096 - back."""
+    from ghost_amd.engine import CwtPlan
+    f = np.geomspace(200.0, 2.0, 100)
+    p = CwtPlan(1000000, 128, 1000.0, f, gamma=3, beta=2)
+    si, info = p.scale_info(), p.info
+    assert info["n_spectral"] == 0 and info["n_fullband"] == 0 and info["n_blockconv"] + info["n_direct"] == 100
+    groups = p.debug_blockconv()
+    assert 2 <= len(groups) <= 8
+    seen = []
+    for g in groups:
+        ln = si["length"][g["scales"]]
+        assert np.all(np.diff(ln) >= 0) and np.all(si["method"][g["scales"]] == _lib.SCALE_BLOCKCONV)
+        behind, ahead = ln - 1 - (ln - 1) // 2, (ln - 1) // 2
+        assert g["back"] % 64 == 0 and g["hop"] % 64 == 0 and g["hop"] >= 1536
+        assert np.all(behind <= g["back"]) and np.all(g["back"] + g["hop"] + ahead <= 4096)
+        seen += g["scales"]
+    assert sorted(seen) == np.flatnonzero(si["method"] == _lib.SCALE_BLOCKCONV).tolist()
+    assert [len(g["scales"]) for g in groups][0] > [len(g["scales"]) for g in groups][-1]     # short kernels share more
+    # the longest kernels of Morse(3, 5) at this shape stay on the full-band path
+    q = CwtPlan(1000000, 128, 1000.0, f, gamma=3, beta=5)
+    ln, m = q.scale_info()["length"], q.scale_info()["method"]
+    assert ln.max() > 2560 and np.all(m[ln > 2560] == _lib.SCALE_FULLBAND) and np.all(m[(ln > 48) & (ln <= 2560)] == _lib.SCALE_BLOCKCONV)
+    # a recording in 300-sample epochs: a block per epoch would be mostly padding, the time domain keeps its 256 taps
+    eb = np.array([[i * 400, i * 400 + 300] for i in range(500)])
+    r = CwtPlan(200000, 2, 1000.0, np.array([300.0, 100.0, 30.0, 12.0]), gamma=3, beta=2, epoch_bounds=eb)
+    ln, m = r.scale_info()["length"], r.scale_info()["method"]
+    assert np.all(m[ln <= 256] == _lib.SCALE_DIRECT) and (ln > 100).any()
+
+
 def test_decimated_model_for_other_wavelets(golden):
     """Planner decisions + exact bank, float64, against the reference-made G11."""
     from decimated_model import cwt_decimated

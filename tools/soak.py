@@ -93,9 +93,9 @@ for case in range(n_cases):
     same = np.array_equal(blk, got[:, :, a:a + ln])
     si = p.scale_info()
     tol = 2 * TOL if output == "power" else TOL
-    print("case %2d: %-5s fs %7.0f ch %d n %6d ep %d g,b %g,%4g scales %d R<=%5d direct %d full %d segs %3d %-9s err %.2e block %s" %
+    print("case %2d: %-5s fs %7.0f ch %d n %6d ep %d g,b %g,%4g scales %d R<=%5d direct %d blocks %d full %d segs %3d %-9s err %.2e block %s" %
           (case, kind, fs, n_ch, n, len(eb), gamma, beta, f.size, si["decimation"].max(), int((si["method"] == 1).sum()),
-           int((si["method"] == 2).sum()), len(p.segments()), output, err, "ok" if same else "DIFFERS"), flush=True)
+           int((si["method"] == 3).sum()), int((si["method"] == 2).sum()), len(p.segments()), output, err, "ok" if same else "DIFFERS"), flush=True)
     if os.environ.get("SOAK_DETAIL") and err / (tol / TOL) > float(os.environ["SOAK_DETAIL"]):   # per scale: where the error sits
         e_s = (np.abs(got - ref) / scale).max(axis=(0, 2))
         print("   per scale: " + ", ".join("%.4g Hz L %d R %d m %d %.1e" % (f[i], si["length"][i], si["decimation"][i], si["method"][i], e_s[i])

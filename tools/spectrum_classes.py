@@ -1,6 +1,7 @@
 """Parity of the engine on recordings with steep spectra, mains interference and drift (round 4,
 VERDICT r03 task 1): input class x scale -> gate metric max|y - ref| / max|ref| against the oracle.
 Headline scales (100 log-spaced 200..2 Hz) at fs = 1 kHz, N = 1e6; SC_N / SC_OUT override.
+SC_GAMMA / SC_BETA: another Morse wavelet; SC_BLOCKCONV=0: the older exact paths (time domain / one FFT per segment).
 Writes gpurun_out/spectrum_classes.json (copy under profiles/ to track)."""
 import json, os, sys, time; sys.path.insert(0, '.')
 import numpy as np
@@ -14,11 +15,18 @@ f = np.geomspace(200.0, 2.0, 100)
 kw = {}
 if os.environ.get("SC_PRECISION"):
     kw["precision"] = os.environ["SC_PRECISION"]
+okw = {}
+if os.environ.get("SC_GAMMA"):
+    okw = dict(gamma=float(os.environ["SC_GAMMA"]), beta=float(os.environ["SC_BETA"]))
+    kw.update(okw)
+if os.environ.get("SC_BLOCKCONV"):
+    from ghost_amd.engine import set_option
+    set_option("blockconv", int(os.environ["SC_BLOCKCONV"]))
 table = {}
 for name in SPECTRUM_CLASSES:
     x = spectrum_class(name, n, fs)
     t0 = time.time()
-    ref = orc.cwt_complex(x.astype(np.float64), fs, f, n_threads=8)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f, n_threads=8, **okw)
     t1 = time.time()
     row = {}
     for output in ("complex", "amplitude"):
