@@ -962,9 +962,9 @@ __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb,
   // twt[256 j + tid] = W_4096^(+(t + 16 j) a): the middle twiddles as each thread meets them (coalesced, L2)
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
-  float* const ex_re = reinterpret_cast<float*>(buf);
+  float* const ex_re = reinterpret_cast<float*>(buf) + (threadIdx.x & 15) * kExColD;
   float* const ex_im = ex_re + 16 * kExColD;
-  __shared__ cf twl[256];
+  __shared__ v2f twl[256];
   const int tid = threadIdx.x, a = tid & 15, t = tid >> 4;
   const int ch = blockIdx.x % bl.n_channels, lb = blockIdx.x / bl.n_channels, blk = blk0 + lb;
   int e = 0;
@@ -973,39 +973,54 @@ __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb,
   const int64_t lo = max(n0, bl.g_lo[e]), hi = min(n0 + bl.hop, bl.g_hi[e]);
   // sample n of the recording is element n - (n0 - back) of the block: this thread's are tid + 256 ka
   const int first = (int)(lo - n0) + bl.back - tid, last = (int)(hi - n0) + bl.back - tid;   // first <= 256 ka < last
-  twl[tid] = tw256[(a * t) & 255];
-  const int at = 16 * t + a;
-  cf xv[16], v[16];
   {
-    const cf* xp = xb + ((int64_t)lb * bl.n_channels + ch) * kRowLenDev + at;
+    const cf w = tw256[(a * t) & 255];
+    twl[tid] = v2f{w.x, w.y};
+  }
+  const int at = 16 * t + a;
+  v2f xv[16], v[16];
+  {
+    const v2f* xp = reinterpret_cast<const v2f*>(xb) + ((int64_t)lb * bl.n_channels + ch) * kRowLenDev + at;
 #pragma unroll
     for (int j = 0; j < 16; ++j) xv[j] = xp[256 * j];
   }
+  const v2f* const tws = reinterpret_cast<const v2f*>(twt) + tid;
+  v2f* const bufv = reinterpret_cast<v2f*>(buf);
   float* const o0 = out + ((int64_t)ch * n_scales * row_len + (n0 - bl.back + tid - col0)) * kElem;
+  // The three radix-16 layers are synth_math.h's packed idft16v (a multiply by +-i is a register swizzle there:
+  // written with float2 operators the loop spent a quarter of its instructions on moves); it leaves output k in
+  // register dft16_pos(k).
   for (int s = 0; s < n_group_scales; ++s) {
-    const cf* __restrict__ hs = h + (int64_t)s * kRowLenDev + at;
+    const v2f* __restrict__ hs = reinterpret_cast<const v2f*>(h) + (int64_t)s * kRowLenDev + at;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = cmul(xv[j], hs[256 * j]);
+    for (int j = 0; j < 16; ++j) v[j] = cmulv(xv[j], hs[256 * j]);
     __syncthreads();                      // twiddle table written / the buffer's last readers done
-    fft256_16t_ldstw<1>(v, twl + t, ex_re + a * kExColD, ex_im + a * kExColD, t);
-    __syncthreads();                      // the element buffer aliases the exchange planes
+    idft16v(v);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int kb = t + 16 * j;
-      buf[pad32(16 * kb + a)] = cmul(v[j], twt[256 * j + tid]);
+    for (int m2 = 0; m2 < 16; ++m2) {
+      const v2f u = cmulv(v[dft16_pos(m2)], twl[t + 16 * m2]);
+      ex_re[t * kExPitch + m2] = u.x;
+      ex_im[t * kExPitch + m2] = u.y;
     }
     __syncthreads();
 #pragma unroll
-    for (int aa = 0; aa < 16; ++aa) v[aa] = buf[pad32(16 * tid + aa)];
-    dft_small<1, 16>(v);
+    for (int k1 = 0; k1 < 16; ++k1) v[k1] = v2f{ex_re[k1 * kExPitch + t], ex_im[k1 * kExPitch + t]};
+    idft16v(v);
+    __syncthreads();                      // the element buffer aliases the exchange planes
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bufv[pad32(16 * (t + 16 * j) + a)] = cmulv(v[dft16_pos(j)], tws[256 * j]);
+    __syncthreads();
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[pad32(16 * tid + aa)];
+    idft16v(v);
     float* const o = o0 + (int64_t)rows[s] * row_len * kElem;
 #pragma unroll
     for (int ka = 0; ka < 16; ++ka) {
       if (256 * ka < first || 256 * ka >= last) continue;
-      const cf w = v[ka];
+      const v2f w = v[dft16_pos(ka)];
       if (MODE == GCWT_OUT_AMPLITUDE_F32) o[256 * ka] = __builtin_amdgcn_sqrtf(w.x * w.x + w.y * w.y);
       else if (MODE == GCWT_OUT_POWER_F32) o[256 * ka] = w.x * w.x + w.y * w.y;
-      else reinterpret_cast<cf*>(o)[256 * ka] = w;
+      else reinterpret_cast<v2f*>(o)[256 * ka] = w;
     }
   }
 }

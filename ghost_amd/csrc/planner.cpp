@@ -27,17 +27,21 @@ static bool uses_segment_fft(int method) { return method == GCWT_SCALE_SPECTRAL 
 // Block convolution: the scales sorted by kernel length and cut into groups.  A group shares the spectra of its
 // blocks, so its hop is set by its longest kernel -- sample j of a 4096-sample block is good for the scale with
 // `b` taps behind the output sample and `f` ahead of it when b <= j < 4096 - f -- and a block costs one forward
-// transform (float64, two blocks each: about two of the others) plus one inverse per scale: the cut that
-// minimises sum (2 + scales) / hop, by dynamic programming over the sorted list.
-static void plan_blockconv(HostPlan* hp) {
+// transform (float64, two blocks each, its own launch: about two of the others) plus one inverse per scale: the
+// cut that minimises sum (2 + scales) / hop, by dynamic programming over the sorted list.  With `rebalance` the
+// shortest kernels may go back to the time domain where that is cheaper: 39 taps there cost what a scale of a
+// full block of the widest hop does (6.4 us per tap against 0.25 ms per scale: 128 ch x 1e6 on an MI355X), a
+// group of two or three scales does not pay for its spectra, and blocks that epochs fill to `bc_fill` cost the same
+// as full ones.
+static void plan_blockconv(HostPlan* hp, bool rebalance) {
   std::vector<int>& order = hp->bc_order;
-  hp->n_blockconv = (int)order.size();
+  order.clear();
+  for (size_t i = 0; i < hp->scales.size(); ++i)
+    if (hp->scales[i].method == GCWT_SCALE_BLOCKCONV) order.push_back((int)i);
   hp->bc_groups.clear();
-  if (order.empty()) return;
   std::stable_sort(order.begin(), order.end(),
                    [&](int x, int y) { return hp->scales[x].length < hp->scales[y].length; });
   const int n = (int)order.size();
-  for (int k = 0; k < n; ++k) hp->scales[order[k]].blockconv_index = k;
   // the longest kernel of a run decides both sides: ahead (L - 1) / 2 taps, behind L - 1 - (L - 1) / 2, the latter
   // rounded up to 64 so that a block's stores start on a 256-byte boundary of the row
   auto geometry = [&](int last, int* hop, int* back) {
@@ -46,25 +50,38 @@ static void plan_blockconv(HostPlan* hp) {
     *back = (int)(((len - 1 - ahead) + 63) & ~(int64_t)63);
     *hop = (kRowLen - *back - ahead) & ~63;
   };
-  const double kForward = 2.0;
-  std::vector<double> best(n + 1, 0.0);
-  std::vector<int> cut(n + 1, 0);
-  for (int end = 1; end <= n; ++end) {
-    int hop, back;
-    geometry(end - 1, &hop, &back);
-    best[end] = 1e300;
-    for (int start = 0; start < end; ++start) {
-      const double c = best[start] + (kForward + (end - start)) / (double)hop;
-      if (c < best[end]) { best[end] = c; cut[end] = start; }
+  const double kForward = 2.0, kWidestHop = 3712.0, kTapsPerUnit = 39.0;
+  std::vector<double> rest(n + 1, 0.0);        // cheapest grouping of order[start ..), in scales of a full widest block
+  std::vector<int> stop(n + 1, n);
+  for (int start = n - 1; start >= 0; --start) {
+    rest[start] = 1e300;
+    for (int end = start + 1; end <= n; ++end) {
+      int hop, back;
+      geometry(end - 1, &hop, &back);
+      const double c = (kForward + (end - start)) * kWidestHop / (double)hop + rest[end];
+      if (c < rest[start]) { rest[start] = c; stop[start] = end; }
     }
   }
-  for (int end = n; end > 0; end = cut[end]) {
-    HostPlan::BcGroup g;
-    g.first = cut[end];
-    g.count = end - cut[end];
-    geometry(end - 1, &g.hop, &g.back);
-    hp->bc_groups.insert(hp->bc_groups.begin(), g);
+  int first = 0;
+  if (rebalance) {
+    double taps = 0.0, best = rest[0] / hp->bc_fill;
+    for (int k = 1; k <= n && hp->scales[order[k - 1]].length <= kDirectMaxLen; ++k) {
+      taps += (double)hp->scales[order[k - 1]].length;
+      const double c = taps / kTapsPerUnit + rest[k] / hp->bc_fill;
+      if (c < best) { best = c; first = k; }
+    }
+    for (int k = 0; k < first; ++k) hp->scales[order[k]].method = GCWT_SCALE_DIRECT;
   }
+  for (int start = first; start < n; start = stop[start]) {
+    HostPlan::BcGroup g;
+    g.first = start - first;
+    g.count = stop[start] - start;
+    geometry(stop[start] - 1, &g.hop, &g.back);
+    hp->bc_groups.push_back(g);
+  }
+  order.erase(order.begin(), order.begin() + first);
+  hp->n_blockconv = (int)order.size();
+  for (int k = 0; k < hp->n_blockconv; ++k) hp->scales[order[k]].blockconv_index = k;
 }
 
 static int halo_margin() { return (int)std::max<long long>(0, option_or("halo_margin", 2)); }
@@ -510,18 +527,16 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     if (s < 0 || t > prm.n_samples || t <= s)
       return fail(GCWT_ERR_INVALID, "epoch bounds outside the data or empty");
   }
-  if (hp->blockconv_max_len > 0 && option_or("direct_max_len", -1) < 0) {
-    // A block costs the same however little of an epoch it holds (8.3 ns per block, channel and scale on an
-    // MI355X against the time domain's 0.05 ps per tap and sample): recordings cut into epochs much shorter than
-    // a block keep longer kernels in the time domain
+  {
+    // how full the 4096-sample blocks of the block convolution would be: a block costs the same however little
+    // of an epoch it holds (plan_blockconv weighs that against the time domain)
     int64_t blocks = 0, samples = 0;
     for (int e = 0; e < n_ep; ++e) {
       const int64_t len = hp->bounds[2 * e + 1] - hp->bounds[2 * e];
       samples += len;
       blocks += (len + 3711) / 3712;
     }
-    const double even = 166000.0 * (double)blocks / (double)std::max<int64_t>(1, samples);
-    hp->direct_max_len = (int)std::min<double>(kDirectMaxLen, std::max<double>(kDirectDefaultLen, even));
+    hp->bc_fill = (double)samples / (3712.0 * (double)std::max<int64_t>(1, blocks));
   }
 
   const double g = prm.gamma, b = prm.beta;
@@ -724,6 +739,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       }
     }
   }
+  plan_blockconv(hp, option_or("direct_max_len", -1) < 0);
   int64_t lmax_spec = longest_fft_kernel();
   for (int i = 0; i < prm.n_freqs; ++i) {
     ScalePlan& sp = hp->scales[i];
@@ -733,11 +749,8 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       hp->direct_total += ((sp.length + 7 + 7) & ~(int64_t)7) + 8;   // up to 7 zero taps in front, whole groups of 8
     } else if (sp.method == GCWT_SCALE_FULLBAND) {
       sp.fullband_index = hp->n_fullband++;
-    } else if (sp.method == GCWT_SCALE_BLOCKCONV) {
-      hp->bc_order.push_back(i);
     }
   }
-  plan_blockconv(hp);
 
   // segments: one per epoch, or overlapping time blocks when an epoch needs a longer FFT
   int64_t pmin = INT64_MAX;

@@ -157,6 +157,7 @@ struct HostPlan {
     int hop = 0, back = 0;         // kernels.h: BcBlocks
   };
   std::vector<BcGroup> bc_groups;
+  double bc_fill = 1.0;            // share of the block convolution's blocks that epochs fill (widest hop)
   int64_t bc_chunk_blocks = 0;     // blocks whose spectra the workspace holds at once (all channels)
   int n_fullband = 0;
   int max_bins = 0;                // largest n_bins
