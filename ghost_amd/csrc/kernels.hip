@@ -951,8 +951,9 @@ __global__ void __launch_bounds__(256, 2) k_fullband_colsq(const cf* __restrict_
 // product with the scale's response (32 KB, L2: every workgroup reads the same ones), 4096-point inverse FFT
 // (the arithmetic of k_fullband_rows), and the block's `hop` samples of the scale's row straight from the
 // registers of the last DFT16, 256 consecutive samples per store.  HBM sees the spectrum once and the result.
-// The loop wants 212 registers: two workgroups per CU (at three, 168 registers, it spilt 33 of them and took
-// 57 ms where this takes 37: 128 ch x 1e6 x 83 scales).  grid (blocks * channels)
+// 164 registers under a launch bound of two workgroups per CU: three are resident (28 ms for 128 ch x 1e6 x 83
+// scales; bound to three the compiler squeezes the loop into 150 registers and it takes 48, held to two by LDS
+// 33: profiles/r04_heavy_tails.md).  grid (blocks * channels)
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb, float* __restrict__ out,
                                                    const cf* __restrict__ h, const int32_t* __restrict__ rows,
