@@ -258,3 +258,22 @@ def test_time_blocks_on_a_steep_spectrum():
     assert err.max() < 0.5 * TOL
     # and a recording with a flat spectrum is unchanged by the faded edges: the streamed blocks equal the whole call
     assert np.array_equal(p.execute_block(x[None], segs[2][0] - 1000, 5000)[0], got[:, segs[2][0] - 1000:segs[2][0] + 4000])
+
+
+@pytest.mark.parametrize("name", ["brown", "f3", "line100", "drift1000", "f3_offset"])
+def test_block_convolution_on_steep_spectra(name):
+    """Morse(3, 2): no scale takes a decimated band, 83 of the headline's 100 go through the block convolution
+    (float64 spectrum of every 4096-sample block, float32 from there: kernels.hip: k_bc_scales) and the rest through
+    the time domain.  Measured 1.5e-7 .. 7.1e-7 on these inputs (profiles/r04_heavy_tails.md); the bound leaves a
+    factor of four."""
+    from ghost_amd.synthetic import spectrum_class
+    from ghost_amd import _lib
+    fs, n = 1000.0, 300000
+    f = np.geomspace(200.0, 2.0, 100)
+    x = _offset(name, n, fs) if name.endswith("_offset") else spectrum_class(name, n, fs)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f, gamma=3.0, beta=2.0, n_threads=8)
+    c, si = _run(x, fs, f, "complex", gamma=3.0, beta=2.0)
+    assert (si["method"] == _lib.SCALE_BLOCKCONV).sum() >= 80 and (si["method"] == _lib.SCALE_SPECTRAL).sum() == 0
+    assert rel_err(c, ref).max() < 3e-6
+    a, _ = _run(x, fs, f, "amplitude", gamma=3.0, beta=2.0)
+    assert rel_err(a, np.abs(ref)).max() < 3e-6
