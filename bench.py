@@ -579,7 +579,8 @@ def run_rank(args):
                 plan.close()
             except Exception:
                 pass
-            line["other_configs"] = {"config2": config2_leg(fs, freqs, dev, lib, check, no_check=args.no_check),
+            line["other_configs"] = {"config1": config1_leg(fs, dev, lib, check, no_check=args.no_check),
+                                     "config2": config2_leg(fs, freqs, dev, lib, check, no_check=args.no_check),
                                      "heavy_tailed_wavelet": heavy_tail_leg(N, C, fs, freqs, dev, lib, check,
                                                                             no_check=args.no_check),
                                      "config5": config5_leg(args)}
@@ -611,6 +612,51 @@ def check_config5(plan, xbuf, ring_buf, base, distinct, fs, freqs, N, S, group, 
         "rows": "time block %d of %d (samples %d..%d), channels {0, %d} x scales {0, %d, %d} vs the oracle"
                 % (i_mid, len(segs), a, b, group - 1, S // 2, S - 1),
         "worst_rel_err": float("%.3g" % worst)}
+
+
+def config1_leg(fs, dev, lib, check, no_check=False, steps=200, warmup=10):
+    """BASELINE.json config 1 -- 1 channel x 16 384 samples x 32 scales (6 voices per octave, 200 Hz down), the
+    reference's own CPU-sized case -- as a latency: device-resident execute of a prebuilt plan, and the public call
+    end to end (plan lookup, host array in, float64 result out)."""
+    from ghost_amd.engine import CwtPlan, DeviceBuffer
+    from ghost_amd.synthetic import lfp_channel
+    from ghost_amd.wave import ContinuousWaveletTransform
+    N = 16384
+    f1 = 200.0 / 2.0 ** (np.arange(32) / 6.0)
+    x = lfp_channel(N, fs, channel=0, seed=99)
+    plan = CwtPlan(N, 1, fs, f1, output="amplitude", device=dev)
+    plan.upload()
+    xb, ob = DeviceBuffer(4 * N), DeviceBuffer(plan.info["out_bytes"])
+    xb.upload(x)
+    for _ in range(warmup):
+        plan.execute_device(xb, ob)
+    check(lib.gcwt_device_synchronize())
+    wall = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        plan.execute_device(xb, ob)
+        wall.append(time.perf_counter() - t0)
+    el = float(np.median(wall))
+    res = {"workload": "1 ch x %d samples @ 1 kHz x 32 Morse scales 200..5.6 Hz, amplitude f32" % N,
+           "device_resident": {"us_per_call": round(el * 1e6, 1), "value": round(N / el / 1e6, 2), "unit": "Msamples/s",
+                               "steps": steps, "warmup": warmup, "statistic": "median"}}
+    if not no_check:
+        from oracle import ghost_oracle as orc
+        ref = orc.cwt_amplitude(x.astype(np.float64), fs, f1)
+        got = ob.download((32, N), np.float32)
+        worst = float((np.abs(got - ref).max(axis=1) / ref.max(axis=1)).max())
+        res["checked"], res["worst_rel_err"] = bool(worst <= 1e-5), float("%.3g" % worst)
+        res["check"] = "all 32 rows vs the oracle"
+    xb.free(); ob.free(); plan.close()
+    cwt = ContinuousWaveletTransform()
+    ts = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        cwt.transform(x, fs=fs, freqs=f1[::-1].copy())
+        ts.append(time.perf_counter() - t0)
+    res["transform_end_to_end"] = {"us_per_call": round(float(np.median(ts[2:])) * 1e6, 1), "first_call_ms": round(ts[0] * 1e3, 2),
+                                   "note": "host in, float64 host out, plan cached after the first call"}
+    return res
 
 
 def heavy_tail_leg(N, C, fs, freqs, dev, lib, check, no_check=False, steps=5, warmup=2, gamma=3.0, beta=2.0):
