@@ -11,7 +11,7 @@
 #include <cmath>
 int main() {
   std::mt19937_64 rng(7);
-  int ok = 0, refused = 0;
+  int ok = 0, refused = 0, bc_plans = 0;
   for (int it = 0; it < 6000; ++it) {
     gcwt_params prm{};
     const double fss[] = {200.0, 1000.0, 1250.0, 30000.0};
@@ -30,7 +30,7 @@ int main() {
     prm.n_freqs = nf; prm.freqs_hz = f.data();
     std::vector<int64_t> eb;
     int64_t cur = 0;
-    const int ne = 1 + (int)(rng() % 5);
+    const int ne = rng() % 6 == 0 ? 200 : 1 + (int)(rng() % 5);      // now and then: many short epochs
     for (int e = 0; e < ne && cur + 8 < prm.n_samples; ++e) {
       const int64_t a = cur + (int64_t)(rng() % 3), b = e == ne - 1 ? prm.n_samples : std::min<int64_t>(prm.n_samples, a + 4 + (int64_t)(rng() % (prm.n_samples / ne + 1)));
       if (b - a > 3) { eb.push_back(a); eb.push_back(b); }
@@ -47,7 +47,29 @@ int main() {
     std::string err;
     const int rc = gcwt::build_host_plan(prm, &hp, &err);
     if (rc == 0) ++ok; else ++refused;
+    if (rc == 0) {
+      // block convolution (round 4): every such scale in exactly one group, whole inside the group's window
+      std::vector<int> seen(hp.scales.size(), 0);
+      int in_groups = 0;
+      for (const auto& g : hp.bc_groups) {
+        if (g.hop < 64 || g.hop % 64 || g.back % 64 || g.count < 1 || g.first != in_groups) { printf("bad group\n"); return 1; }
+        for (int k = g.first; k < g.first + g.count; ++k) {
+          const gcwt::ScalePlan& sp = hp.scales[hp.bc_order[k]];
+          const int64_t ahead = (sp.length - 1) / 2, behind = sp.length - 1 - ahead;
+          if (sp.method != GCWT_SCALE_BLOCKCONV || sp.blockconv_index != k || behind > g.back ||
+              g.back + g.hop + ahead > 4096 || seen[hp.bc_order[k]]++) { printf("bad member\n"); return 1; }
+        }
+        in_groups += g.count;
+      }
+      int n_bc = 0;
+      for (const auto& sp : hp.scales) n_bc += sp.method == GCWT_SCALE_BLOCKCONV;
+      if (n_bc != in_groups || n_bc != hp.n_blockconv || (int)hp.bc_order.size() != n_bc ||
+          (n_bc > 0 && hp.bc_chunk_blocks < 1) || !(hp.bc_fill > 0.0 && hp.bc_fill <= 1.0)) { printf("bad count\n"); return 1; }
+      for (const auto& sp : hp.scales)
+        if (sp.method == GCWT_SCALE_DIRECT && sp.length > 256) { printf("direct too long\n"); return 1; }
+      bc_plans += n_bc > 0;
+    }
   }
-  printf("plans ok %d refused %d\n", ok, refused);
+  printf("plans ok %d refused %d, with block-convolution scales %d\n", ok, refused, bc_plans);
   return 0;
 }
