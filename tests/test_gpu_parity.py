@@ -635,6 +635,35 @@ def test_blockconv_path_lengths_epochs_modes_and_ranges(option):
     assert rel_err(old.execute(x), got).max() < 3e-6
 
 
+def test_blockconv_many_epochs(option):
+    """Forty epochs (more than one launch's sixteen), from 9 samples to several blocks long, gaps between them,
+    both precisions: every epoch is convolved on its own, zero outside (transforms.py:185, convolution.py:68-87)."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd import _lib
+    option("direct_max_len", 48)         # (a recording this ragged would keep its short kernels in the time domain)
+    fs, n = 1000.0, 120000
+    rng = np.random.default_rng(17)
+    x = (rng.standard_normal((2, n)) * 3 + 0.1 * np.cumsum(rng.standard_normal((2, n)), axis=1)).astype(np.float32)
+    cuts = np.sort(rng.choice(np.arange(10, n - 10), size=39, replace=False))
+    edges = [0, *cuts.tolist(), n]
+    eb = np.array([[a + int(rng.integers(0, 4)), b - int(rng.integers(0, 3))] for a, b in zip(edges[:-1], edges[1:]) if b - a > 12])
+    eb[3, 1] = eb[3, 0] + 9
+    f = np.array([150.0, 42.0, 11.0, 3.3])
+    ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, eb, gamma=2, beta=3) for c in range(2)])
+    scale = np.abs(ref).max(axis=2, keepdims=True)
+    for precision in ("high", "fast"):
+        p = CwtPlan(n, 2, fs, f, gamma=2, beta=3, epoch_bounds=eb, output="complex", precision=precision)
+        assert (p.scale_info()["method"] == _lib.SCALE_BLOCKCONV).sum() >= 3
+        got = p.execute(x)
+        assert (np.abs(got - ref) / scale).max() < TOL, precision
+        inside = np.zeros(n, bool)
+        for a, b in eb:
+            inside[a:b] = True
+        assert np.all(got[:, :, ~inside] == 0)
+        a, b = int(eb[20, 0]) - 5, int(eb[24, 1]) + 7
+        np.testing.assert_array_equal(p.execute_block(x, a, b - a), got[:, :, a:b])
+
+
 @pytest.mark.parametrize("n, p1", [(1000000, 256), (2000003, 512), (4000000, 1024)])
 def test_fullband_fused_passes(n, p1, option):
     """FFT lengths 2^20 .. 2^22: the full-band path's product rides the inverse row pass and its column pass
