@@ -1113,6 +1113,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       bl.n_channels = C;
       bl.hop = g.hop;
       bl.back = g.back;
+      bl.ramp = g.ramp;
       int ne = 0;
       auto flush = [&]() -> int {
         bl.n_epochs = ne;

@@ -470,6 +470,20 @@ __global__ void __launch_bounds__(256) k_bc_forward(const float* __restrict__ x,
     v[j] = make_double2(n >= w0.e0 && n < w0.e1 ? (double)xa - mean : 0.0,
                         second && m >= w1.e0 && m < w1.e1 ? (double)xm - mean : 0.0);
   }
+  if (bl.ramp > 0) {
+    // precision = exact: the block's edges fade (C2), so that a strong line elsewhere in the band does not reach this
+    // scale's bins as the leakage of a cut -- which float32 could not cancel again after the product
+    const double inv = 1.0 / (double)bl.ramp;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int off = 16 * (t + 16 * j) + a;
+      const int edge = min(off, kRowLenDev - 1 - off);
+      if (edge < bl.ramp) {
+        const double u = ((double)edge + 0.5) * inv, w = u * u * u * (10.0 + u * (6.0 * u - 15.0));
+        v[j] = make_double2(v[j].x * w, v[j].y * w);
+      }
+    }
+  }
   __syncthreads();
   d_fft256(v, twl + t, ex_re + a * kDCol, ex_im + a * kDCol, t);
   __syncthreads();

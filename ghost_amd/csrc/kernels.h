@@ -273,7 +273,8 @@ struct BcBlocks {
   int32_t blk_first[kSegBatch + 1];             // blocks of epoch e: [blk_first[e], blk_first[e + 1])
   int32_t n_channels, n_epochs;
   int32_t hop, back;
-};
+  int32_t ramp, pad;                            // the block's first and last `ramp` samples fade in / out (smootherstep;
+};                                              //   they lie outside what its outputs read: planner.h, BcGroup)
 // spectra of the blocks [blk0, blk0 + nblk) of every channel: float64 transform of x - mean, rounded per bin;
 // xb[(blk - blk0) * n_channels + ch][4096]
 hipError_t launch_bc_forward(const float* x, float2* xb, const BcBlocks& bl, int blk0, int nblk,

@@ -44,11 +44,12 @@ static void plan_blockconv(HostPlan* hp, bool rebalance) {
   const int n = (int)order.size();
   // the longest kernel of a run decides both sides: ahead (L - 1) / 2 taps, behind L - 1 - (L - 1) / 2, the latter
   // rounded up to 64 so that a block's stores start on a 256-byte boundary of the row
+  const int ramp = hp->exact_only ? kBlockConvRamp : 0;
   auto geometry = [&](int last, int* hop, int* back) {
     const int64_t len = hp->scales[order[last]].length;
     const int ahead = (int)((len - 1) / 2);
-    *back = (int)(((len - 1 - ahead) + 63) & ~(int64_t)63);
-    *hop = (kRowLen - *back - ahead) & ~63;
+    *back = (int)(((len - 1 - ahead) + ramp + 63) & ~(int64_t)63);
+    *hop = (kRowLen - *back - ahead - ramp) & ~63;
   };
   const double kForward = 2.0, kWidestHop = 3712.0, kTapsPerUnit = 39.0;
   std::vector<double> rest(n + 1, 0.0);        // cheapest grouping of order[start ..), in scales of a full widest block
@@ -77,6 +78,7 @@ static void plan_blockconv(HostPlan* hp, bool rebalance) {
     g.first = start - first;
     g.count = stop[start] - start;
     geometry(stop[start] - 1, &g.hop, &g.back);
+    g.ramp = ramp;
     hp->bc_groups.push_back(g);
   }
   order.erase(order.begin(), order.begin() + first);
@@ -503,9 +505,13 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   if (prm.support_tol > 0) hp->support_tol = prm.support_tol;
   if (hp->support_tol > 1e-2) return fail(GCWT_ERR_INVALID, "support_tol too large");
   if (prm.reserved0 != 0) return fail(GCWT_ERR_INVALID, "gcwt_params.reserved0 must be 0 (caller built against an older ghostcwt.h?)");
-  if (prm.precision < 0 || prm.precision > 2) return fail(GCWT_ERR_INVALID, "bad precision (0 default, 1 fast, 2 high)");
+  if (prm.precision < 0 || prm.precision > 3) return fail(GCWT_ERR_INVALID, "bad precision (0 default, 1 fast, 2 high, 3 exact)");
   hp->high_precision = prm.precision != GCWT_PRECISION_FAST;
-  if (option_or("blockconv", 1) != 0) {
+  hp->exact_only = prm.precision == GCWT_PRECISION_EXACT;
+  if (hp->exact_only) {                     // every kernel through a float64 spectrum: none in the time domain either
+    hp->direct_max_len = 0;
+    hp->blockconv_max_len = kBlockConvExactMaxLen;
+  } else if (option_or("blockconv", 1) != 0) {
     hp->direct_max_len = (int)std::min<long long>(kDirectMaxLen, std::max<long long>(0, option_or("direct_max_len", kDirectDefaultLen)));
     hp->blockconv_max_len = kBlockConvMaxLen;
   } else {                                  // rounds 1-4: time domain up to 256 taps, full band beyond
@@ -570,6 +576,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     hp->amps.insert(hp->amps.end(), amp.begin(), amp.end());
     hp->max_bins = std::max(hp->max_bins, (int)sp.n_bins);
     analyse_scale(*hp, &sp, amp.data());
+    if (hp->exact_only) sp.band_ok = false;
     sp.method = sp.band_ok ? GCWT_SCALE_SPECTRAL
                            : exact_method(*hp, sp.length);
   }
@@ -739,7 +746,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
       }
     }
   }
-  plan_blockconv(hp, option_or("direct_max_len", -1) < 0);
+  plan_blockconv(hp, option_or("direct_max_len", -1) < 0 && !hp->exact_only);
   int64_t lmax_spec = longest_fft_kernel();
   for (int i = 0; i < prm.n_freqs; ++i) {
     ScalePlan& sp = hp->scales[i];

@@ -28,6 +28,10 @@ constexpr int kSynthWide = 32;      // columns per batch of the production kerne
 constexpr int kDirectMaxLen = 256;  // longest kernel the time-domain path can take (k_direct's tile)
 constexpr int kDirectDefaultLen = 48;   // ... and takes by default: ~6.4 us per tap and scale at 128 ch x 1e6, against
                                         // the block convolution's flat cost per scale
+constexpr int kBlockConvRamp = 256;     // precision = exact: faded samples at either end of a block ...
+constexpr int kBlockConvExactMaxLen = 1024;   // ... and the longest kernel that goes by blocks there: longer ones sit at
+                                        // low frequencies, a few bins of a block from any drift, where 256 faded samples
+                                        // do not keep its leakage out; the full-band path has no block edges
 constexpr int kBlockConvMaxLen = 2560;  // longest kernel of the block convolution: its 4096-sample blocks then still
                                         // yield 1537 samples each; beyond it the full-band path (one FFT of the
                                         // whole segment per scale)
@@ -150,11 +154,13 @@ struct HostPlan {
   bool halo_static = true;         // every level is `fast`
   int n_direct = 0;
   int n_blockconv = 0;
+  bool exact_only = false;         // precision = exact: no scale takes a decimated band or the time domain
   int direct_max_len = kDirectDefaultLen, blockconv_max_len = kBlockConvMaxLen;   // (options direct_max_len, blockconv)
   std::vector<int> bc_order;       // block-convolution scales by kernel length
   struct BcGroup {                 // consecutive entries of bc_order that share one set of block spectra
     int first = 0, count = 0;
     int hop = 0, back = 0;         // kernels.h: BcBlocks
+    int ramp = 0;                  // precision = exact: samples at either end of a block that fade and that no output reads
   };
   std::vector<BcGroup> bc_groups;
   double bc_fill = 1.0;            // share of the block convolution's blocks that epochs fill (widest hop)

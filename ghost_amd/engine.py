@@ -120,9 +120,9 @@ class CwtPlan:
         p.wavelet_flags = int(order) | (_lib.WAVELET_ENERGY if normalization == "energy" else 0)
         # 'high' (default): float64 forward transform and per-level low cut, the reference's dynamic
         # range (it computes in float64: transforms.py:142-143); 'fast': float32 throughout
-        if precision not in (None, "default", "fast", "high"):
-            raise ValueError("precision must be 'fast' or 'high'")
-        p.precision = {None: 0, "default": 0, "fast": 1, "high": 2}[precision]
+        if precision not in (None, "default", "fast", "high", "exact"):
+            raise ValueError("precision must be 'fast', 'high' or 'exact'")
+        p.precision = {None: 0, "default": 0, "fast": 1, "high": 2, "exact": 3}[precision]
         p.support_tol = float(support_tol)
         check(lib.gcwt_plan_create(C.byref(self._handle), C.byref(p)))
         self.n_samples, self.n_channels = int(n_samples), int(n_channels)

@@ -62,7 +62,9 @@ class ContinuousWaveletTransform(WaveletTransform):
         (validated, then ignored: the GPU does all scales at once), ``verbose``.
         Beyond the reference: ``multichannel``, ``output`` ('amplitude', 'power', 'complex'), ``dtype``,
         ``device`` and ``precision`` ('high', the default: the forward FFT in float64 like the reference's
-        arithmetic, transforms.py:142-143; 'fast': float32 throughout).
+        arithmetic, transforms.py:142-143; 'fast': float32 throughout; 'exact': every scale by FFT convolution
+        with its literal kernel, 3 - 5 x slower, for recordings with interference far above the signal inside the
+        analysed band).
         """
         if multichannel is None:
             multichannel = False
@@ -149,9 +151,10 @@ class ContinuousWaveletTransform(WaveletTransform):
         self._wavelet.fs = self._fs                            # transforms.py:179
 
         from ..engine import CwtPlan   # needs the built library; no CPU fallback
-        if precision not in (None, "high", "fast"):
+        if precision not in (None, "high", "fast", "exact"):
             raise ValueError("'precision' must be 'high' (default: the reference's float64 dynamic range in "
-                             "front of the float32 synthesis) or 'fast' (float32 throughout)")
+                             "front of the float32 synthesis), 'fast' (float32 throughout) or 'exact' (no decimated "
+                             "path: every scale's float32 stages see only what its own filter lets through)")
         key = (n_samples, n_channels, float(self._fs), f.tobytes(), float(self._wavelet.gamma),
                float(self._wavelet.beta), epoch_bounds.tobytes(), output, int(device), precision)
         if self._plan is None or self._plan_key != key:

@@ -112,12 +112,19 @@ typedef struct {
  * its slice of the spectrum to zero below the band of its scales (where every gain is under 2e-8 of
  * its peak) before the float32 stages: content BELOW the analysed bands (drift, offsets, 1/f^n
  * backgrounds) up to ~1000 x the quietest band still meets 1e-5 (FAST: ~65 x).  Interference INSIDE a
- * level's band (a mains line between its scales) is good to ~65 x in both (profiles/r04_dynamic_range.md).
- * FAST: float32 throughout (rounds 1-3). */
+ * level's band (a mains line between its scales) is good to ~65 x in both (profiles/r04_dynamic_range.md);
+ * EXACT below lifts both limits at 4.4 x the time.  FAST: float32 throughout (rounds 1-3). */
 typedef enum {
   GCWT_PRECISION_DEFAULT = 0,
   GCWT_PRECISION_FAST = 1,
-  GCWT_PRECISION_HIGH = 2
+  GCWT_PRECISION_HIGH = 2,
+  GCWT_PRECISION_EXACT = 3   /* no decimated path: every scale through the block convolution (kernels up to 1024
+                              * taps, block edges faded) or the full-band path -- float64 forward transforms, and
+                              * the float32 stages after them only ever see what the scale's own filter lets
+                              * through, so an error stays relative to the scale's own output whatever else the
+                              * recording holds: a mains line or a drift 1e4 x the recording's std reads 5e-7 /
+                              * 2e-6 (profiles/r04_dynamic_range.md).  4.4 x the time of HIGH on the default
+                              * wavelet at the headline shape. */
 } gcwt_precision;
 
 typedef struct {

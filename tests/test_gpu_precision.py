@@ -277,3 +277,31 @@ def test_block_convolution_on_steep_spectra(name):
     assert rel_err(c, ref).max() < 3e-6
     a, _ = _run(x, fs, f, "amplitude", gamma=3.0, beta=2.0)
     assert rel_err(a, np.abs(ref)).max() < 3e-6
+
+
+def test_exact_precision_under_a_mains_line_inside_the_band():
+    """precision='exact': no decimated path -- every scale by FFT convolution with its literal kernel from float64
+    spectra (blocks with faded edges for kernels up to 1024 taps, the full-band path beyond), so the float32 stages see
+    a scale's own filtered content only.  A 60 Hz line of 1000 x and a 0.05 Hz drift of 3000 x the recording's std
+    together, faded in and out (D ~ 2300 and ~ 6800 against the quietest band): 'high' is two orders over the gate
+    (the line sits inside the bands of three decimation levels), 'exact' reads 1e-6 (profiles/r04_dynamic_range.md)."""
+    from ghost_amd.synthetic import lfp_channel
+    from ghost_amd import _lib
+    fs, n = 1000.0, 1 << 19
+    f = np.geomspace(200.0, 2.0, 100)[::2]
+    t = np.arange(n) / fs
+    base = lfp_channel(n, fs, 2).astype(np.float64)
+    win = np.ones(n)
+    m = n // 10
+    win[:m] = 0.5 - 0.5 * np.cos(np.pi * np.arange(m) / m)
+    win[-m:] = win[:m][::-1]
+    x = (base + base.std() * win * (1000.0 * np.sin(2 * np.pi * 60.0 * t + 0.7) + 3000.0 * np.sin(2 * np.pi * 0.05 * t + 0.2))).astype(np.float32)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f, n_threads=8)
+    exact, si = _run(x, fs, f, "complex", precision="exact")
+    assert not np.isin(si["method"], (_lib.SCALE_SPECTRAL, _lib.SCALE_DIRECT)).any()
+    high, _ = _run(x, fs, f, "complex", precision="high")
+    e_x, e_h = rel_err(exact, ref).max(), rel_err(high, ref).max()
+    print("60 Hz at 1000 x + drift at 3000 x std: exact %.2e high %.2e" % (e_x, e_h))
+    assert e_x < 0.3 * TOL and e_h > 10 * TOL
+    amp, _ = _run(x, fs, f, "amplitude", precision="exact")
+    assert rel_err(amp, np.abs(ref)).max() < 0.3 * TOL

@@ -468,6 +468,21 @@ def test_planner_measures_each_wavelet():
     assert (q.scale_info()["method"] == _lib.SCALE_SPECTRAL).sum() >= 30
 
 
+def test_exact_precision_plans_no_decimated_scale():
+    """precision='exact' (ghostcwt.h: GCWT_PRECISION_EXACT): the default wavelet's scales all go through the block
+    convolution or the full-band path; 'high' stays the default; other values are refused."""
+    from ghost_amd.engine import CwtPlan
+    f = np.geomspace(200.0, 2.0, 100)
+    p = CwtPlan(1000000, 8, 1000.0, f, precision="exact")
+    m, ln = p.scale_info()["method"], p.scale_info()["length"]
+    assert p.info["n_spectral"] == 0 and p.info["n_direct"] == 0
+    assert np.all(m[ln <= 1024] == _lib.SCALE_BLOCKCONV) and np.all(m[ln > 1024] == _lib.SCALE_FULLBAND)
+    assert all(g["hop"] + g["back"] + 256 <= 4096 and g["back"] >= 256 for g in p.debug_blockconv())   # faded block edges
+    assert CwtPlan(1000000, 8, 1000.0, f).info["n_spectral"] == 100
+    with pytest.raises(ValueError):
+        CwtPlan(1000, 1, 1000.0, f[:3], precision="double")
+
+
 def test_blockconv_planning():
     """Kernels no decimated band holds, by length: time domain up to 48 taps, overlap-save blocks up to 2560, one
     FFT per segment beyond (planner.h).  The block scales are grouped by length; every scale of a group is whole

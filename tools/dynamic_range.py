@@ -1,7 +1,7 @@
 """The engine's dynamic-range envelope, measured (round 4): gate metric against the amplitude of an interferer -- a 60 Hz
 line (inside the bands of the levels R = 2, 4, 16 of the headline grid) and a 0.05 Hz drift (below every level's low
-cut) -- added to the pink LFP workload data, N = 2^19 @ 1 kHz, the headline's 100 scales, complex output, both
-precisions.  D = interferer amplitude over the smallest row maximum of the clean recording's coefficients: how far the
+cut) -- added to the pink LFP workload data, N = 2^19 @ 1 kHz, the headline's 100 scales, complex output, the three
+precisions ('exact': no decimated path).  D = interferer amplitude over the smallest row maximum of the clean recording's coefficients: how far the
 quietest analysed band lies below the interferer.  Writes gpurun_out/dynamic_range.json."""
 import json, sys; sys.path.insert(0, '.')
 import numpy as np
@@ -24,14 +24,15 @@ for kind, freq in (("line 60 Hz", 60.0), ("drift 0.05 Hz", 0.05)):
         x = (base + amp * base.std() * win * np.sin(2 * np.pi * freq * t + 0.7)).astype(np.float32)
         ref = orc.cwt_complex(x.astype(np.float64), fs, f, n_threads=8)
         res = {}
-        for prec in ("high", "fast"):
+        for prec in ("high", "fast", "exact"):
             p = CwtPlan(n, 1, fs, f, output="complex", precision=prec)
             got = p.execute(x[None])[0]
             si = p.scale_info()
             p.close()
             err = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
             res[prec] = (float(err.max()), int(si["decimation"][err.argmax()]), float(f[err.argmax()]))
-        rows.append(dict(kind=kind, amp_over_std=amp, D=float(amp * base.std() / quiet), high=res["high"], fast=res["fast"]))
-        print("%-14s A = %6.0f std  D = %8.0f   high %.2e (R %d, %.1f Hz)   fast %.2e (R %d, %.1f Hz)" % (
-            kind, amp, rows[-1]["D"], *res["high"], *res["fast"]), flush=True)
+        rows.append(dict(kind=kind, amp_over_std=amp, D=float(amp * base.std() / quiet), high=res["high"], fast=res["fast"],
+                         exact=res["exact"]))
+        print("%-14s A = %6.0f std  D = %8.0f   high %.2e (R %d, %.1f Hz)   fast %.2e (R %d, %.1f Hz)   exact %.2e (%.1f Hz)" % (
+            kind, amp, rows[-1]["D"], *res["high"], *res["fast"], res["exact"][0], res["exact"][2]), flush=True)
 json.dump(dict(fs=fs, n=n, quiet_row_max_over_std=float(quiet / base.std()), rows=rows), open("gpurun_out/dynamic_range.json", "w"), indent=1)

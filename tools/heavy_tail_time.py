@@ -11,7 +11,7 @@ for k in ('blockconv', 'direct_max_len'):
 fs = 1000.; N = 1000000; C = int(os.environ.get("QB_C", "128")); S = 100
 g, b = float(os.environ.get("HT_GAMMA", "3")), float(os.environ.get("HT_BETA", "4"))
 f = np.geomspace(200.0, 2.0, S)
-plan = CwtPlan(N, C, fs, f, gamma=g, beta=b); plan.set_profiling(True)
+plan = CwtPlan(N, C, fs, f, gamma=g, beta=b, precision=os.environ.get('HT_PRECISION')); plan.set_profiling(True)
 info = plan.info
 x = lfp(4, N); x = np.tile(x, (C // 4 + 1, 1))[:C]
 xb = DeviceBuffer(x.nbytes); xb.upload(x)

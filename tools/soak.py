@@ -2,7 +2,7 @@
 epochs with gaps, sampling rates, frequency ranges down to large decimations, forced time
 blocks, output modes, block requests).  Prints the worst relative error per case; exits
 non-zero on the first case over the 1e-5 gate.  SOAK_N cases (default 60), SOAK_SEED;
-SOAK_BIG=1 adds recordings of up to 2.5 M samples (FFT lengths up to 2^22); SOAK_DETAIL=3e-6 prints the
+SOAK_EXACT=1: most cases with precision = 'exact'; SOAK_BIG=1 adds recordings of up to 2.5 M samples (FFT lengths up to 2^22); SOAK_DETAIL=3e-6 prints the
 per-scale errors of every case above that."""
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np
@@ -73,6 +73,8 @@ for case in range(n_cases):
         kw["max_fft_log2"] = int(rng.choice([12, 13, 14, 16] + ([20, 21, 22] if os.environ.get("SOAK_BIG") else [])))
     if long_mode and rng.random() < 0.5:
         kw["max_fft_log2"] = 24
+    if os.environ.get("SOAK_EXACT") and not long_mode and rng.random() < 0.6:     # precision = exact: no decimated path
+        kw["precision"] = "exact"
     try:
         p = CwtPlan(n, n_ch, fs, f, **kw)
     except Exception as e:
