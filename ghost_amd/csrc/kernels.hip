@@ -800,49 +800,65 @@ __global__ void __launch_bounds__(256, 2) k_fullband_rows(const cf* __restrict__
                                                        const cf* __restrict__ tw4096,
                                                        const cf* __restrict__ tw256, int n_slots, int group) {
   __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
-  float* const ex_re = reinterpret_cast<float*>(buf);
+  float* const ex_re = reinterpret_cast<float*>(buf) + (threadIdx.x & 15) * kExColD;
   float* const ex_im = ex_re + 16 * kExColD;
-  __shared__ cf twl[256];
+  __shared__ v2f twl[256];
   const int tid = threadIdx.x, a = tid & 15, t = tid >> 4;
   const int bid = blockIdx.x, per = group * n_slots;
   const int slot = (bid % per) / group, row = bid % group + group * (bid / per);
-  twl[tid] = tw256[(a * t) & 255];
-  const int64_t at = (int64_t)row * kRowLenDev + 16 * t + a;
-  cf xv[16], v[16];
   {
-    const cf* xp = in + (int64_t)slot * in_cstride + at;
+    const cf w = tw256[(a * t) & 255];
+    twl[tid] = v2f{w.x, w.y};
+  }
+  const int64_t at = (int64_t)row * kRowLenDev + 16 * t + a;
+  v2f xv[16], v[16];
+  {
+    const v2f* xp = reinterpret_cast<const v2f*>(in) + (int64_t)slot * in_cstride + at;
 #pragma unroll
     for (int j = 0; j < 16; ++j) xv[j] = xp[256 * j];
   }
-  cf w0 = make_float2(1.f, 0.f), st = w0;
+  v2f w0 = {1.f, 0.f}, st = w0;
   if (tw_n > 0) {
-    w0 = unit_phase((int64_t)row * tid, tw_n, 1);
-    st = unit_phase((int64_t)row * 256, tw_n, 1);
+    const cf p0 = unit_phase((int64_t)row * tid, tw_n, 1), p1 = unit_phase((int64_t)row * 256, tw_n, 1);
+    w0 = v2f{p0.x, p0.y};
+    st = v2f{p1.x, p1.y};
   }
+  v2f* const bufv = reinterpret_cast<v2f*>(buf);
+  // the three radix-16 layers are synth_math.h's packed idft16v, as in k_bc_scales (output k in register dft16_pos(k))
   for (int sel = 0; sel < 2; ++sel) {
     const cf* __restrict__ h = sel ? h1 : h0;
     if (!h) break;
-    cf* __restrict__ o = (sel ? z1 : z0) + (int64_t)slot * out_cstride + (int64_t)row * kRowLenDev;
+    const v2f* __restrict__ hs = reinterpret_cast<const v2f*>(h) + at;
+    v2f* __restrict__ o = reinterpret_cast<v2f*>(sel ? z1 : z0) + (int64_t)slot * out_cstride + (int64_t)row * kRowLenDev;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = cmul(xv[j], h[at + 256 * j]);
+    for (int j = 0; j < 16; ++j) v[j] = cmulv(xv[j], hs[256 * j]);
     __syncthreads();                      // twiddle table written / the buffer's last readers done
-    fft256_16t_ldstw<1>(v, twl + t, ex_re + a * kExColD, ex_im + a * kExColD, t);
+    idft16v(v);
+#pragma unroll
+    for (int m2 = 0; m2 < 16; ++m2) {
+      const v2f u = cmulv(v[dft16_pos(m2)], twl[t + 16 * m2]);
+      ex_re[t * kExPitch + m2] = u.x;
+      ex_im[t * kExPitch + m2] = u.y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) v[k1] = v2f{ex_re[k1 * kExPitch + t], ex_im[k1 * kExPitch + t]};
+    idft16v(v);
     __syncthreads();                      // the element buffer aliases the exchange planes
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int kb = t + 16 * j;
-      buf[pad32(16 * kb + a)] = cmul(v[j], tw4096_at<1>(tw4096, kb * a));
+      const cf w = tw4096_at<1>(tw4096, (t + 16 * j) * a);
+      bufv[pad32(16 * (t + 16 * j) + a)] = cmulv(v[dft16_pos(j)], v2f{w.x, w.y});
     }
     __syncthreads();
-    cf u[16];
 #pragma unroll
-    for (int aa = 0; aa < 16; ++aa) u[aa] = buf[pad32(16 * tid + aa)];
-    dft_small<1, 16>(u);
-    cf w = w0;
+    for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[pad32(16 * tid + aa)];
+    idft16v(v);
+    v2f w = w0;
 #pragma unroll
     for (int ka = 0; ka < 16; ++ka) {
-      cf val = u[ka];
-      if (tw_n > 0) { val = cmul(val, w); w = cmul(w, st); }
+      v2f val = v[dft16_pos(ka)];
+      if (tw_n > 0) { val = cmulv(val, w); w = cmulv(w, st); }
       o[tid + 256 * ka] = val;
     }
   }
