@@ -163,6 +163,18 @@ struct gcwt_plan {
   gcwt_timings last{};
   bool have_timings = false;
   bool have_means = false;
+  // Small device-resident executes are launch-bound (config 1: fifteen kernels of a few microseconds each): the
+  // second execute with the same arguments is captured into a graph, later ones replay it
+  struct GraphKey {
+    const void* x = nullptr; const void* out = nullptr;
+    int64_t r0 = 0, r1 = 0, row_len = 0; bool reuse = false;
+    bool operator==(const GraphKey& o) const {
+      return x == o.x && out == o.out && r0 == o.r0 && r1 == o.r1 && row_len == o.row_len && reuse == o.reuse;
+    }
+  };
+  GraphKey graph_key, graph_seen;
+  hipGraphExec_t graph_exec = nullptr;
+  bool graph_seen_valid = false, graph_failed = false;
   int64_t row_pitch = 0;     // device output rows, samples; 0 = dense
 };
 
@@ -195,6 +207,7 @@ void free_dev(gcwt_plan* p) {
   p->host_out.release();
   for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.items7w); fr(e.levels7); fr(e.items_i); fr(e.levels_i); }
   p->ep_dev.clear();
+  if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
   p->ev_pool.clear();
   if (p->stream) { (void)hipStreamDestroy(p->stream); p->stream = nullptr; }
@@ -1197,11 +1210,47 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   p->spans.clear();
   if (p->profiling) { p->last = gcwt_timings{}; }
   const bool reuse = (flags & GCWT_REUSE_MEANS) && p->have_means;
-  rc = run_pipeline(p, dx, dout, r0, r1, row_len, reuse);
-  if (rc) {   // a failure between a fork and its join: nothing may still be running on any of the plan's streams
-    (void)hipStreamSynchronize(p->stream);
-    for (auto& q : p->aux) (void)hipStreamSynchronize(q);
-    return rc;
+  // graph replay: device in and out, nothing to time, no full-band scale (its response cache allocates on the way),
+  // and a result small enough for the launches to matter (16 M coefficients)
+  const bool graphable = !p->graph_failed && !p->profiling && (flags & GCWT_X_ON_DEVICE) && (flags & GCWT_OUT_ON_DEVICE) &&
+                         hp.n_fullband == 0 && option_or("graphs", 1) != 0 &&
+                         (int64_t)rows * n_out <= ((int64_t)1 << 24);
+  const gcwt_plan::GraphKey key{dx, dout, r0, r1, row_len, reuse};
+  bool done = false;
+  if (graphable && p->graph_exec && key == p->graph_key) {
+    HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
+    done = true;
+  } else if (graphable && p->graph_seen_valid && key == p->graph_seen) {
+    if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    bool ok = hipStreamBeginCapture(p->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+    if (ok) {
+      const int rc_cap = run_pipeline(p, dx, dout, r0, r1, row_len, reuse);
+      const hipError_t he_end = hipStreamEndCapture(p->stream, &graph);
+      ok = rc_cap == GCWT_OK && he_end == hipSuccess && graph != nullptr;
+      if (ok) ok = hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+    }
+    if (ok) {
+      p->graph_key = key;
+      HIP_TRY(hipGraphLaunch(p->graph_exec, p->stream));
+      done = true;
+    } else {                                 // whatever did not capture: this plan runs eagerly from here on
+      (void)hipGetLastError();
+      p->graph_exec = nullptr;
+      p->graph_failed = true;
+      p->ev_used = 0;
+    }
+  }
+  if (!done) {
+    p->graph_seen = key;
+    p->graph_seen_valid = true;
+    rc = run_pipeline(p, dx, dout, r0, r1, row_len, reuse);
+    if (rc) {   // a failure between a fork and its join: nothing may still be running on any of the plan's streams
+      (void)hipStreamSynchronize(p->stream);
+      for (auto& q : p->aux) (void)hipStreamSynchronize(q);
+      return rc;
+    }
   }
   p->have_means = true;
   if (!(flags & GCWT_OUT_ON_DEVICE)) {
@@ -1376,6 +1425,11 @@ int gcwt_debug_scale_theta_lo(const gcwt_plan* p, double* theta_lo) {
   if (!p || !theta_lo) return set_err(GCWT_ERR_INVALID, "NULL argument");
   for (size_t i = 0; i < p->hp.scales.size(); ++i) theta_lo[i] = p->hp.scales[i].theta_lo;
   return GCWT_OK;
+}
+
+int gcwt_debug_graph_state(const gcwt_plan* p) {
+  if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  return p->graph_failed ? -1 : p->graph_exec ? 1 : 0;
 }
 
 int gcwt_debug_blockconv_groups(const gcwt_plan* p, int32_t* first, int32_t* count, int32_t* hop, int32_t* back,

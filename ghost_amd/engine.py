@@ -256,6 +256,10 @@ class CwtPlan:
                         "nblk": nb.value, "m": m.value, "band_shift": sh.value, "low_cut": cut.value})
         return res
 
+    def debug_graph_state(self):
+        """1: executes replay a HIP graph, 0: not (yet), -1: capture failed, eager from then on."""
+        return int(lib.gcwt_debug_graph_state(self._handle))
+
     def debug_blockconv(self):
         """Groups of the block-convolution scales: [{"scales": rows in order of kernel length, "hop", "back"}]."""
         i32p = C.POINTER(C.c_int32)

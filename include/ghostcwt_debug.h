@@ -37,6 +37,9 @@ int gcwt_debug_level_band_shift(const gcwt_plan* plan, int level, int32_t* shift
  * which its exact response stays under 2e-8 of its peak. */
 int gcwt_debug_level_low_cut(const gcwt_plan* plan, int level, double* theta_cut);
 int gcwt_debug_scale_theta_lo(const gcwt_plan* plan, double* theta_lo);
+/* Small device-resident executes replay a HIP graph from the third call with the same arguments on: 1 = a graph is
+ * instantiated, 0 = none (yet), -1 = capture failed once and the plan runs eagerly. */
+int gcwt_debug_graph_state(const gcwt_plan* plan);
 /* Block convolution (GCWT_SCALE_BLOCKCONV): the scales in order of kernel length (`order`, n_blockconv entries)
  * and the groups of consecutive entries that share the spectra of their blocks: blocks of `hop` output
  * samples from the 4096 recording samples that start `back` before them.  Returns the number of groups. */

@@ -635,6 +635,43 @@ def test_blockconv_path_lengths_epochs_modes_and_ranges(option):
     assert rel_err(old.execute(x), got).max() < 3e-6
 
 
+def test_small_device_resident_executes_replay_a_graph(option):
+    """Config 1's shape is launch-bound (fifteen kernels of microseconds): the second device-resident execute with the
+    same arguments is captured into a HIP graph (api.cpp: execute_range) and later ones replay it.  The replay must
+    read the buffers as they are at the time -- new samples through the same pointers -- serve block requests and two
+    epochs, and give what the eager path gives, bit for bit."""
+    from ghost_amd.engine import CwtPlan, DeviceBuffer
+    from ghost_amd.synthetic import lfp
+    fs, n, C = 1000.0, 16384, 2
+    f = 200.0 / 2.0 ** (np.arange(32) / 6.0)
+    eb = np.array([[0, 9000], [9003, n]])
+    xs = [lfp(C, n, fs, seed=s) for s in (1, 2, 3)]
+    eager = []
+    option("graphs", 0)
+    p0 = CwtPlan(n, C, fs, f, epoch_bounds=eb, output="amplitude")
+    for x in xs:
+        eager.append(p0.execute(x))
+    blk0 = p0.execute_block(xs[2], 5000, 7000)
+    option("graphs", None)
+    p = CwtPlan(n, C, fs, f, epoch_bounds=eb, output="amplitude")
+    xb, ob = DeviceBuffer(4 * C * n), DeviceBuffer(p.info["out_bytes"])
+    for rep in range(2):
+        for x, want in zip(xs, eager):                      # execute 1 eager, 2 captured, 3 .. 6 replayed
+            xb.upload(x)
+            p.execute_device(xb, ob)
+            np.testing.assert_array_equal(ob.download((C, 32, n), np.float32), want)
+    assert p.debug_graph_state() == 1 and p0.debug_graph_state() == 0
+    ref = np.stack([orc.cwt_amplitude(xs[2][c].astype(np.float64), fs, f, eb) for c in range(C)])
+    assert rel_err(ob.download((C, 32, n), np.float32), ref).max() < TOL
+    bb = DeviceBuffer(4 * C * 32 * 7000)
+    for _ in range(4):                                        # another key: eager, captured, replayed
+        p.execute_block_device(xb, bb, 5000, 7000)
+        np.testing.assert_array_equal(bb.download((C, 32, 7000), np.float32), blk0)
+    p.execute_device(xb, ob)                                  # back to the first key
+    np.testing.assert_array_equal(ob.download((C, 32, n), np.float32), eager[2])
+    xb.free(); ob.free(); bb.free()
+
+
 def test_blockconv_many_epochs(option):
     """Forty epochs (more than one launch's sixteen), from 9 samples to several blocks long, gaps between them,
     both precisions: every epoch is convolved on its own, zero outside (transforms.py:185, convolution.py:68-87)."""
