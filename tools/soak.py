@@ -2,7 +2,8 @@
 epochs with gaps, sampling rates, frequency ranges down to large decimations, forced time
 blocks, output modes, block requests).  Prints the worst relative error per case; exits
 non-zero on the first case over the 1e-5 gate.  SOAK_N cases (default 60), SOAK_SEED;
-SOAK_EXACT=1: most cases with precision = 'exact'; SOAK_BIG=1 adds recordings of up to 2.5 M samples (FFT lengths up to 2^22); SOAK_DETAIL=3e-6 prints the
+SOAK_GRAPH=1: small cases also run device-resident four times (graph replay) and must
+reproduce the host result bit for bit; SOAK_EXACT=1: most cases with precision = 'exact'; SOAK_BIG=1 adds recordings of up to 2.5 M samples (FFT lengths up to 2^22); SOAK_DETAIL=3e-6 prints the
 per-scale errors of every case above that."""
 import os, sys, time; sys.path.insert(0, '.')
 import numpy as np
@@ -94,6 +95,16 @@ for case in range(n_cases):
     blk = p.execute_block(x, a, ln)
     same = np.array_equal(blk, got[:, :, a:a + ln])
     si = p.scale_info()
+    if os.environ.get("SOAK_GRAPH") and got.size <= 1 << 24 and p.info["n_fullband"] == 0:
+        # small plans replay a HIP graph from the third device-resident execute on: the same numbers, bit for bit
+        from ghost_amd.engine import DeviceBuffer
+        xb, ob = DeviceBuffer(x.nbytes), DeviceBuffer(p.info["out_bytes"])
+        xb.upload(x)
+        for _ in range(4):
+            p.execute_device(xb, ob)
+        dev = ob.download(got.shape, got.dtype)
+        same = same and np.array_equal(dev, got) and p.debug_graph_state() == 1
+        xb.free(); ob.free()
     tol = 2 * TOL if output == "power" else TOL
     print("case %2d: %-5s fs %7.0f ch %d n %6d ep %d g,b %g,%4g scales %d R<=%5d direct %d blocks %d full %d segs %3d %-9s err %.2e block %s" %
           (case, kind, fs, n_ch, n, len(eb), gamma, beta, f.size, si["decimation"].max(), int((si["method"] == 1).sum()),
