@@ -126,9 +126,10 @@ struct gcwt_plan {
   double* d_amps = nullptr;   // kept spectrum samples A_j of every scale (planner.h: amps)
   float2* d_xs = nullptr;     // [C][xs_stride] shifted slice of the spectrum of the level in hand (levels with a
   int64_t xs_stride = 0;      //   band shift: heavy-tailed wavelets); xs_stride = the largest such level's M
-  float2* d_z = nullptr;      // [2][slots][max_p]  full-band scales, two at a time: row-transformed spectrum * response
-  int64_t z_half = 0;         //              elements between the pair's two halves
-  float2* d_hfull = nullptr;  // [2][max_p]   full-band responses of the scales in hand (when the cache below is full)
+  float2* d_z = nullptr;      // [z_sets][slots][max_p]  full-band scales, up to four at a time: row-transformed spectrum * response
+  int64_t z_half = 0;         //              elements between two of the set
+  int z_sets = 1;
+  float2* d_hfull = nullptr;  // [z_sets][max_p]  full-band responses of the scales in hand (when the cache below is full)
   // Full-band responses are an O(n_bins P) fp64 evaluation each: computed once per (scale, FFT
   // length) and kept on the device while they fit 4 GiB, reused by every later batch and execute.
   std::map<std::pair<int, int>, float2*> hfull_cache;
@@ -478,10 +479,10 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     // one slice buffer per stream the level passes run on (run_pipeline: three streams)
     if (p->xs_stride > 0 && (rc = dev_alloc(&p->d_xs, (size_t)(3 * slots * p->xs_stride)))) return bail(rc);
     if (hp.n_fullband > 0) {
-      const int pairs = hp.n_fullband > 1 ? 2 : 1;      // two scales share a pass over X
+      p->z_sets = std::min(hp.n_fullband, kFullbandSet);   // that many scales share a pass over X
       p->z_half = slots * hp.max_p;
-      if ((rc = dev_alloc(&p->d_z, (size_t)(pairs * p->z_half)))) return bail(rc);
-      if ((rc = dev_alloc(&p->d_hfull, (size_t)(pairs * hp.max_p)))) return bail(rc);
+      if ((rc = dev_alloc(&p->d_z, (size_t)(p->z_sets * p->z_half)))) return bail(rc);
+      if ((rc = dev_alloc(&p->d_hfull, (size_t)(p->z_sets * hp.max_p)))) return bail(rc);
     }
   }
   if (he_sync_tables && hipStreamSynchronize(p->stream) != hipSuccess)      // the host table went out of scope
@@ -541,12 +542,10 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   }
   if ((rc = upload_vec(&p->d_bank_sc, bsc, p->stream))) return bail(rc);
   if ((rc = upload_vec(&p->d_direct_sc, dsc, p->stream))) return bail(rc);
-  if (hp.n_blockconv > 0) {
-    std::vector<int32_t> rows(hp.bc_order.begin(), hp.bc_order.end());
-    if ((rc = upload_vec(&p->d_bc_rows, rows, p->stream))) return bail(rc);
-    if ((rc = dev_alloc(&p->d_bc_h, (size_t)hp.n_blockconv * kRowLen))) return bail(rc);
-    if ((rc = dev_alloc(&p->d_bc_x, (size_t)(hp.bc_chunk_blocks * C) * kRowLen))) return bail(rc);
-    std::vector<float2> twt(kRowLen);                 // the values k_fullband_rows takes from tw4096, per thread
+  if (hp.n_blockconv > 0 || hp.n_fullband > 0) {
+    // W_4096^(+(t + 16 j) a) at [256 j + 16 t + a]: the middle twiddles of the 4096-point inverse transforms of
+    // k_bc_scales and k_fullband_rows as each thread meets them (the values tw4096_at<+1> gives)
+    std::vector<float2> twt(kRowLen);
     for (int j = 0; j < 16; ++j)
       for (int tid = 0; tid < 256; ++tid) {
         const int idx = (((tid >> 4) + 16 * j) * (tid & 15)) & (kRowLen - 1);
@@ -556,6 +555,12 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       }
     if ((rc = upload_vec(&p->d_bc_tw, twt, p->stream))) return bail(rc);
     HIP_TRY(hipStreamSynchronize(p->stream));         // `twt` goes out of scope
+  }
+  if (hp.n_blockconv > 0) {
+    std::vector<int32_t> rows(hp.bc_order.begin(), hp.bc_order.end());
+    if ((rc = upload_vec(&p->d_bc_rows, rows, p->stream))) return bail(rc);
+    if ((rc = dev_alloc(&p->d_bc_h, (size_t)hp.n_blockconv * kRowLen))) return bail(rc);
+    if ((rc = dev_alloc(&p->d_bc_x, (size_t)(hp.bc_chunk_blocks * C) * kRowLen))) return bail(rc);
     if (!p->d_tw64) {
       std::vector<double2> tw(8192);
       fwd64_fill_tables(tw.data());
@@ -1065,30 +1070,31 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       return GCWT_OK;
     };
     for (int i = 0; i < S && hp.n_fullband > 0;) {
-      int pair[2], np = 0;
-      for (; i < S && np < 2; ++i)
-        if (hp.scales[i].method == GCWT_SCALE_FULLBAND) pair[np++] = i;
+      int member[kFullbandSet], np = 0;
+      for (; i < S && np < p->z_sets; ++i)
+        if (hp.scales[i].method == GCWT_SCALE_FULLBAND) member[np++] = i;
       if (np == 0) break;
-      const float2* h[2] = {nullptr, nullptr};
-      float2* z[2] = {p->d_z, np > 1 ? p->d_z + p->z_half : nullptr};
+      FullbandSet set{};
+      set.n = np;
       for (int k = 0; k < np; ++k) {
-        const int rc_ = response(pair[k], k, &h[k]);
+        set.z[k] = p->d_z + (int64_t)k * p->z_half;
+        const int rc_ = response(member[k], k, &set.h[k]);
         if (rc_) return rc_;
       }
       // inverse: rows over k2 of the products X H with the W_P^(k1 n2) twiddle, then columns over k1 ->
-      // natural order; the usual FFT lengths store from the column pass's registers (3.2 GB of traffic per
+      // natural order; the usual FFT lengths store from the column pass's registers (2.9 GB of traffic per
       // scale at the headline shape; product, two passes and a store kernel moved 8)
-      RUN(ST_FULLBAND, launch_fullband_rows(p->d_x, h[0], h[1], z[0], z[1], P1, P, P, p->d_tw4096, p->d_tw256,
-                                            slots, st, (int)option_or("fullband_group", 0)));
+      RUN(ST_FULLBAND, launch_fullband_rows(p->d_x, set, P1, P, P, p->d_bc_tw, p->d_tw256, slots, st,
+                                            (int)option_or("fullband_group", 0)));
       for (int k = 0; k < np; ++k) {
         if (fullband_cols_fused(P1)) {
-          RUN(ST_FULLBAND, launch_fullband_cols(mode, z[k], dout, P1, P, p->d_tw4096, p->d_tw256, pair[k], S,
+          RUN(ST_FULLBAND, launch_fullband_cols(mode, set.z[k], dout, P1, P, p->d_tw4096, p->d_tw256, member[k], S,
                                                 row_len, sout, slots, st));
         } else {
           if (P1 > 1)
-            RUN(ST_FULLBAND, launch_fft_cols(+1, false, z[k], z[k], P1, kRowLen, P, P, 0, p->d_tw4096,
+            RUN(ST_FULLBAND, launch_fft_cols(+1, false, set.z[k], set.z[k], P1, kRowLen, P, P, 0, p->d_tw4096,
                                              p->d_tw256, p->d_sums, inv_n, 0, slots, st));
-          RUN(ST_FULLBAND, launch_fullband_store(mode, z[k], dout, P, pair[k], S, row_len, sout, nb, st));
+          RUN(ST_FULLBAND, launch_fullband_store(mode, set.z[k], dout, P, member[k], S, row_len, sout, nb, st));
         }
       }
     }

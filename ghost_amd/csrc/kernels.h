@@ -197,10 +197,18 @@ hipError_t launch_fullband_filter(float2* h, const BankScale* sc, int scale, con
                                   int p1, hipStream_t st);
 hipError_t launch_fullband_mul(const float2* x, const float2* h, float2* z, int64_t p, int n_slots,
                                hipStream_t st);
-// the fused passes: rows of X * H for one or two scales (h1, z1 may be null) (pass 1), columns + crop + |.| + store (pass 2; p1 = 256, 512, 1024)
-hipError_t launch_fullband_rows(const float2* x, const float2* h0, const float2* h1, float2* z0, float2* z1,
-                                int p1, int64_t x_cstride, int64_t z_cstride, const float2* tw4096,
-                                const float2* tw256, int n_slots, hipStream_t st, int group = 0);
+// the fused passes: rows of X * H for up to four scales per pass over X (pass 1), columns + crop + |.| + store
+// (pass 2; p1 = 256, 512, 1024)
+constexpr int kFullbandSet = 4;
+struct FullbandSet {
+  const float2* h[kFullbandSet];     // responses, k1-major like one slot of x
+  float2* z[kFullbandSet];           // [slots][P] each
+  int32_t n, pad;
+};
+// twt[256 j + 16 t + a] = exp(+2 pi i (t + 16 j) a / 4096), as for launch_bc_scales
+hipError_t launch_fullband_rows(const float2* x, const FullbandSet& set, int p1, int64_t x_cstride, int64_t z_cstride,
+                                const float2* twt, const float2* tw256, int n_slots, hipStream_t st,
+                                int group = 0);
 bool fullband_cols_fused(int p1);
 hipError_t launch_fullband_cols(int mode, const float2* z, float* out, int p1, int64_t z_cstride,
                                 const float2* tw4096, const float2* tw256, int scale, int n_scales,

@@ -789,15 +789,13 @@ __global__ void __launch_bounds__(256, 2) k_fft_colsq(const void* __restrict__ i
 }
 
 // ---- the full-band path's two fused passes (exact.hip describes the path) -------------------------------
-// Pass 1: Z_s = IFFT rows of (X * H_s) for one or two scales: the 4096-point inverse row pass of
-// rows_fast_body<+1, 4> with the product folded into its loads; a row of X is read once for both scales.
+// Pass 1: Z_s = IFFT rows of (X * H_s) for up to four scales: the 4096-point inverse row pass of
+// rows_fast_body<+1, 4> with the product folded into its loads; a row of X is read once for all of them.
 // grid (slots * P1): workgroup id -> (row % group, slot, row / group), so that the workgroups that run together
 // share `group` rows of H (32 KB each, L2) without all of them reading the same offset of 8 MB-strided slots
-__global__ void __launch_bounds__(256, 2) k_fullband_rows(const cf* __restrict__ in, const cf* __restrict__ h0,
-                                                       const cf* __restrict__ h1, cf* __restrict__ z0,
-                                                       cf* __restrict__ z1, int64_t in_cstride,
-                                                       int64_t out_cstride, int64_t tw_n,
-                                                       const cf* __restrict__ tw4096,
+__global__ void __launch_bounds__(256, 2) k_fullband_rows(const cf* __restrict__ in, const FullbandSet set,
+                                                       int64_t in_cstride, int64_t out_cstride, int64_t tw_n,
+                                                       const cf* __restrict__ twt,
                                                        const cf* __restrict__ tw256, int n_slots, int group) {
   __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
   float* const ex_re = reinterpret_cast<float*>(buf) + (threadIdx.x & 15) * kExColD;
@@ -824,12 +822,11 @@ __global__ void __launch_bounds__(256, 2) k_fullband_rows(const cf* __restrict__
     st = v2f{p1.x, p1.y};
   }
   v2f* const bufv = reinterpret_cast<v2f*>(buf);
+  const v2f* const tws = reinterpret_cast<const v2f*>(twt) + tid;
   // the three radix-16 layers are synth_math.h's packed idft16v, as in k_bc_scales (output k in register dft16_pos(k))
-  for (int sel = 0; sel < 2; ++sel) {
-    const cf* __restrict__ h = sel ? h1 : h0;
-    if (!h) break;
-    const v2f* __restrict__ hs = reinterpret_cast<const v2f*>(h) + at;
-    v2f* __restrict__ o = reinterpret_cast<v2f*>(sel ? z1 : z0) + (int64_t)slot * out_cstride + (int64_t)row * kRowLenDev;
+  for (int sel = 0; sel < set.n; ++sel) {
+    const v2f* __restrict__ hs = reinterpret_cast<const v2f*>(set.h[sel]) + at;
+    v2f* __restrict__ o = reinterpret_cast<v2f*>(set.z[sel]) + (int64_t)slot * out_cstride + (int64_t)row * kRowLenDev;
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = cmulv(xv[j], hs[256 * j]);
     __syncthreads();                      // twiddle table written / the buffer's last readers done
@@ -846,10 +843,8 @@ __global__ void __launch_bounds__(256, 2) k_fullband_rows(const cf* __restrict__
     idft16v(v);
     __syncthreads();                      // the element buffer aliases the exchange planes
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const cf w = tw4096_at<1>(tw4096, (t + 16 * j) * a);
-      bufv[pad32(16 * (t + 16 * j) + a)] = cmulv(v[dft16_pos(j)], v2f{w.x, w.y});
-    }
+    for (int j = 0; j < 16; ++j)        // twt[256 j + tid] = W_4096^(+(t + 16 j) a), as in k_bc_scales
+      bufv[pad32(16 * (t + 16 * j) + a)] = cmulv(v[dft16_pos(j)], tws[256 * j]);
     __syncthreads();
 #pragma unroll
     for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[pad32(16 * tid + aa)];
@@ -1856,15 +1851,16 @@ hipError_t launch_fft_rows(int sign, const cf* in, cf* out, int len, int64_t n_r
   return hipSuccess;
 }
 
-hipError_t launch_fullband_rows(const cf* x, const cf* h0, const cf* h1, cf* z0, cf* z1, int p1,
-                                int64_t x_cstride, int64_t z_cstride, const cf* tw4096, const cf* tw256,
-                                int n_slots, hipStream_t st, int group) {
-  if (p1 < 1 || !tw4096 || !tw256 || !h0 || !z0 || (h1 && !z1)) return hipErrorInvalidValue;
+hipError_t launch_fullband_rows(const cf* x, const FullbandSet& set, int p1, int64_t x_cstride, int64_t z_cstride,
+                                const cf* twt, const cf* tw256, int n_slots, hipStream_t st, int group) {
+  if (p1 < 1 || !twt || !tw256 || set.n < 1 || set.n > kFullbandSet) return hipErrorInvalidValue;
+  for (int k = 0; k < set.n; ++k)
+    if (!set.h[k] || !set.z[k]) return hipErrorInvalidValue;
   if ((int64_t)n_slots * p1 > 0x7fffffff) return hipErrorInvalidValue;
   const int64_t p = (int64_t)p1 * kRowLenDev;
   if (group < 1 || group > p1 || p1 % group) group = p1 < 32 ? p1 : 32;   // p1 is a power of two
-  hipLaunchKernelGGL(k_fullband_rows, dim3((unsigned)(n_slots * p1)), dim3(256), 0, st, x, h0, h1, z0, z1,
-                     x_cstride, z_cstride, p1 > 1 ? p : 0, tw4096, tw256, n_slots, group);
+  hipLaunchKernelGGL(k_fullband_rows, dim3((unsigned)(n_slots * p1)), dim3(256), 0, st, x, set, x_cstride, z_cstride,
+                     p1 > 1 ? p : 0, twt, tw256, n_slots, group);
   return hipGetLastError();
 }
 

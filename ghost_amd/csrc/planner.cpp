@@ -940,7 +940,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     EpochPlan& lead = hp->epochs[first];
     int64_t blocks = 0;
     for (size_t l = 0; l < hp->levels.size(); ++l) blocks += (int64_t)lead.lv[l].nblk * B;
-    const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks + (hp->n_fullband > 1 ? 2 * lead.p : hp->n_fullband > 0 ? lead.p : 0));   // X + x_R (< P) + XB (+ Z), roughly
+    const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks + std::min(hp->n_fullband, 4) * lead.p);   // X + x_R (< P) + XB (+ Z), roughly
     int cap = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, budget / std::max<int64_t>(1, per_slot)));
     cap = (int)std::max<int64_t>(1, std::min<int64_t>(cap, 65535 / C));   // grid.y = segments * channels
     size_t count = 1;
@@ -997,7 +997,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   }
   hp->workspace_bytes = 8 * C * hp->max_batch * (hp->max_p_store + hp->max_xr + hp->max_xb)   // X, x_R, XB
                         + 8 * kRowLen * (C * hp->bc_chunk_blocks + hp->n_blockconv)             // block spectra, responses
-                        + (hp->n_fullband > 0 ? 8 * (hp->n_fullband > 1 ? 2 : 1) * (C * hp->max_batch + 1) * hp->max_p : 0)  // Z, H
+                        + 8 * std::min<int64_t>(hp->n_fullband, 4) * (C * hp->max_batch + 1) * hp->max_p  // Z, H
                         + 8 * (int64_t)hp->amps.size()
                         + 8 * (int64_t)prm.n_freqs * B                  // bank
                         + 8 * (hp->direct_total + hp->level_twiddle_total + kRowLen + 256)
