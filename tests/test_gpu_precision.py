@@ -198,7 +198,7 @@ def test_lowest_frequency_the_reference_permits_at_30_khz():
 def test_public_call_on_a_steep_spectrum():
     """`ContinuousWaveletTransform.transform()` as a user of the reference calls it, on a 1/f^3 recording with an
     offset: the float64 `amplitude` against the oracle over the grid the call builds itself (time-domain scales at the
-    top included); `precision='fast'` is accepted, and anything else is a ValueError before any work."""
+    top included); `precision='fast'` and `'exact'` are accepted, and anything else is a ValueError before any work."""
     from ghost_amd.synthetic import power_law_noise
     from ghost_amd.wave import ContinuousWaveletTransform
     fs, n = 1000.0, 200000
@@ -213,6 +213,10 @@ def test_public_call_on_a_steep_spectrum():
     e_fast = rel_err(cwt.amplitude, ref).max()
     print("public call, 1/f^3 + offset: high %.2e fast %.2e" % (e_high, e_fast))
     assert e_fast > 3 * e_high                                 # the float32 front end: what the default avoids
+    cwt.transform(x, fs=fs, freq_limits=[2, 380], voices_per_octave=4, precision="exact")
+    e_exact = rel_err(cwt.amplitude, ref).max()
+    print("                              exact %.2e" % e_exact)
+    assert e_exact < 2e-6                                      # no decimated path: block convolution + full band
     with pytest.raises(ValueError):
         cwt.transform(x, fs=fs, precision="double")
 
