@@ -1040,7 +1040,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       if (he != hipSuccess) return hip_err(he, "synthesis join");
     }
     if (p->profiling && !hp.levels.empty()) p->last.synth_launches++;
-    // full-band scales: W = IFFT_P(X H_s) for every slot of the batch, two scales per pass over X
+    // full-band scales: W = IFFT_P(X H_s) for every slot of the batch, up to four scales per pass over X
     auto response = [&](int i, int scratch, const float2** h_out) -> int {
       const auto cached = p->hfull_cache.find({i, P1});
       if (cached != p->hfull_cache.end()) { *h_out = cached->second; return GCWT_OK; }
