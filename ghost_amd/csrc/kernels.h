@@ -271,7 +271,7 @@ hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi
                          const DirectScale* sc, int n_direct, const double* sums, double inv_n,
                          int64_t n_samples, int n_scales, const DirectEpochs& eps, int n_epochs,
                          int64_t col0, int64_t row_len, int64_t max_len, const float2* tail, hipStream_t st);
-// Block convolution (overlap-save; blockconv.hip describes the path): the blocks of up to kSegBatch epochs that
+// Block convolution (overlap-save; kernels.hip: k_bc_scales and fwd64.hip: k_bc_forward describe the path): the blocks of up to kSegBatch epochs that
 // one launch handles.  Blocks are `hop` samples long and aligned to multiples of `hop` in recording time; block
 // q of an epoch produces samples [q hop, (q + 1) hop) cut to [g_lo, g_hi) from the 4096 recording samples that
 // start at q hop - back (those outside [epoch_start, epoch_stop) read as zero).
