@@ -824,11 +824,23 @@ __global__ void __launch_bounds__(256, 2) k_fullband_rows(const cf* __restrict__
   v2f* const bufv = reinterpret_cast<v2f*>(buf);
   const v2f* const tws = reinterpret_cast<const v2f*>(twt) + tid;
   // the three radix-16 layers are synth_math.h's packed idft16v, as in k_bc_scales (output k in register dft16_pos(k))
+  // the next scale's row of H is on its way while this one's transform runs (the rows come from beyond L2: the
+  // waves sat waiting 74 % of their cycles without it)
+  v2f hc[16];
+  {
+    const v2f* __restrict__ hs = reinterpret_cast<const v2f*>(set.h[0]) + at;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) hc[j] = hs[256 * j];
+  }
   for (int sel = 0; sel < set.n; ++sel) {
-    const v2f* __restrict__ hs = reinterpret_cast<const v2f*>(set.h[sel]) + at;
     v2f* __restrict__ o = reinterpret_cast<v2f*>(set.z[sel]) + (int64_t)slot * out_cstride + (int64_t)row * kRowLenDev;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = cmulv(xv[j], hs[256 * j]);
+    for (int j = 0; j < 16; ++j) v[j] = cmulv(xv[j], hc[j]);
+    if (sel + 1 < set.n) {
+      const v2f* __restrict__ hs = reinterpret_cast<const v2f*>(set.h[sel + 1]) + at;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) hc[j] = hs[256 * j];
+    }
     __syncthreads();                      // twiddle table written / the buffer's last readers done
     idft16v(v);
 #pragma unroll
