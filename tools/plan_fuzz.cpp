@@ -3,7 +3,7 @@
 // AddressSanitizer and UBSan on the CPU (GPU sanitizers are not available on this pool).
 //   cd ghost_amd/csrc && g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer \
 //     -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I. -I../../include ../../tools/plan_fuzz.cpp planner.cpp options.cpp \
-//     -o /tmp/plan_fuzz && /tmp/plan_fuzz        (6 000 requests incl. long mode and all precisions, 3 min; round 4: clean)
+//     -o /tmp/plan_fuzz && /tmp/plan_fuzz        (6 000 requests incl. long mode, all four precisions, many-epoch layouts and the block-convolution invariants, 2 min; round 4: clean)
 #include "planner.h"
 #include <cstdio>
 #include <random>
@@ -41,7 +41,7 @@ int main() {
     prm.out_mode = (int)(rng() % 3);
     const int mf[] = {0, 0, 12, 13, 14, 16, 21, 23, 24};          // 23 / 24: long mode (round 4)
     prm.max_fft_log2 = mf[rng() % 9];
-    prm.precision = (int)(rng() % 3);                              // default / fast / high: low cut, ramps, full support
+    prm.precision = (int)(rng() % 4);                              // default / fast / high / exact: low cut, ramps, full support, no decimated path
     if (rng() % 8 == 0) prm.support_tol = 1e-7;
     gcwt::HostPlan hp;
     std::string err;
