@@ -1137,8 +1137,9 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       auto flush = [&]() -> int {
         bl.n_epochs = ne;
         const int total = ne > 0 ? bl.blk_first[ne] : 0;
-        for (int b0 = 0; b0 < total; b0 += (int)hp.bc_chunk_blocks) {
-          const int nblk = (int)std::min<int64_t>(hp.bc_chunk_blocks, total - b0);
+        const int chunk = (int)std::max<int64_t>(2, hp.bc_chunk_blocks & ~(int64_t)1);
+        for (int b0 = 0; b0 < total; b0 += chunk) {
+          const int nblk = std::min(chunk, total - b0);
           RUN(ST_BLOCKCONV, launch_bc_forward(dx, p->d_bc_x, bl, b0, nblk, N, p->d_tw64, p->d_sums, inv_n, st));
           RUN(ST_BLOCKCONV, launch_bc_scales(mode, p->d_bc_x, dout, p->d_bc_h + (int64_t)g.first * kRowLen,
                                              p->d_bc_rows + g.first, g.count, p->d_bc_tw, p->d_tw256, bl, b0, nblk,
@@ -1151,7 +1152,9 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         const int64_t e0 = hp.bounds[i], e1 = hp.bounds[i + 1];
         const int64_t g_lo = std::max(e0, r0), g_hi = std::min(e1, r1);
         if (g_hi <= g_lo) continue;
-        const int64_t blocks = (g_hi - 1) / g.hop - g_lo / g.hop + 1;
+        // whole pairs of blocks, even-aligned in recording time: the forward transform carries two blocks at a
+        // time, and which two must not depend on the range asked for (execute_block gives execute's bits)
+        const int64_t blocks = (((g_hi - 1) / g.hop) | 1) - ((g_lo / g.hop) & ~(int64_t)1) + 1;
         if (ne > 0 && (int64_t)bl.blk_first[ne] + blocks > (1 << 30)) { int rc_ = flush(); if (rc_) return rc_; }
         if (ne == 0) bl.blk_first[0] = 0;
         bl.epoch_start[ne] = e0;

@@ -438,7 +438,7 @@ __device__ __forceinline__ BcWindow bc_window(const BcBlocks& bl, int blk) {
   int e = 0;
   while (e + 1 < bl.n_epochs && blk >= bl.blk_first[e + 1]) ++e;
   BcWindow w;
-  w.in0 = (bl.g_lo[e] / bl.hop + (blk - bl.blk_first[e])) * bl.hop - bl.back;
+  w.in0 = (((bl.g_lo[e] / bl.hop) & ~(int64_t)1) + (blk - bl.blk_first[e])) * bl.hop - bl.back;   // kernels.h: BcBlocks
   w.e0 = bl.epoch_start[e];
   w.e1 = bl.epoch_stop[e];
   return w;

@@ -274,7 +274,9 @@ hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi
 // Block convolution (overlap-save; kernels.hip: k_bc_scales and fwd64.hip: k_bc_forward describe the path): the blocks of up to kSegBatch epochs that
 // one launch handles.  Blocks are `hop` samples long and aligned to multiples of `hop` in recording time; block
 // q of an epoch produces samples [q hop, (q + 1) hop) cut to [g_lo, g_hi) from the 4096 recording samples that
-// start at q hop - back (those outside [epoch_start, epoch_stop) read as zero).
+// start at q hop - back (those outside [epoch_start, epoch_stop) read as zero).  An epoch's blocks run from
+// (g_lo / hop) & ~1 to ((g_hi - 1) / hop) | 1: whole even-aligned pairs, as the forward transform takes them
+// whatever range is asked for (execute_block must give execute's bits).
 struct BcBlocks {
   int64_t epoch_start[kSegBatch], epoch_stop[kSegBatch];
   int64_t g_lo[kSegBatch], g_hi[kSegBatch];     // samples of the recording to produce

@@ -993,7 +993,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     int min_hop = kRowLen;
     for (const HostPlan::BcGroup& g : hp->bc_groups) min_hop = std::min(min_hop, g.hop);
     const int64_t most = prm.n_samples / min_hop + 2 * (int64_t)n_ep + 1;
-    hp->bc_chunk_blocks = std::max<int64_t>(1, std::min<int64_t>(most, ((int64_t)1 << 30) / (8 * kRowLen * C)));
+    hp->bc_chunk_blocks = std::max<int64_t>(2, std::min<int64_t>(most + 2, ((int64_t)1 << 30) / (8 * kRowLen * C)) & ~(int64_t)1);   // whole pairs
   }
   hp->workspace_bytes = 8 * C * hp->max_batch * (hp->max_p_store + hp->max_xr + hp->max_xb)   // X, x_R, XB
                         + 8 * kRowLen * (C * hp->bc_chunk_blocks + hp->n_blockconv)             // block spectra, responses

@@ -672,6 +672,30 @@ def test_small_device_resident_executes_replay_a_graph(option):
     xb.free(); ob.free(); bb.free()
 
 
+def test_blockconv_blocks_pair_the_same_way_for_any_range(option):
+    """The forward transform of the block convolution carries two real blocks at a time; which two must not depend
+    on the range a call asks for, or execute_block differs from execute in a last bit now and then (soak seed 831,
+    case 185: three epochs, power, precision='exact', block request 13952 + 34449).  Blocks are paired even-aligned in
+    recording time (kernels.h: BcBlocks)."""
+    from ghost_amd.engine import CwtPlan
+    fs, n = 1000.0, 70000
+    rng = np.random.default_rng(831)
+    spec = np.fft.rfft(rng.standard_normal((3, n)), axis=1)
+    x = (np.fft.irfft(spec / np.maximum(np.arange(spec.shape[1]), 1.0) ** 1.5, n=n, axis=1) * 40 + 7.0).astype(np.float32)
+    eb = np.array([[2, 9458], [9460, 50145], [50146, 50545]])
+    f = np.array([342.3177436147193, 336.88327324365497, 186.76392799751358, 148.86165586583928, 135.53799461991628,
+                  123.2482109509881])
+    option("direct_max_len", 48)
+    for precision in ("exact", "high"):
+        kw = dict(gamma=3.0, beta=20.0) if precision == "exact" else dict(gamma=3.0, beta=3.0)
+        ff = f if precision == "exact" else np.array([120.0, 47.0, 19.0, 8.0, 4.0])
+        p = CwtPlan(n, 3, fs, ff, epoch_bounds=eb, output="power", precision=precision, **kw)
+        assert p.info["n_blockconv"] >= 4
+        got = p.execute(x)
+        for a, ln in [(13952, 34449), (1, 9457), (9459, 3), (3329, 3328), (6655, 50000), (50146, 399), (0, n)]:
+            np.testing.assert_array_equal(p.execute_block(x, a, ln), got[:, :, a:a + ln])
+
+
 def test_blockconv_many_epochs(option):
     """Forty epochs (more than one launch's sixteen), from 9 samples to several blocks long, gaps between them,
     both precisions: every epoch is convolved on its own, zero outside (transforms.py:185, convolution.py:68-87)."""

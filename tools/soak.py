@@ -116,7 +116,7 @@ for case in range(n_cases):
         print("   epochs", eb, "kw", {k: v for k, v in kw.items() if k != "epoch_bounds"}, flush=True)
     worst = max(worst, err / (tol / TOL))
     if err > tol or not same:
-        print("FAILED", dict(fs=fs, n=n, eb=eb, f=f.tolist(), kw=kw))
+        print("FAILED", dict(fs=fs, n=n, eb=eb, f=f.tolist(), kw=kw, block=(a, ln), gamma_beta=(gamma, beta)))
         sys.exit(1)
     p.close()
 print("worst %.2e over %d cases in %.0f s" % (worst, n_cases, time.time() - t_start))
