@@ -113,7 +113,7 @@ typedef struct {
  * its peak) before the float32 stages: content BELOW the analysed bands (drift, offsets, 1/f^n
  * backgrounds) up to ~1000 x the quietest band still meets 1e-5 (FAST: ~65 x).  Interference INSIDE a
  * level's band (a mains line between its scales) is good to ~65 x in both (profiles/r04_dynamic_range.md);
- * EXACT below lifts both limits at 3.8 x the time.  FAST: float32 throughout (rounds 1-3). */
+ * EXACT below lifts both limits at 3.4 x the time.  FAST: float32 throughout (rounds 1-3). */
 typedef enum {
   GCWT_PRECISION_DEFAULT = 0,
   GCWT_PRECISION_FAST = 1,
@@ -123,7 +123,7 @@ typedef enum {
                               * the float32 stages after them only ever see what the scale's own filter lets
                               * through, so an error stays relative to the scale's own output whatever else the
                               * recording holds: a mains line or a drift 1e4 x the recording's std reads 5e-7 /
-                              * 2e-6 (profiles/r04_dynamic_range.md).  3.8 x the time of HIGH on the default
+                              * 2e-6 (profiles/r04_dynamic_range.md).  3.4 x the time of HIGH on the default
                               * wavelet at the headline shape. */
 } gcwt_precision;
 
