@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cmath>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 
 namespace gcwt {
 
@@ -308,7 +310,7 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
 // the interpolation adds: max over bins of |G_s[k]| / peak times the interpolator's error at that
 // bin's distance from the demodulation centre.  A level whose bound exceeds interp_tol stays on
 // the FFT-per-sample kernels.
-static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp) {
+static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp, std::vector<float>* coef_out) {
   constexpr int T = kInterpTaps;
   const int B = hp->block, R = lp->decimation;
   lp->interp_q = 0;
@@ -378,15 +380,18 @@ static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp) {
     static std::map<std::vector<float>, std::vector<double>> cache;
     std::vector<float> key{(float)T, (float)I, (float)q, (float)B};
     for (double v : genv) key.push_back((float)v);
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(key);
-    if (it == cache.end()) {
+    bool hit = false;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = cache.find(key);
+      if (it != cache.end()) { c = it->second; hit = true; }
+    }
+    if (!hit) {                           // (outside the lock: the levels of a plan are designed side by side)
       design_interp_weighted(T, I, q, B, genv.data(), 0.0, c.data());
       design_interp_weighted(T, I, q, B, genv.data(), 0.5, c.data() + (size_t)I * T);
+      std::lock_guard<std::mutex> lock(mu);
       if (cache.size() >= 64) cache.clear();
       cache.emplace(std::move(key), c);
-    } else {
-      c = it->second;
     }
   }
   // the tables the kernel uses are float32: bound the error with what it will multiply by
@@ -419,8 +424,8 @@ static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp) {
   if (!(bound <= hp->interp_tol)) return;
   lp->interp_q = q;
   lp->interp_factor = I;
-  lp->coef_offset = (int64_t)hp->interp_coef.size();
-  for (double v : c) hp->interp_coef.push_back((float)v);
+  lp->coef_offset = 0;                    // within coef_out: the caller places it in HostPlan::interp_coef
+  for (double v : c) coef_out->push_back((float)v);
 }
 
 // The same levels come back with every plan of a recording (ContinuousWaveletTransform.transform() makes one per
@@ -436,7 +441,7 @@ struct InterpDesign {
 };
 }  // namespace
 
-static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
+static void plan_interp_level(HostPlan* hp, LevelPlan* lp, std::vector<float>* coef_out) {
   static std::mutex mu;
   static std::map<std::vector<double>, InterpDesign> cache;
   std::vector<double> key{(double)hp->block, (double)lp->decimation, (double)lp->band_shift, (double)hp->prm.out_mode,
@@ -454,17 +459,17 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp) {
       lp->interp_err = d.err;
       for (size_t n = 0; n < lp->scales.size() && n < d.demod.size(); ++n) hp->scales[lp->scales[n]].demod_bin = d.demod[n];
       if (!d.coef.empty()) {
-        lp->coef_offset = (int64_t)hp->interp_coef.size();
-        hp->interp_coef.insert(hp->interp_coef.end(), d.coef.begin(), d.coef.end());
+        lp->coef_offset = 0;
+        *coef_out = d.coef;
       }
       return;
     }
   }
-  const size_t before = hp->interp_coef.size();
-  plan_interp_level_uncached(hp, lp);
+  plan_interp_level_uncached(hp, lp, coef_out);
   InterpDesign d{lp->interp_q, lp->interp_factor, lp->interp_alpha, lp->interp_err, {}, {}};
   for (int sidx : lp->scales) d.demod.push_back(hp->scales[sidx].demod_bin);
-  if (lp->interp_q > 0) d.coef.assign(hp->interp_coef.begin() + (std::ptrdiff_t)before, hp->interp_coef.end());
+  if (lp->interp_q > 0) d.coef = *coef_out;
+  else coef_out->clear();
   std::lock_guard<std::mutex> lock(mu);
   if (cache.size() >= 256) cache.clear();
   cache.emplace(std::move(key), std::move(d));
@@ -895,8 +900,30 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   }
   // GHOSTCWT_INTERP=0: every level on the FFT-per-sample kernels (A/B runs, tests)
   {
-    if (option_or("interp", 1) != 0)
-      for (LevelPlan& lp : hp->levels) plan_interp_level(hp, &lp);
+    if (option_or("interp", 1) != 0) {
+      // The levels' designs are independent (each writes its own LevelPlan and the demodulation bins of its own
+      // scales) and are most of a first plan's host time (config 5: 120 ms): side by side on up to eight threads,
+      // their tables appended in level order afterwards
+      const size_t nl = hp->levels.size();
+      std::vector<std::vector<float>> coef(nl);
+      const unsigned n_thr = (unsigned)std::min<size_t>(nl, std::min<unsigned>((unsigned)std::max<long long>(1, option_or("plan_threads", 8)), std::max(1u, std::thread::hardware_concurrency())));
+      if (n_thr <= 1) {
+        for (size_t l = 0; l < nl; ++l) plan_interp_level(hp, &hp->levels[l], &coef[l]);
+      } else {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned k = 0; k < n_thr; ++k)
+          pool.emplace_back([&]() {
+            for (size_t l = next++; l < nl; l = next++) plan_interp_level(hp, &hp->levels[l], &coef[l]);
+          });
+        for (std::thread& t : pool) t.join();
+      }
+      for (size_t l = 0; l < nl; ++l) {
+        if (hp->levels[l].interp_q <= 0 || coef[l].empty()) continue;
+        hp->levels[l].coef_offset = (int64_t)hp->interp_coef.size();
+        hp->interp_coef.insert(hp->interp_coef.end(), coef[l].begin(), coef[l].end());
+      }
+    }
   }
 
   // long mode (FFT lengths 2^23, 2^24): what the combined low half of the spectrum can serve

@@ -468,6 +468,33 @@ def test_planner_measures_each_wavelet():
     assert (q.scale_info()["method"] == _lib.SCALE_SPECTRAL).sum() >= 30
 
 
+def test_level_designs_side_by_side_equal_one_after_the_other(option):
+    """The interpolation designs of a plan's levels run on up to eight threads (planner.cpp): same tables, bounds and
+    demodulation bins as one after the other.  (The design caches are per process: beta differs in its last digits.)"""
+    from ghost_amd.engine import CwtPlan
+    plans = []
+    f = np.geomspace(480.0, 1.1, 190)
+    for threads in (1, 8):
+        option("plan_threads", threads)
+        beta = 21.0 * (1.0 + 4e-14 * threads)        # a fresh cache key, the same design to twelve digits
+        plans.append(CwtPlan(18000000, 4, 30000.0, f, gamma=3.0, beta=beta))
+    a, b = (p.debug_interp() for p in plans)
+    np.testing.assert_array_equal(a["demod"], b["demod"])
+    made = 0
+    for la, lb in zip(a["levels"], b["levels"]):
+        assert (la is None) == (lb is None)
+        if la is None:
+            continue
+        made += 1
+        assert la["q"] == lb["q"] and la["factor"] == lb["factor"]
+        np.testing.assert_allclose(la["coef"], lb["coef"], rtol=0, atol=1e-6)
+        # (the bound is taken with the float32-rounded tables: a coefficient that rounds the other way moves a bound of
+        # 6e-8 by up to 15 %, between two runs one after the other just as well)
+        assert abs(la["err_bound"] - lb["err_bound"]) <= 0.3 * la["err_bound"]
+    assert made >= 6
+    np.testing.assert_array_equal(plans[0].scale_info()["decimation"], plans[1].scale_info()["decimation"])
+
+
 def test_exact_precision_plans_no_decimated_scale():
     """precision='exact' (ghostcwt.h: GCWT_PRECISION_EXACT): the default wavelet's scales all go through the block
     convolution or the full-band path; 'high' stays the default; other values are refused."""

@@ -3,16 +3,18 @@
 // AddressSanitizer and UBSan on the CPU (GPU sanitizers are not available on this pool).
 //   cd ghost_amd/csrc && g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer \
 //     -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I. -I../../include ../../tools/plan_fuzz.cpp planner.cpp options.cpp \
-//     -o /tmp/plan_fuzz && /tmp/plan_fuzz        (6 000 requests incl. long mode, all four precisions, many-epoch layouts and the block-convolution invariants, 2 min; round 4: clean)
+//     -o /tmp/plan_fuzz && /tmp/plan_fuzz        (-fsanitize=thread with PLAN_FUZZ_N=400 for the level designs' threads; 6 000 requests incl. long mode, all four precisions, many-epoch layouts and the block-convolution invariants, 2 min; round 4: clean)
 #include "planner.h"
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <algorithm>
 #include <cmath>
 int main() {
   std::mt19937_64 rng(7);
   int ok = 0, refused = 0, bc_plans = 0;
-  for (int it = 0; it < 6000; ++it) {
+  const int n_it = getenv("PLAN_FUZZ_N") ? atoi(getenv("PLAN_FUZZ_N")) : 6000;
+  for (int it = 0; it < n_it; ++it) {
     gcwt_params prm{};
     const double fss[] = {200.0, 1000.0, 1250.0, 30000.0};
     prm.fs = fss[rng() % 4];
