@@ -121,7 +121,15 @@ class ContinuousWaveletTransform(WaveletTransform):
 
         epoch_bounds = kwargs.pop("epoch_bounds", None)
         # (N, C) column signals from the adapter -> (C, N) rows for the device
-        x = np.ascontiguousarray(np.asarray(data).reshape(data.shape[0], -1).T, dtype=np.float32)
+        arr = np.asarray(data).reshape(data.shape[0], -1).T
+        if arr.dtype != np.float32:
+            # The reference works on a float64 copy with the global mean removed (transforms.py:142-143).  The
+            # device takes float32: wider input loses its mean here, in its own precision, so that an offset
+            # far above the signal (raw counts, a DC level of 1e7 x the fluctuation) does not cost the cast
+            # the signal's bits; the device removes what is left of the mean in float64 as it always does.
+            arr = arr.astype(np.float64, copy=False)
+            arr = arr - arr.mean(axis=1, keepdims=True)
+        x = np.ascontiguousarray(arr, dtype=np.float32)
         n_channels, n_samples = x.shape
         if epoch_bounds is None:
             epoch_bounds = np.array([[0, n_samples]])

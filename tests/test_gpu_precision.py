@@ -309,3 +309,17 @@ def test_exact_precision_under_a_mains_line_inside_the_band():
     assert e_x < 0.3 * TOL and e_h > 10 * TOL
     amp, _ = _run(x, fs, f, "amplitude", precision="exact")
     assert rel_err(amp, np.abs(ref)).max() < 0.3 * TOL
+
+
+def test_public_call_float64_input_with_a_huge_offset():
+    """A float64 recording whose DC level is 1e7 x its fluctuation (float32 would quantise it to steps the size of
+    the signal): `transform()` removes the mean in the input's own precision before the cast to the device's float32
+    (transforms.py:142-143 does it in float64), so the result matches the oracle as on any other recording."""
+    from ghost_amd.synthetic import lfp_channel
+    from ghost_amd.wave import ContinuousWaveletTransform
+    fs, n = 1000.0, 100000
+    x = lfp_channel(n, fs, 3).astype(np.float64) + 1.0e7 * float(np.std(lfp_channel(n, fs, 3)))
+    cwt = ContinuousWaveletTransform()
+    cwt.transform(x, fs=fs, freq_limits=[3, 300], voices_per_octave=4)
+    ref = orc.cwt_amplitude(x, fs, cwt.frequencies, n_threads=8)
+    assert rel_err(cwt.amplitude, ref).max() < 0.2 * TOL
