@@ -979,16 +979,16 @@ __global__ void __launch_bounds__(256, 2) k_fullband_colsq(const cf* __restrict_
 // product with the scale's response (32 KB, L2: every workgroup reads the same ones), 4096-point inverse FFT
 // (the arithmetic of k_fullband_rows), and the block's `hop` samples of the scale's row straight from the
 // registers of the last DFT16, 256 consecutive samples per store.  HBM sees the spectrum once and the result.
-// 164 registers under a launch bound of two workgroups per CU: three are resident (28 ms for 128 ch x 1e6 x 83
-// scales; bound to three the compiler squeezes the loop into 150 registers and it takes 48, held to two by LDS
-// 33: profiles/r04_heavy_tails.md).  grid (blocks * channels)
+// 152 registers under a launch bound of two waves per SIMD: three workgroups are resident (25 ms for 128 ch x 1e6
+// x 83 scales; bound to three waves the compiler squeezed an earlier version into 150 registers and it took 48
+// ms, held to two workgroups by LDS 33: profiles/r04_heavy_tails.md).  grid (blocks * channels)
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb, float* __restrict__ out,
                                                    const cf* __restrict__ h, const int32_t* __restrict__ rows,
                                                    int n_group_scales, const cf* __restrict__ twt,
                                                    const cf* __restrict__ tw256, const BcBlocks bl, int blk0,
                                                    int n_scales, int64_t col0, int64_t row_len) {
-  // twt[256 j + tid] = W_4096^(+(t + 16 j) a): the middle twiddles as each thread meets them (coalesced, L2)
+  // twt[256 j + tid] = W_4096^(+(t + 16 j) a): the middle twiddles in the order the threads meet them
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
   float* const ex_re = reinterpret_cast<float*>(buf) + (threadIdx.x & 15) * kExColD;
