@@ -75,7 +75,7 @@ struct EpochDev {
 
 // full-band responses kept on the device across executes (one P-point row per (scale, FFT length)); counted in
 // gcwt_plan_info.workspace_bytes
-constexpr int64_t kFullbandCacheBytes = (int64_t)4 << 30;
+constexpr int64_t kFullbandCacheBytes = (int64_t)16 << 30;   // 193 responses of 2^22 bins (config 5, precision = exact) are 6.2 GB
 
 enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_FULLBAND, ST_INTERP, ST_BLOCKCONV, ST_COUNT };
 
@@ -131,7 +131,7 @@ struct gcwt_plan {
   int z_sets = 1;
   float2* d_hfull = nullptr;  // [z_sets][max_p]  full-band responses of the scales in hand (when the cache below is full)
   // Full-band responses are an O(n_bins P) fp64 evaluation each: computed once per (scale, FFT
-  // length) and kept on the device while they fit 4 GiB, reused by every later batch and execute.
+  // length) and kept on the device while they fit 16 GiB, reused by every later batch and execute.
   std::map<std::pair<int, int>, float2*> hfull_cache;
   int64_t hfull_cache_bytes = 0;
   float2* d_tw4096 = nullptr; // exp(-2 pi i j/4096), j < 2048
