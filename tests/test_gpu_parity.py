@@ -672,6 +672,33 @@ def test_small_device_resident_executes_replay_a_graph(option):
     xb.free(); ob.free(); bb.free()
 
 
+def test_blockconv_against_the_reference_itself(golden):
+    """G15: the reference's own numbers (not the oracle's) for Morse(3, 2), (1, 5), (3, 5) with kernels of 27 .. 2250
+    taps over two epochs -- complex coefficients of its inner loop (transforms.py:187-204) and the public call's
+    amplitude -- against the engine, whose scales here go through the time domain (<= 48 taps) and the block
+    convolution."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd import _lib
+    from ghost_amd.wave import ContinuousWaveletTransform, Morse
+    g = golden("g15_blockconv.npz")
+    fs, f, cols, eb = float(g["fs"]), g["frequencies"], g["cols"], g["epochs"]
+    x = g["x"]
+    for gamma, beta in g["pairs"]:
+        tag = "%g_%g" % (gamma, beta)
+        p = CwtPlan(x.size, 1, fs, f, gamma=float(gamma), beta=float(beta), epoch_bounds=eb, output="complex")
+        si = p.scale_info()
+        np.testing.assert_array_equal(si["length"], g["lengths_" + tag])
+        assert (si["method"] == _lib.SCALE_BLOCKCONV).sum() >= 4 and (si["method"] == _lib.SCALE_SPECTRAL).sum() == 0
+        got = p.execute(x[None])[0]
+        err = np.abs(got[:, cols] - g["complex_cols_" + tag]).max(axis=1) / g["rowmax_" + tag]
+        assert err.max() < TOL, (tag, err)
+    cwt = ContinuousWaveletTransform(wavelet=Morse(gamma=3.0, beta=2.0))
+    cwt.transform(x[:17000].astype(np.float64), fs=fs, freq_limits=[4, 120], voices_per_octave=4)
+    np.testing.assert_allclose(cwt.frequencies, g["api_frequencies"], rtol=1e-13)
+    c17 = cols[cols < 17000]
+    assert rel_err(cwt.amplitude[:, c17], g["api_amplitude_cols"]).max() < TOL
+
+
 def test_blockconv_blocks_pair_the_same_way_for_any_range(option):
     """The forward transform of the block convolution carries two real blocks at a time; which two must not depend
     on the range a call asks for, or execute_block differs from execute in a last bit now and then (soak seed 831,

@@ -232,3 +232,23 @@ def test_oracle_restates_the_reference_on_steep_spectra(golden):
     want = g["api_amplitude_cols_f3_offset"]
     np.testing.assert_allclose(orc.frequency_grid(fs, x.size, freq_limits=[9, 200], voices_per_octave=4), fa, rtol=1e-14)
     assert (np.abs(amp[:, cols] - want).max(axis=1) / want.max(axis=1)).max() < 1e-11
+
+
+def test_oracle_against_reference_on_heavy_tailed_long_kernels(golden):
+    """G15 (tests/golden/make_golden_blockconv.py): Morse(3, 2), (1, 5), (3, 5) with kernels of 27 .. 2250 taps, two
+    epochs, through the reference's inner loop (transforms.py:142-143, :187-204) and, for (3, 2), its public call: the
+    regime of round 4's block convolution.  The oracle reproduces both to 1e-12 / 1e-11 of a row's maximum."""
+    g = golden("g15_blockconv.npz")
+    fs, f, cols, eb = float(g["fs"]), g["frequencies"], g["cols"], g["epochs"]
+    x = g["x"].astype(np.float64)
+    for gamma, beta in g["pairs"]:
+        tag = "%g_%g" % (gamma, beta)
+        ref = orc.cwt_complex(x, fs, f, eb, gamma=float(gamma), beta=float(beta))
+        assert np.array_equal(orc.morse_lengths(orc.hz_to_rad(f, fs), float(gamma), float(beta)), g["lengths_" + tag])
+        err = np.abs(ref[:, cols] - g["complex_cols_" + tag]).max(axis=1) / g["rowmax_" + tag]
+        assert err.max() < 1e-12, (tag, err)
+    fa = g["api_frequencies"]
+    amp = orc.cwt_amplitude(x[:17000], fs, fa, gamma=3.0, beta=2.0)
+    want = g["api_amplitude_cols"]
+    c17 = cols[cols < 17000]
+    assert (np.abs(amp[:, c17] - want).max(axis=1) / want.max(axis=1)).max() < 1e-11
