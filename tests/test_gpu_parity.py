@@ -672,6 +672,23 @@ def test_small_device_resident_executes_replay_a_graph(option):
     xb.free(); ob.free(); bb.free()
 
 
+def test_fullband_sets_of_four_with_a_remainder(option):
+    """The full-band row pass takes up to four scales per pass over the spectrum (kernels.h: FullbandSet): seven scales
+    -- a set of four and one of three -- and a single one, two epochs, against the oracle."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd import _lib
+    from ghost_amd.synthetic import lfp
+    option("blockconv", 0)
+    fs, n = 1000.0, 70000
+    x = lfp(2, n, fs, seed=44)
+    eb = np.array([[3, 41000], [41007, n]])
+    for f in (np.array([9.5, 8.0, 7.0, 5.5, 4.4, 3.1, 2.2]), np.array([5.0])):
+        ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, eb, gamma=3, beta=2) for c in range(2)])
+        p = CwtPlan(n, 2, fs, f, gamma=3, beta=2, epoch_bounds=eb, output="complex")
+        assert (p.scale_info()["method"] == _lib.SCALE_FULLBAND).all()
+        assert rel_err(p.execute(x), ref).max() < TOL
+
+
 def test_blockconv_against_the_reference_itself(golden):
     """G15: the reference's own numbers (not the oracle's) for Morse(3, 2), (1, 5), (3, 5) with kernels of 27 .. 2250
     taps over two epochs -- complex coefficients of its inner loop (transforms.py:187-204) and the public call's
