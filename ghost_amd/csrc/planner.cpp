@@ -911,11 +911,16 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
         for (size_t l = 0; l < nl; ++l) plan_interp_level(hp, &hp->levels[l], &coef[l]);
       } else {
         std::atomic<size_t> next{0};
+        auto work = [&]() {
+          for (size_t l = next++; l < nl; l = next++) plan_interp_level(hp, &hp->levels[l], &coef[l]);
+        };
         std::vector<std::thread> pool;
-        for (unsigned k = 0; k < n_thr; ++k)
-          pool.emplace_back([&]() {
-            for (size_t l = next++; l < nl; l = next++) plan_interp_level(hp, &hp->levels[l], &coef[l]);
-          });
+        try {
+          for (unsigned k = 1; k < n_thr; ++k) pool.emplace_back(work);
+        } catch (...) {
+          // no more threads to be had: this one and those that did start take the levels (nothing throws across the ABI)
+        }
+        work();
         for (std::thread& t : pool) t.join();
       }
       for (size_t l = 0; l < nl; ++l) {
