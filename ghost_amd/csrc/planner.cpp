@@ -11,6 +11,7 @@
 #include <map>
 #include <atomic>
 #include <mutex>
+#include <new>
 #include <thread>
 
 namespace gcwt {
@@ -911,8 +912,13 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
         for (size_t l = 0; l < nl; ++l) plan_interp_level(hp, &hp->levels[l], &coef[l]);
       } else {
         std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
         auto work = [&]() {
-          for (size_t l = next++; l < nl; l = next++) plan_interp_level(hp, &hp->levels[l], &coef[l]);
+          try {
+            for (size_t l = next++; l < nl; l = next++) plan_interp_level(hp, &hp->levels[l], &coef[l]);
+          } catch (...) {                  // (an exception must not leave a thread; the caller reports it)
+            failed = true;
+          }
         };
         std::vector<std::thread> pool;
         try {
@@ -922,6 +928,7 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
         }
         work();
         for (std::thread& t : pool) t.join();
+        if (failed) throw std::bad_alloc();
       }
       for (size_t l = 0; l < nl; ++l) {
         if (hp->levels[l].interp_q <= 0 || coef[l].empty()) continue;
