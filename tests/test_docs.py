@@ -40,3 +40,12 @@ def test_profiles_named_in_design_exist():
         if "{" in name:
             continue
         assert os.path.exists(os.path.join(ROOT, "profiles", name)), name
+
+
+def test_readme_quotes_the_tracked_headline():
+    """README.md's measured paragraph is generated from the same tracked files (tools/design_numbers.py)."""
+    text = open(os.path.join(ROOT, "README.md")).read()
+    m = re.search(r"<!-- gen:measured -->(.*?)<!-- /gen -->", text, re.S)
+    assert m
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read().strip().splitlines()[-1])
+    assert "%.0f Msamples/s" % line["value"] in m.group(1) and "%.3f" % line["roofline"]["frac"] in m.group(1)

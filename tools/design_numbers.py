@@ -51,6 +51,24 @@ rows = [(b, "value", "%.2f" % j["value"]), (b, "ms_per_step", "%.4f" % j["ms_per
         (b, "other_configs.config5.roofline.frac", "%.4f" % c5["roofline"]["frac"]), (b, "cpu_baseline.value", "%.4f" % j["cpu_baseline"]["value"]),
         (b5, "ms_per_step", "%.4f" % j5["ms_per_step"]), (b5, "value", "%.2f" % j5["value"]), (b5, "roofline.frac", "%.4f" % j5["roofline"]["frac"]),
         ("profiles/traffic.json", "k_synth_hbm_bytes_per_launch", "%d" % tr["k_synth_hbm_bytes_per_launch"])]
+# README.md: the measured paragraph, from the same files
+oc = j["other_configs"]
+readme_text = (
+    "Measured (round 4, one MI355X, `profiles/%s_bench.json`; the boxes of the pool differ by a few per cent): headline\n"
+    "128 ch x 1e6 samples x 100 scales, amplitude, device-resident %.0f Msamples/s (%.2f ms per step; the synthesis\n"
+    "kernels at %.3f of the 8 TB/s HBM peak on algorithmic bytes, PMC traffic %.2f x those bytes), checked against the\n"
+    "oracle in the same run; complex output %.0f Msamples/s; config 5 (48 ch x 18e6 samples @ 30 kHz x 200 scales,\n"
+    "streamed in time blocks) %.0f Msamples/s at %.3f; config 2 (1 channel) %.2f ms per execute; config 1 (16 384 samples x\n"
+    "32 scales) %.0f us; Morse(3, 2) at the headline shape %.1f ms per step; the oracle on the host's cores %.2f Msamples/s."
+    % (rnd, j["value"], j["ms_per_step"], rl["frac"], rl["traffic"] / rl["algorithmic_bytes"], cx["value"], j5["value"], j5["roofline"]["frac"],
+       oc["config2"]["device_resident"]["ms_per_step"], oc["config1"]["device_resident"]["us_per_call"],
+       oc["heavy_tailed_wavelet"]["ms_per_step"], j["cpu_baseline"]["value"]))
+rpath = os.path.join(root, "README.md")
+r = open(rpath).read()
+rpat = re.compile(r"(<!-- gen:measured -->).*?(<!-- /gen -->)", re.S)
+assert rpat.search(r), "README.md has no generated fragment"
+open(rpath, "w").write(rpat.sub(lambda m: m.group(1) + readme_text + m.group(2), r))
+
 path = os.path.join(root, "DESIGN.md")
 s = open(path).read()
 for name, text in gen.items():
