@@ -71,6 +71,9 @@ struct EpochDev {
   SynthiItem* items_i = nullptr;     // interpolating kernel (synthi.hip)
   SynthiLevel* levels_i = nullptr;
   int n_items_i = 0;
+  SynthpItem* items_p[2] = {nullptr, nullptr};   // pipelined interpolating kernel (synthp.hip); [1]: levels with I = 4
+  SynthpLevel* levels_p = nullptr;
+  int n_items_p[2] = {0, 0};
 };
 
 // full-band responses kept on the device across executes (one P-point row per (scale, FFT length)); counted in
@@ -101,6 +104,10 @@ struct gcwt_plan {
   hipStream_t stream = nullptr;
   hipStream_t aux[2] = {nullptr, nullptr};   // the level passes of a batch run beside each other (run_pipeline)
   bool level_streams = true;  // GHOSTCWT_LEVEL_STREAMS=0: everything on `stream`
+  bool use_synthp = false;    // option synthp = 1: q = 2 levels with I <= 256 go to the pipelined kernel (synthp.hip); it
+                              // ties with k_synthi on the headline and loses at R = 8 (profiles/r05_synth_study.md): off
+  int synthp_help = -1;       // option synthp_help: share (of 128) of a round's tasks the producer waves take (A/B runs; default: by level)
+  int synthp_lgnb = -1;       // option synthp_lgnb: blocks per k_synthp workgroup forced (A/B runs)
   int interp_lgnb = -1;       // option interp_lgnb: blocks per k_synthi workgroup forced (A/B runs)
   int interp_grid = -1;       // GHOSTCWT_INTERP_GRID=0|1: k_synthi's grid order forced (default: by the number of channel slots)
   bool synth_streams = false; // GHOSTCWT_SYNTH_STREAMS=1: the interpolating kernel runs beside k_synth7 on aux[0] (its store-bound
@@ -206,7 +213,7 @@ void free_dev(gcwt_plan* p) {
   p->hfull_cache.clear();
   p->hfull_cache_bytes = 0;
   p->host_out.release();
-  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.items7w); fr(e.levels7); fr(e.items_i); fr(e.levels_i); }
+  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.items7w); fr(e.levels7); fr(e.items_i); fr(e.levels_i); fr(e.items_p[0]); fr(e.items_p[1]); fr(e.levels_p); }
   p->ep_dev.clear();
   if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
@@ -230,6 +237,12 @@ int get_event(gcwt_plan* p, hipEvent_t* e) {
 // (amplitude / power, R >= 16), else k_synth7 when the block layout allows, else the 16-column
 // fallback.  GHOSTCWT_SYNTH16=1 sends everything to the fallback (A/B tests).
 enum LevelKernel { LK_SYNTH16 = 0, LK_SYNTH7 = 7, LK_INTERP = 9 };
+// an interpolated level goes to the pipelined kernel (synthp.hip) when its layout fits: two phases per scale, a
+// lane's sub-sample positions fixed by the lane (I <= 256), whole lane-tasks per block (hop R a multiple of 4 I)
+inline bool level_pipelined(const gcwt_plan* p, const LevelPlan& lp) {
+  return p->use_synthp && lp.interp_q == 2 && lp.interp_factor >= 4 && lp.interp_factor <= kSynthpMaxFactor &&
+         lp.scales.size() <= 256;
+}
 inline LevelKernel level_kernel(const gcwt_plan* p, const LevelPlan& lp) {
   // (the 16-column kernel knows nothing of a band shift: shifted levels keep k_synth7 whatever the option says)
   if (p->use_synth16 && lp.band_shift == 0) return LK_SYNTH16;
@@ -338,6 +351,9 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   if (option_is_set("interp_grid")) p->interp_grid = option_or("interp_grid", 0) != 0;
   p->synth_streams = option_or("synth_streams", 0) != 0;
   p->interp_lgnb = (int)option_or("interp_lgnb", -1);
+  p->use_synthp = option_or("synthp", 0) != 0;
+  p->synthp_lgnb = (int)option_or("synthp_lgnb", -1);
+  p->synthp_help = (int)option_or("synthp_help", -1);
   p->synth_kernel = kMeasureBuild && option_or("synth_kernel", 7) == 8 ? 8 : 7;
   p->drop_stores = kMeasureBuild && option_is_set("synth_drop_stores") ? (int)std::max<long long>(1, option_or("synth_drop_stores", 1)) : 0;
   p->clock_probe = kMeasureBuild && option_is_set("clock_probe");
@@ -641,9 +657,13 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     std::vector<std::pair<int, int>> pending;          // (level, log2 blocks per workgroup)
     std::vector<SynthiLevel> lvi(hp.levels.size());
     std::vector<int> order;
+    std::vector<int> order_p;                            // ... the ones the pipelined kernel takes
     for (size_t l = 0; l < hp.levels.size(); ++l)
-      if (level_kernel(p, hp.levels[l]) == LK_INTERP) order.push_back((int)l);
+      if (level_kernel(p, hp.levels[l]) == LK_INTERP)
+        (level_pipelined(p, hp.levels[l]) ? order_p : order).push_back((int)l);
     std::sort(order.begin(), order.end(),
+              [&](int x, int y) { return hp.levels[x].decimation > hp.levels[y].decimation; });
+    std::sort(order_p.begin(), order_p.end(),
               [&](int x, int y) { return hp.levels[x].decimation > hp.levels[y].decimation; });
     for (int l : order) {
       const LevelPlan& lp = hp.levels[l];
@@ -713,6 +733,62 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     p->ep_dev[e].n_items_i = (int)items_i.size();
     if ((rc = upload_vec(&p->ep_dev[e].items_i, items_i, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels_i, lvi, p->stream))) return bail(rc);
+    // pipelined kernel: a workgroup owns nb consecutive blocks and walks the level's scales 4 / nb at a time (a
+    // round: 8 columns, 4 z slots).  Blocks per workgroup by decimation, so that a (round, scale) run is at least a
+    // few dozen wave-tasks of 256 samples for the six consumer waves: four blocks up to R = 16, two at R = 32, one
+    // beyond.  A run of rounds is cut at `target` bytes of rows like k_synthi's passes; largest items first.
+    {
+      std::vector<SynthpLevel> lvp(hp.levels.size());
+      std::vector<SynthpItem> items_p[2];
+      std::vector<int64_t> bytes_p[2];
+      const int64_t n_ch_slots = (int64_t)hp.prm.n_channels * std::max(1, ep.batch_count);
+      for (int l : order_p) {
+        const LevelPlan& lp = hp.levels[l];
+        int lgnb = lp.decimation <= 16 ? 2 : lp.decimation <= 32 ? 1 : 0;
+        if (p->synthp_lgnb >= 0) lgnb = std::min(p->synthp_lgnb, 2);
+        if (lp.interp_factor * 2 != lp.decimation || lp.halo < 16 || lp.hop != hp.block - 2 * lp.halo || lp.hop < 1 ||
+            hp.block != 256 || (lp.hop * lp.decimation) % (4 * lp.interp_factor) != 0)
+          return bail(set_err(GCWT_ERR_INVALID, "internal: pipelined level outside the kernel's limits"));
+        // what the two producer waves take of a round's tasks after making the next round's z (about 4.5 tasks' worth
+        // of instructions each): all eight waves done together when (T - h) / 6 = 4.5 + h / 2
+        const double tasks = 4.0 * lp.hop * lp.decimation / 256.0;
+        int help = (int)std::lround(128.0 * std::max(0.0, (tasks - 27.0) / (4.0 * tasks)));
+        if (p->synthp_help >= 0) help = std::min(p->synthp_help, 64);
+        lvp[l] = {lp.decimation, lp.interp_factor, lp.hop, lp.halo, ep.lv[l].nblk, (int32_t)lp.scales.size(),
+                  scale_off[l], ep.lv[l].blk_lo, lgnb, n_plain[l], (int32_t)(l * 256), help, lp.twiddle_offset,
+                  ep.lv[l].xr_offset, ep.lv[l].m - 1, lp.coef_offset};
+      }
+      int64_t target = (int64_t)2 << 20;
+      for (int attempt = 0;; ++attempt) {
+        for (int k = 0; k < 2; ++k) { items_p[k].clear(); bytes_p[k].clear(); }
+        for (int l : order_p) {
+          const LevelPlan& lp = hp.levels[l];
+          const int nb = 1 << lvp[l].log2nb, ns = kSynthpSlots / nb;
+          const int n_rounds = ((int)lp.scales.size() + ns - 1) / ns;
+          const int64_t round_bytes = (int64_t)ns * nb * lp.hop * lp.decimation * 4;
+          const int run = (int)std::max<int64_t>(1, std::min<int64_t>(n_rounds, target / std::max<int64_t>(1, round_bytes)));
+          const int k = lp.interp_factor == 4 ? 1 : 0;
+          for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += nb)
+            for (int r0 = 0; r0 < n_rounds; r0 += run) {
+              const int nr = std::min(run, n_rounds - r0);
+              items_p[k].push_back({(int32_t)l, b0, r0, nr});
+              bytes_p[k].push_back((int64_t)nr * round_bytes);
+            }
+        }
+        if ((int64_t)(items_p[0].size() + items_p[1].size()) * n_ch_slots >= 2048 || target <= ((int64_t)1 << 19) || attempt > 6) break;
+        target >>= 1;
+      }
+      for (int k = 0; k < 2; ++k) {
+        std::vector<size_t> ord(items_p[k].size());
+        for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return bytes_p[k][x] > bytes_p[k][y]; });
+        std::vector<SynthpItem> sorted(items_p[k].size());
+        for (size_t i = 0; i < ord.size(); ++i) sorted[i] = items_p[k][ord[i]];
+        p->ep_dev[e].n_items_p[k] = (int)sorted.size();
+        if ((rc = upload_vec(&p->ep_dev[e].items_p[k], sorted, p->stream))) return bail(rc);
+      }
+      if ((rc = upload_vec(&p->ep_dev[e].levels_p, lvp, p->stream))) return bail(rc);
+    }
   }
 
   hipError_t he = launch_build_bank(p->d_bank, p->d_gain, p->d_bank_sc, p->d_amps, S, B, p->stream);
@@ -981,6 +1057,32 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       ai.seg = sout;
       p->cur = si;
       RUN(ST_INTERP, launch_synthi(mode, ai, dev.n_items_i, slots, si));
+      p->cur = nullptr;
+    }
+    for (int k = 0; k < 2; ++k) {
+      if (dev.n_items_p[k] == 0) continue;
+      SynthpArgs ap{};
+      ap.tw256 = p->d_tw256;
+      ap.level_tw = p->d_level_tw;
+      ap.items = dev.items_p[k];
+      ap.levels = dev.levels_p;
+      ap.scale_list = p->d_scale_list;
+      ap.scale_aux = p->d_scale_aux;
+      ap.gain_lv = p->d_gain_lv;
+      ap.level_half_tw = p->d_half_tw;
+      ap.coef = p->d_interp_coef;
+      ap.out = dout;
+      ap.row_len = row_len;
+      ap.xr = p->d_xr;
+      ap.xr_cstride = hp.max_xr;
+      ap.xb_scale = (float)(1.0 / ((double)hp.block * (double)Pt));
+      ap.n_scales = S;
+      ap.channels_fastest = p->interp_grid >= 0 ? p->interp_grid : (slots <= 32 ? 1 : 0);
+      if (dev.n_items_p[k] > 65535) ap.channels_fastest = 0;     // (grid.y is 16 bits wide)
+      ap.flags = 0;
+      ap.seg = sout;
+      p->cur = si;
+      RUN(ST_INTERP, launch_synthp(mode, ap, dev.n_items_p[k], slots, k == 1, si));
       p->cur = nullptr;
     }
     if (dev.n_items > 0) {

@@ -171,6 +171,51 @@ struct SynthiArgs {
   SegOut seg;
 };
 hipError_t launch_synthi(int mode, const SynthiArgs& a, int n_items, int n_channels, hipStream_t st);
+// Pipelined interpolating synthesis (synthp.hip): q = 2 levels with I = R / 2 <= 256; producer waves make the z of
+// round n + 1 while consumer waves interpolate and store round n.
+constexpr int kSynthpThreads = 512;
+constexpr int kSynthpProducers = 2;      // waves
+constexpr int kSynthpSlots = 4;          // z slots (block, scale) of a round: nb blocks x ns scales
+constexpr int kSynthpMaxFactor = 256;    // I: a lane's sub-sample positions depend on the lane alone
+struct SynthpItem {
+  int32_t level, blk0;          // first block of the workgroup's group of 1 << log2nb
+  int32_t round0, n_rounds;     // the rounds (4 >> log2nb scales each) of the level's walk it makes
+};
+struct SynthpLevel {
+  int32_t decimation, factor;   // R, I = R / 2
+  int32_t hop, halo, nblk, n_scales, scale_offset, blk_base;
+  int32_t log2nb;               // 1 << log2nb consecutive blocks per workgroup (0, 1, 2)
+  int32_t n_plain;              // the first n_plain scales of the level's list have odd L; the rest carry the
+  int32_t half_offset;          //   half-sample phase level_half_tw[half_offset + k]
+  int32_t help;                 // of 128: the share of a round's tasks the two producer waves take once their z is made
+  int64_t tw_offset;            // into level_tw
+  int64_t xr_offset;            // per-channel offset of this level's decimated signal x_R (complex elems)
+  int64_t m_mask;               // M - 1, M = P / R samples of x_R (circular index)
+  int64_t coef_offset;          // into coef: [2][I][T] floats (the first table, tau = rho / I, is the one used)
+};
+struct SynthpArgs {
+  const float2* tw256;
+  const float2* level_tw;
+  const SynthpItem* items;
+  const SynthpLevel* levels;
+  const int32_t* scale_list;    // as Synth7Args
+  const int32_t* scale_aux;     // per list entry: demodulation bin | (kernel length is even) << 16
+  const float* gain_lv;         // gains in list order, [entry][t][16 j] (k_scale_windows)
+  const float2* level_half_tw;  // exp(-i pi k/(256 R)), 256 per level
+  const float* coef;
+  float* out;
+  int64_t row_len;
+  const float2* xr;
+  int64_t xr_cstride;
+  float xb_scale;               // 1 / (256 P)
+  int32_t n_scales;
+  int32_t channels_fastest;
+  int32_t flags;                // (unused)
+  int32_t pad0;
+  SegOut seg;
+};
+// exact0: the items' levels have I = 4 (a lane's first sample is z itself)
+hipError_t launch_synthp(int mode, const SynthpArgs& a, int n_items, int n_channels, bool exact0, hipStream_t st);
 // same work items and arguments as launch_synth7 (synth8.hip)
 hipError_t launch_synth8(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
                          hipStream_t st);

@@ -338,12 +338,14 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
                               __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
               __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (unsigned)s0 * 4u, 0, GCWT_STORE_AUX);
             } else {
-              // the window's edge (or the block's last samples) runs through this wave-task: one
-              // sample at a time, the range check drops what lies outside (negative offsets wrap)
+              // the window's edge (or the block's last samples) runs through this wave-task: one sample at
+              // a time, each under its own test (four plain stores in a row may be merged into one 16-byte store
+              // by the compiler, whose single range check would drop samples inside the window: synthp.hip)
 #pragma unroll
               for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rsrc,
-                                                      (unsigned)(s0 + i) * 4u, 0, GCWT_STORE_AUX);
+                if ((unsigned)(s0 + i) < (unsigned)w_len)
+                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rsrc,
+                                                        (unsigned)(s0 + i) * 4u, 0, GCWT_STORE_AUX);
             }
           }
         }

@@ -948,6 +948,22 @@ def test_synthesis_kernels_agree(option):
         _, ref16 = _plan(x, fs, f, output=output, epoch_bounds=eb)
         assert (np.abs(prod - ref16) / scale).max() < 2e-6, output
         option("synth16", None)
+        # the pipelined interpolating kernel (synthp.hip: producer / consumer waves, double-buffered z; option
+        # synthp = 1) makes the same rows; blocks per workgroup 1, 2 and 4 and both task shares
+        option("interp", None)
+        for lgnb, help_ in ((None, None), (0, 0), (1, 40), (2, None)):
+            option("synthp", 1)
+            option("synthp_lgnb", lgnb)
+            option("synthp_help", help_)
+            pp, gotp = _plan(x, fs, f, output=output, epoch_bounds=eb)
+            assert pp.info["n_interp"] > 0
+            assert (np.abs(gotp - ref7) / scale).max() < 2e-6, (output, lgnb, help_)
+            assert not gotp[:, :, 15001:15006].any()
+            # any sample range from the whole recording: window edges on no multiple of 4
+            blk = pp.execute_block(x, 7777, 9001)
+            np.testing.assert_array_equal(blk, gotp[:, :, 7777:7777 + 9001])
+        for name in ("synthp", "synthp_lgnb", "synthp_help"):
+            option(name, None)
         if lib.gcwt_debug_measure_build():
             for cols in (32, 16):
                 option("synth_kernel", 8)
