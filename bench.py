@@ -754,16 +754,31 @@ def config2_leg(fs, freqs, dev, lib, check, no_check=False, steps=20, warmup=3):
     api = {}
     for name, kw in (("float64", {}), ("float32", {"dtype": np.float32})):
         cwt = ContinuousWaveletTransform()
-        ts = []
-        for _ in range(4):
+        ts, t_call, t_slice = [], [], []
+        for _ in range(5):
             t0 = time.perf_counter()
             cwt.transform(x, fs=fs, freqs=freqs[::-1].copy(), **kw)
+            t1 = time.perf_counter()
+            amp = cwt.amplitude                  # the whole result on the host, as the reference leaves it
             ts.append(time.perf_counter() - t0)
+            t_call.append(t1 - t0)
+            nbytes = int(amp.nbytes)
+            del amp
+            # what a caller who looks at part of the result pays: transform() + one second of every scale
+            t0 = time.perf_counter()
+            cwt.transform(x, fs=fs, freqs=freqs[::-1].copy(), **kw)
+            piece = cwt.fetch(start=500000, stop=501000)
+            t_slice.append(time.perf_counter() - t0)
+            assert piece.shape == (S, 1000)
         api[name] = {"ms_per_call": round(float(np.median(ts[1:])) * 1e3, 2), "first_call_ms": round(ts[0] * 1e3, 2),
                      "value": round(N / float(np.median(ts[1:])) / 1e6, 2), "unit": "Msamples/s",
-                     "result_bytes": int(cwt.amplitude.nbytes)}
+                     "result_bytes": nbytes,
+                     "transform_returns_ms": round(float(np.median(t_call[1:])) * 1e3, 2),
+                     "transform_plus_1s_slice_ms": round(float(np.median(t_slice[1:])) * 1e3, 2)}
         del cwt
-    res["transform_end_to_end"] = dict(api, note="host in, host out over PCIe, plan creation included: never the headline value")
+    res["transform_end_to_end"] = dict(api, note="host array in, transform() and then the whole `amplitude` on the host (page-locked result from the pool of "
+                                            "ghost_amd.hostmem, float64 widened on the device); transform_returns_ms: the call alone (rows left on the "
+                                            "device); transform_plus_1s_slice_ms: transform() + fetch() of 1000 samples of every scale.  PCIe-inclusive: never the headline value")
     return res
 
 

@@ -8,14 +8,14 @@ import ctypes as C
 import os
 
 __all__ = ["lib", "GhostCwtError", "check", "Params", "PlanInfo", "Timings", "LIB_PATH",
-           "OUT_AMPLITUDE", "OUT_POWER", "OUT_COMPLEX", "X_ON_DEVICE", "OUT_ON_DEVICE", "OUT_F64",
+           "OUT_AMPLITUDE", "OUT_POWER", "OUT_COMPLEX", "X_ON_DEVICE", "OUT_ON_DEVICE", "OUT_F64", "HOST_PINNED",
            "SCALE_SPECTRAL", "SCALE_DIRECT", "SCALE_FULLBAND", "SCALE_BLOCKCONV", "ERR_INVALID", "ERR_UNSUPPORTED", "ERR_NO_DEVICE"]
 
 LIB_PATH = os.environ.get("GHOSTCWT_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "libghostcwt.so")
 
 OUT_AMPLITUDE, OUT_POWER, OUT_COMPLEX = 0, 1, 2
-X_ON_DEVICE, OUT_ON_DEVICE, REUSE_MEANS, OUT_F64 = 1, 2, 4, 8
+X_ON_DEVICE, OUT_ON_DEVICE, REUSE_MEANS, OUT_F64, HOST_PINNED = 1, 2, 4, 8, 16
 SCALE_SPECTRAL, SCALE_DIRECT, SCALE_FULLBAND, SCALE_BLOCKCONV = 0, 1, 2, 3
 WAVELET_ENERGY = 0x100
 ERR_INVALID, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_COMM, ERR_COMM_INCOMPLETE = -1, -2, -3, -4, -5, -6, -7
@@ -74,6 +74,9 @@ def _load():
         "gcwt_device_memset": (C.c_int, [vp, C.c_int, C.c_size_t]),
         "gcwt_device_synchronize": (C.c_int, []),
         "gcwt_device_memory": (C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+        "gcwt_host_alloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+        "gcwt_host_free": (C.c_int, [vp]),
+        "gcwt_rows_to_host": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int]),
         "gcwt_plan_create": (C.c_int, [C.POINTER(vp), C.POINTER(Params)]),
         "gcwt_plan_destroy": (None, [vp]),
         "gcwt_plan_get_info": (C.c_int, [vp, C.POINTER(PlanInfo)]),

@@ -326,6 +326,25 @@ int gcwt_device_memset(void* dst, int value, size_t bytes) {
   HIP_TRY(hipMemset(dst, value, bytes)); return GCWT_OK;
 }
 int gcwt_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return GCWT_OK; }
+int gcwt_host_alloc(void** ptr, size_t bytes) {
+  if (!ptr) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return GCWT_OK;
+}
+int gcwt_host_free(void* ptr) { HIP_TRY(hipHostFree(ptr)); return GCWT_OK; }
+int gcwt_rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, int64_t row_elems, void* dst,
+                      int64_t dst_pitch, int flags) {
+  return guarded([&] {
+    if (!d_src || !dst) return set_err(GCWT_ERR_INVALID, "NULL argument");
+    if (n_rows < 0 || row_elems < 0 || src_pitch < row_elems || dst_pitch < row_elems)
+      return set_err(GCWT_ERR_INVALID, "bad rectangle (rows, elements per row, pitches)");
+    if (!(flags & GCWT_HOST_PINNED) && dst_pitch != row_elems)
+      return set_err(GCWT_ERR_INVALID, "a destination that is not page-locked takes dense rows (dst_pitch = row_elems)");
+    HIP_TRY(rows_to_host(d_src, src_pitch, n_rows, row_elems, dst, dst_pitch, (flags & GCWT_OUT_F64) != 0,
+                         (flags & GCWT_HOST_PINNED) != 0));
+    return (int)GCWT_OK;
+  });
+}
 
 static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   if (!out || !params) return set_err(GCWT_ERR_INVALID, "NULL argument");

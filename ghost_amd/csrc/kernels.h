@@ -220,6 +220,10 @@ hipError_t launch_synthp(int mode, const SynthpArgs& a, int n_items, int n_chann
 hipError_t launch_synth8(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
                          hipStream_t st);
 
+// a rectangle of a device-resident result to the host (result_io.hip; include/ghostcwt.h: gcwt_rows_to_host)
+hipError_t rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, int64_t row_elems, void* dst,
+                        int64_t dst_pitch, bool widen, bool pinned);
+
 // sums: channel_sum_doubles(n_channels) doubles -- the results, then the workgroups' partial
 // sums (kernels.hip: k_channel_sum, k_channel_sum_final)
 constexpr int kSumParts = 64;

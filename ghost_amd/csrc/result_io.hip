@@ -1,0 +1,109 @@
+// result_io.hip -- a device-resident result on its way to the host (include/ghostcwt.h: gcwt_host_alloc,
+// gcwt_rows_to_host).  The reference hands back whole float64 arrays (transforms.py:203-204, 496-527); here the
+// result stays on the device after transform() and is brought over when -- and as far as -- it is asked for:
+//   * into page-locked memory (gcwt_host_alloc) the DMA engines write at the link's rate, no staging copy and no
+//     page faults (a fresh 856 MB NumPy array costs more in first-touch faults than the 428 MB cost on the wire);
+//   * float64 results are widened on the device (one pass at HBM rate) and cross the link as they are: no host
+//     thread touches them;
+//   * any rectangle of (row, sample) goes by itself: rows `src_pitch` apart on the device, `dst_pitch` on the host.
+// Destinations that are not page-locked go through the plan-independent staging ring (host_out.cpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+
+#include "host_out.h"
+#include "kernels.h"
+
+namespace gcwt {
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_widen_rows(const float* __restrict__ src, int64_t src_pitch,
+                                                    double* __restrict__ dst, int64_t row_elems, int64_t n) {
+  // n = rows * row_elems elements of the chunk, dense in dst; 4 per thread
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = i0 + k;
+    if (i < n) {
+      const int64_t r = i / row_elems, c = i - r * row_elems;
+      dst[i] = (double)src[r * src_pitch + c];
+    }
+  }
+}
+
+struct ResultIo {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  double* d_stage = nullptr;            // widened chunk on the device
+  size_t stage_elems = 0;
+  HostOut ring;                         // destinations that are not page-locked
+  int device = -1;
+};
+ResultIo& io() {
+  static ResultIo s;
+  return s;
+}
+constexpr size_t kStageElems = (size_t)16 << 20;   // 128 MB of doubles
+
+}  // namespace
+
+hipError_t rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, int64_t row_elems, void* dst,
+                        int64_t dst_pitch, bool widen, bool pinned) {
+  if (n_rows <= 0 || row_elems <= 0) return hipSuccess;
+  ResultIo& s = io();
+  std::lock_guard<std::mutex> lock(s.mu);
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, d_src);
+  if (e != hipSuccess) return e;
+  if ((e = hipSetDevice(attr.device)) != hipSuccess) return e;
+  if (s.device != attr.device) {        // (a process that moves to another device: the stream and the staging buffer follow)
+    if (s.stream) { (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
+    if (s.d_stage) { (void)hipFree(s.d_stage); s.d_stage = nullptr; s.stage_elems = 0; }
+    s.ring.release();
+    s.device = attr.device;
+  }
+  if (!s.stream && (e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+  if (!pinned) {
+    if (dst_pitch != row_elems) return hipErrorInvalidValue;   // the staging ring scatters into dense rows
+    return s.ring.drain(d_src, (size_t)src_pitch, (size_t)n_rows, (size_t)row_elems, dst, widen, s.stream);
+  }
+  if (!widen) {
+    if (src_pitch == row_elems && dst_pitch == row_elems)
+      e = hipMemcpyAsync(dst, d_src, sizeof(float) * (size_t)n_rows * (size_t)row_elems, hipMemcpyDeviceToHost, s.stream);
+    else
+      e = hipMemcpy2DAsync(dst, sizeof(float) * (size_t)dst_pitch, d_src, sizeof(float) * (size_t)src_pitch,
+                           sizeof(float) * (size_t)row_elems, (size_t)n_rows, hipMemcpyDeviceToHost, s.stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s.stream);
+  }
+  // float64: chunks of whole rows (or pieces of one long row) widened into the staging buffer, then over the link;
+  // the stream keeps widen(c + 1) behind copy(c), and a widening pass is a hundredth of its copy
+  if (!s.d_stage) {
+    if ((e = hipMalloc((void**)&s.d_stage, sizeof(double) * kStageElems)) != hipSuccess) return e;
+    s.stage_elems = kStageElems;
+  }
+  const int64_t cols_per = std::min<int64_t>(row_elems, (int64_t)s.stage_elems);
+  const int64_t rows_per = std::max<int64_t>(1, (int64_t)s.stage_elems / cols_per);
+  for (int64_t r0 = 0; r0 < n_rows; r0 += rows_per) {
+    const int64_t nr = std::min(rows_per, n_rows - r0);
+    for (int64_t c0 = 0; c0 < row_elems; c0 += cols_per) {
+      const int64_t nc = std::min(cols_per, row_elems - c0);
+      const int64_t n = nr * nc;
+      hipLaunchKernelGGL(k_widen_rows, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s.stream,
+                         d_src + r0 * src_pitch + c0, src_pitch, s.d_stage, nc, n);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      double* out = static_cast<double*>(dst) + r0 * dst_pitch + c0;
+      if (nc == dst_pitch)
+        e = hipMemcpyAsync(out, s.d_stage, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s.stream);
+      else
+        e = hipMemcpy2DAsync(out, sizeof(double) * (size_t)dst_pitch, s.d_stage, sizeof(double) * (size_t)nc,
+                             sizeof(double) * (size_t)nc, (size_t)nr, hipMemcpyDeviceToHost, s.stream);
+      if (e != hipSuccess) return e;
+    }
+  }
+  return hipStreamSynchronize(s.stream);
+}
+
+}  // namespace gcwt

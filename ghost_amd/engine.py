@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import lib, check
 
-__all__ = ["CwtPlan", "DeviceBuffer", "set_option", "device_count", "device_name", "device_memory"]
+__all__ = ["CwtPlan", "DeviceBuffer", "DeviceResult", "set_option", "device_count", "device_name", "device_memory"]
 
 
 def set_option(name, value=None):
@@ -73,6 +73,61 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class DeviceResult:
+    """A transform's result left on the device: ``shape`` (C, S, N) rows of float32 (complex64 for complex
+    output), ``pitch`` samples apart.  ``to_host`` brings over the whole result or any (scale, sample) range
+    of it -- straight into page-locked memory at the link's rate (ghost_amd.hostmem), float64 widened on the
+    device -- and ``buffer.ptr`` is the handle for whoever keeps working on the device."""
+
+    def __init__(self, buffer, shape, pitch, complex_):
+        self.buffer, self.shape, self.pitch, self.is_complex = buffer, tuple(int(v) for v in shape), int(pitch), bool(complex_)
+
+    @property
+    def nbytes(self):
+        return self.shape[0] * self.shape[1] * self.pitch * (8 if self.is_complex else 4)
+
+    def to_host(self, dtype=None, scales=None, start=0, stop=None):
+        """ndarray (C, S', n): scales ``scales`` (slice or None = all), samples [start, stop) of every channel.
+        dtype: float32 / float64 (complex64 / complex128 for complex results); default the device's."""
+        from . import hostmem
+        c, s, n = self.shape
+        k = 2 if self.is_complex else 1
+        narrow = np.complex64 if self.is_complex else np.float32
+        wide = np.complex128 if self.is_complex else np.float64
+        dtype = np.dtype(narrow if dtype is None else dtype)
+        if dtype not in (np.dtype(narrow), np.dtype(wide)):
+            raise ValueError("dtype must be %s or %s" % (np.dtype(narrow), np.dtype(wide)))
+        sl = range(s)[slice(None) if scales is None else scales]
+        if sl.step != 1 and len(sl) > 1:
+            raise ValueError("scales must be a contiguous range")
+        stop = n if stop is None else min(int(stop), n)
+        start = max(0, int(start))
+        cols = max(0, stop - start)
+        out_shape = (c, len(sl), cols)
+        out = hostmem.empty(out_shape, dtype)
+        pinned = out is not None
+        if not pinned:
+            out = np.empty(out_shape, dtype=dtype)
+        if out.size == 0:
+            return out
+        flags = (_lib.OUT_F64 if dtype == np.dtype(wide) else 0) | (_lib.HOST_PINNED if pinned else 0)
+        esz = 4 * k
+        if len(sl) == s:                       # all scales: the channels' rows follow each other
+            groups = [(0, c * s, out.reshape(c * s, cols))]
+        else:
+            groups = [(ch * s + sl.start, len(sl), out[ch]) for ch in range(c)]
+        for row0, n_rows, dst in groups:
+            src = C.c_void_p(self.buffer.ptr.value + (row0 * self.pitch + start) * esz)
+            check(lib.gcwt_rows_to_host(src, self.pitch * k, n_rows, cols * k, dst.ctypes.data_as(C.c_void_p),
+                                        cols * k, flags))
+        return out
+
+    def free(self):
+        if self.buffer is not None:
+            self.buffer.free()
+            self.buffer = None
 
 
 _OUT_DTYPE = {_lib.OUT_AMPLITUDE: np.float32, _lib.OUT_POWER: np.float32,
@@ -194,6 +249,26 @@ class CwtPlan:
         check(lib.gcwt_execute(self._handle, x.ctypes.data_as(C.c_void_p),
                                out.ctypes.data_as(C.c_void_p), flags))
         return out
+
+    def execute_resident(self, x, result=None):
+        """x: array-like (C, N) on the host; the result stays on the device: a DeviceResult (``result`` is reused
+        when it is one of this shape).  Rows are padded to 32 samples (128-byte row starts: DESIGN.md 5)."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(self.n_channels, self.n_samples)
+        self.upload()                           # (without a GPU this is where GCWT_ERR_NO_DEVICE is raised)
+        pitch = (self.n_samples + 31) & ~31
+        cplx = self.out_dtype == np.complex64
+        if (result is None or result.buffer is None or result.shape != self.out_shape or result.pitch != pitch
+                or result.is_complex != cplx):
+            if result is not None:
+                result.free()
+            nbytes = self.n_channels * self.n_freqs * pitch * (8 if cplx else 4)
+            result = DeviceResult(DeviceBuffer(nbytes), self.out_shape, pitch, cplx)
+        self.set_row_pitch(pitch)
+        try:
+            check(lib.gcwt_execute(self._handle, x.ctypes.data_as(C.c_void_p), result.buffer.ptr, _lib.OUT_ON_DEVICE))
+        finally:
+            self.set_row_pitch(0)
+        return result
 
     def execute_device(self, x_buf, out_buf):
         """Both buffers are DeviceBuffer (or raw c_void_p); returns when done."""

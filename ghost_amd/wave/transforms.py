@@ -52,6 +52,9 @@ class ContinuousWaveletTransform(WaveletTransform):
         self._plan = None
         self._plan_key = None
         self.last_timings = None
+        self._device_result = None          # the last transform's rows, still on the device
+        self._pending = None                # (output, dtype, squeeze): what first access to a result attribute brings over
+        self._last_kind = None              # ... of the result that has been brought over (fetch() after that)
 
     def transform(self, *args, multichannel=None, **kwargs):
         """Does a continuous wavelet transform; returns None and stores
@@ -61,6 +64,9 @@ class ContinuousWaveletTransform(WaveletTransform):
         ``fs``, ``freq_limits``, ``freqs``, ``voices_per_octave``, ``parallel``
         (validated, then ignored: the GPU does all scales at once), ``verbose``.
         Beyond the reference: ``multichannel``, ``output`` ('amplitude', 'power', 'complex'), ``dtype``,
+        ``lazy`` (default True: the result stays on the device when transform() returns and crosses PCIe on first
+        access to ``amplitude`` / ``power`` / ``coefficients`` -- or piecewise through ``fetch()`` --; False: it is on
+        the host when transform() returns, as in the reference),
         ``device`` and ``precision`` ('high', the default: the forward FFT in float64 like the reference's
         arithmetic, transforms.py:142-143; 'fast': float32 throughout; 'exact': every scale by FFT convolution
         with its literal kernel, 3 - 5 x slower, for recordings with interference far above the signal inside the
@@ -89,7 +95,7 @@ class ContinuousWaveletTransform(WaveletTransform):
 
     def _run(self, data, *, squeeze, timestamps=None, fs=None, freq_limits=None, freqs=None,
              voices_per_octave=None, parallel=None, verbose=None, output=None, dtype=None,
-             device=None, precision=None, **kwargs):
+             device=None, precision=None, lazy=None, **kwargs):
         self.fs = fs                        # validates (transforms.py:109)
         self._time = timestamps
 
@@ -118,6 +124,10 @@ class ContinuousWaveletTransform(WaveletTransform):
             dtype = np.float64
         if device is None:
             device = -1
+        if lazy is None:
+            lazy = True
+        if lazy not in (True, False):
+            raise ValueError("'lazy' must be either True or False")
 
         epoch_bounds = kwargs.pop("epoch_bounds", None)
         # (N, C) column signals from the adapter -> (C, N) rows for the device
@@ -174,23 +184,69 @@ class ContinuousWaveletTransform(WaveletTransform):
             self._plan_key = key
         self._plan.set_profiling(bool(verbose))
         start_time = time.time()
-        # float64 (the reference's dtype) is widened by the library while the result is copied
-        res = self._plan.execute(x, wide=np.dtype(dtype) == np.float64)   # (C, S, N)
+        # The rows stay on the device (engine.DeviceResult); what the reference keeps as whole host arrays
+        # (transforms.py:203-204, 496-527) is brought over by the first access to the attribute: into page-locked
+        # memory at the link's rate, float64 (the reference's dtype) widened on the device.
+        self._amplitude = self._power = self._coefficients = None
+        self._device_result = self._plan.execute_resident(x, self._device_result)
+        self._pending = (output, np.dtype(dtype), squeeze)
         if verbose:
             self.last_timings = self._plan.timings()
             print("Elapsed time (only wavelet convolution): {} seconds"
                   " to analyze {} frequencies".format(time.time() - start_time, f.size))
             print("device stages (ms): {}".format(self.last_timings))
+        if not lazy:
+            self._materialize()
 
+    # -- results: on the device until asked for ------------------------------------
+    def _materialize(self):
+        if self._pending is None or self._device_result is None:
+            return
+        output, dtype, squeeze = self._pending
+        self._last_kind = self._pending
+        self._pending = None
+        wide = dtype == np.dtype(np.float64)
+        if output == "complex":
+            res = self._device_result.to_host(np.complex128 if wide else np.complex64)
+        else:
+            res = self._device_result.to_host(np.float64 if wide else np.float32)
+            res = res.astype(dtype, copy=False)
         if squeeze:
             res = res[0]
-        self._amplitude = self._power = self._coefficients = None
         if output == "amplitude":
-            self._amplitude = res.astype(dtype, copy=False)
+            self._amplitude = res
         elif output == "power":
-            self._power = res.astype(dtype, copy=False)
+            self._power = res
         else:
             self._coefficients = res
+
+    @property
+    def device_result(self):
+        """The last transform's rows on the device (engine.DeviceResult: ``buffer.ptr``, ``shape`` (C, S, N),
+        ``pitch``), or None.  Valid until the next transform() or ``release_device()``."""
+        return self._device_result
+
+    def fetch(self, scales=None, start=0, stop=None, dtype=None):
+        """Scales ``scales`` (a slice; None = all) and samples [start, stop) of the last transform, straight from
+        the device, without bringing the rest of the result over: ndarray (S', n) -- (C, S', n) for multichannel
+        transforms -- of what ``output=`` selected.  dtype: float32 or float64 (default: the transform's)."""
+        if self._device_result is None:
+            raise ValueError("no transform on the device (call transform() first)")
+        out_kind, t_dtype, squeeze = self._pending if self._pending is not None else self._last_kind
+        dtype = np.dtype(t_dtype if dtype is None else dtype)
+        wide = dtype == np.dtype(np.float64)
+        if out_kind == "complex":
+            res = self._device_result.to_host(np.complex128 if wide else np.complex64, scales, start, stop)
+        else:
+            res = self._device_result.to_host(np.float64 if wide else np.float32, scales, start, stop)
+        return res[0] if squeeze else res
+
+    def release_device(self):
+        """Frees the device copy of the last result (bringing it over first if nothing has asked for it yet)."""
+        self._materialize()
+        if self._device_result is not None:
+            self._device_result.free()
+            self._device_result = None
 
     # -- plotting (reference: transforms.py:233-402) --------------------------
     def plot(self, *, kind=None, timescale=None, logscale=None, standardize=None,
@@ -330,6 +386,7 @@ class ContinuousWaveletTransform(WaveletTransform):
 
     @property
     def amplitude(self):
+        self._materialize()
         if self._amplitude is None:
             if self._power is not None:
                 return np.sqrt(self._power)
@@ -343,6 +400,7 @@ class ContinuousWaveletTransform(WaveletTransform):
 
     @property
     def power(self):
+        self._materialize()
         if self._power is not None:
             return self._power
         return np.square(self.amplitude)
@@ -354,6 +412,7 @@ class ContinuousWaveletTransform(WaveletTransform):
     @property
     def coefficients(self):
         """Complex coefficients (only kept when ``output='complex'``)."""
+        self._materialize()
         return self._coefficients
 
     @property

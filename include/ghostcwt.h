@@ -70,9 +70,11 @@ enum {
   GCWT_OUT_ON_DEVICE = 2, /* gcwt_execute: out is a device pointer               */
   GCWT_REUSE_MEANS = 4,   /* gcwt_execute_block: keep the channel means of the
                              previous call on this plan (same x)                 */
-  GCWT_OUT_F64 = 8        /* host output only: out is float64 (amplitude, power) or
+  GCWT_OUT_F64 = 8,       /* host output only: out is float64 (amplitude, power) or
                              float64 pairs (complex), the reference's result dtype
                              (transforms.py:185); widened while the copy is in flight */
+  GCWT_HOST_PINNED = 16   /* gcwt_rows_to_host: dst is page-locked (gcwt_host_alloc): the copy goes
+                             straight into it, no staging                         */
 };
 
 typedef struct gcwt_plan gcwt_plan;
@@ -176,6 +178,19 @@ int gcwt_device_memset(void* dst, int value, size_t bytes);
 int gcwt_device_synchronize(void);
 /* Free and total bytes of the current device's memory (for sizing time blocks). */
 int gcwt_device_memory(size_t* free_bytes, size_t* total_bytes);
+/* Page-locked host memory for results: a destination the device's copy engines write at the link's
+ * rate, with no staging copy and no first-touch page faults (what a fresh array of the reference's
+ * result size, transforms.py:185, costs on the host). */
+int gcwt_host_alloc(void** ptr, size_t bytes);
+int gcwt_host_free(void* ptr);
+/* A rectangle of a device-resident result (gcwt_execute with GCWT_OUT_ON_DEVICE) to the host: n_rows rows of
+ * row_elems float32 (complex results: two per sample), src_pitch elements apart on the device, to rows dst_pitch
+ * elements apart in dst.  flags: GCWT_OUT_F64 -- dst is float64, the reference's result dtype (transforms.py:185,
+ * 203-204), widened on the device; GCWT_HOST_PINNED -- dst is page-locked (else it goes through a pinned
+ * staging ring and dst_pitch must equal row_elems).  What ContinuousWaveletTransform.amplitude does on first
+ * access, and how any (scale, sample) range of a result is read without moving the rest (transforms.py:496-527). */
+int gcwt_rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, int64_t row_elems, void* dst,
+                      int64_t dst_pitch, int flags);
 
 /* Planning: host only, touches no device.  Replaces the per-call setup of
  * transforms.py:179-185 (wavelet lengths, output allocation) and decides, per

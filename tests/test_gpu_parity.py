@@ -41,6 +41,66 @@ def test_config1_public_api(golden):
     np.testing.assert_allclose(cwt.time, np.arange(16384) / 1000.0)
 
 
+def test_results_stay_on_the_device_until_asked_for(golden):
+    """transform() leaves the rows on the device; `amplitude` / `power` / `coefficients` bring them over on first
+    access (reference semantics: whole float64 host arrays, transforms.py:203-204, 496-527), `fetch()` any (scale,
+    sample) range without the rest, `lazy=False` restores results-on-return.  Page-locked destinations (the pool of
+    ghost_amd.hostmem) and pageable ones (pool limit 0) give the same bits, float32 and widened float64."""
+    from ghost_amd import hostmem
+    from ghost_amd.wave import ContinuousWaveletTransform
+    g = golden("g1_config1.npz")
+    x, fs = g["x"], 1000.0
+    eager = _cwt(x, fs, freq_limits=[5, 200], voices_per_octave=6, lazy=False)
+    assert eager._amplitude is not None and eager._pending is None
+    ref = eager.amplitude
+    assert rel_err(ref[:, g["cols"]], g["amplitude_cols"]).max() < TOL
+    lazy = _cwt(x, fs, freq_limits=[5, 200], voices_per_octave=6)
+    assert lazy._amplitude is None and lazy.device_result.shape == (1, 32, 16384)
+    # a slice straight from the device: scales 3..9, an unaligned sample range; float64 and float32
+    piece = lazy.fetch(scales=slice(3, 10), start=1001, stop=7778)
+    assert piece.dtype == np.float64 and lazy._amplitude is None
+    np.testing.assert_array_equal(piece, ref[3:10, 1001:7778])
+    np.testing.assert_array_equal(lazy.fetch(slice(31, 32), 0, 5, dtype=np.float32), ref[31:32, :5].astype(np.float32))
+    assert hostmem.is_pinned(piece)
+    amp = lazy.amplitude
+    assert amp.dtype == np.float64 and amp.shape == (32, 16384) and hostmem.is_pinned(amp)
+    np.testing.assert_array_equal(amp, ref)
+    np.testing.assert_array_equal(lazy.fetch(start=16000), ref[:, 16000:])       # after the whole came over, too
+    assert lazy.amplitude is amp                                                   # brought over once
+    # a second transform on the same object reuses the device buffer and replaces the attributes
+    buf = lazy.device_result.buffer.ptr.value
+    lazy.transform(x[::-1].copy(), fs=fs, freq_limits=[5, 200], voices_per_octave=6, dtype=np.float32)
+    assert lazy.device_result.buffer.ptr.value == buf and lazy._amplitude is None
+    assert lazy.amplitude.dtype == np.float32 and not np.array_equal(lazy.amplitude, amp.astype(np.float32))
+    np.testing.assert_array_equal(amp, ref)                                        # the first result is the caller's
+    # pageable destinations (nothing pinned handed out) give the same numbers; multichannel, power and complex
+    old_limit, hostmem.limit_bytes = hostmem.limit_bytes, 0
+    try:
+        xs = np.stack([x, x[::-1]])
+        for out, dt in (("power", np.float64), ("complex", np.float64), ("amplitude", np.float32)):
+            a = ContinuousWaveletTransform(); a.transform(xs, fs=fs, freq_limits=[8, 200], voices_per_octave=4,
+                                                            multichannel=True, output=out, dtype=dt)
+            unpinned = a.coefficients if out == "complex" else getattr(a, out)
+            part = a.fetch(slice(2, 5), 100, 9000)
+            assert not hostmem.is_pinned(unpinned)
+            hostmem.limit_bytes = old_limit
+            b = ContinuousWaveletTransform(); b.transform(xs, fs=fs, freq_limits=[8, 200], voices_per_octave=4,
+                                                            multichannel=True, output=out, dtype=dt)
+            pinned = b.coefficients if out == "complex" else getattr(b, out)
+            hostmem.limit_bytes = 0
+            assert hostmem.is_pinned(pinned) and pinned.shape == (2, len(a.frequencies), 16384)
+            np.testing.assert_array_equal(unpinned, pinned)
+            np.testing.assert_array_equal(part, pinned[:, 2:5, 100:9000])
+            assert unpinned.dtype == (np.complex128 if out == "complex" else dt)
+    finally:
+        hostmem.limit_bytes = old_limit
+    lazy.release_device()
+    assert lazy.device_result is None and lazy.amplitude is not None
+    with pytest.raises(ValueError):
+        lazy.fetch()
+    hostmem.trim()
+
+
 def test_two_tone_known_answers(golden):
     g = golden("g4b_two_tone.npz")
     fs, n = 1000.0, 4096
