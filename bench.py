@@ -134,15 +134,20 @@ def cpu_baseline(fs, freqs, budget_s=25.0):
                 "shape": "1 ch x %d samples x %d scales" % (n, len(f)), "best_s": round(best, 3), "runs": reps}
 
     f1 = 200.0 / 2.0 ** (np.arange(32) / 6.0)          # config 1: 32 scales, 6 voices per octave
-    pool = leg(1000000, freqs, cores, 2, budget_s * 0.4)
-    serial = leg(1000000, freqs, 1, 1, budget_s * 0.45)
+    pool = leg(1000000, freqs, cores, 2, budget_s * 0.3)
+    # what the reference's parallel=True does on this box: ThreadPool(cpu_count()) (transforms.py:210) -- every
+    # core the process may run on, at most one thread per scale
+    every = max(1, min(affinity, len(freqs)))
+    pool_all = leg(1000000, freqs, every, 2, budget_s * 0.2) if every != cores else dict(pool)
+    serial = leg(1000000, freqs, 1, 1, budget_s * 0.4)
     m1 = leg(16384, f1, 1, 3, budget_s * 0.1)
     return {"value": pool["value"], "unit": "Msamples/s", "cores": cores,
             "os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "kind": "port",
             "sample": "1 ch x 1000000 samples x %d scales (config 2 of the same fs and scales), float64, "
                       "scipy.fft overlap-add, ThreadPool(%d) over scales, best of %d runs (%.2f s each)"
                       % (len(freqs), cores, pool["runs"], pool["best_s"]),
-            "legs": {"config2_threadpool": pool, "config2_serial": serial, "config1_serial": m1}}
+            "legs": {"config2_threadpool": pool, "config2_threadpool_all_cores": pool_all, "config2_serial": serial,
+                     "config1_serial": m1}}
 
 
 def oracle_rows_window(x_full, fs, freqs, a, b):
@@ -229,14 +234,27 @@ class PowerSampler:
         return best
 
 
-def spot_check(obuf, base, fs, freqs, C, N, distinct, output="amplitude"):
+def check_scales(S, dec=None):
+    """The rows of a channel the bench compares with the oracle: the first and the last scale and, when the plan's
+    decimations are given, the middle scale of every decimation level (each level is its own kernel launch
+    geometry: seven levels on the headline grid)."""
+    scales = {0, (57 * S) // 100, S - 1}
+    if dec is not None:
+        dec = np.asarray(dec)
+        for r in sorted(set(dec.tolist())):
+            idx = np.nonzero(dec == r)[0]
+            scales.add(int(idx[len(idx) // 2]))
+    return sorted(scales)
+
+
+def spot_check(obuf, base, fs, freqs, C, N, distinct, output="amplitude", dec=None):
     """Looks at what the timed steps wrote: rows (channel, scale) of the device result
     against the oracle (transforms.py:187-204), and the tiled channels c and c + distinct
     (same input) bit for bit.  Returns (ok, worst relative error)."""
     from oracle import ghost_oracle as orc
     S = len(freqs)
     chans = sorted({0, min(7, C - 1), C - 1})
-    scales = sorted({0, (57 * S) // 100, S - 1})
+    scales = check_scales(S, dec)
     dtype, width = (np.complex64, 8) if output == "complex" else (np.float32, 4)
     worst, same = 0.0, True
     for c in chans:
@@ -553,11 +571,13 @@ def run_rank(args):
             line["checked"], line["check"] = check_config5(plan, xbuf, ring[0], base, distinct, fs, freqs, N, S,
                                                            group, segs)
         if not cfg5 and not args.no_check:
-            ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=args.output)
+            dec = plan.scale_info()["decimation"]
+            ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=args.output, dec=dec)
             full = full_output_check(obuf, C, N, S, distinct, output=args.output)
             line["checked"] = bool(ok and full["ok"])
-            line["check"] = {"rows": "channels {0,7,C-1} x scales {0,57%%,S-1} vs the oracle, "
-                                     "tiled channels c / c+%d bit-equal" % distinct,
+            line["check"] = {"rows": "channels {0,7,C-1} x scales %s (first, last, 57 %% and the middle one of every "
+                                     "decimation level) vs the oracle, tiled channels c / c+%d bit-equal"
+                                     % (check_scales(S, dec), distinct),
                              "worst_rel_err": float("%.3g" % worst), "full_output": full}
         if world == 1 and not cfg5 and args.output == "amplitude" and not args.no_other_modes:
             # Secondary measurement, after and outside the timed region: the same workload with the
@@ -839,7 +859,7 @@ def other_mode(output, N, C, fs, freqs, S, xbuf, dev, lib, check, steps=10, warm
            "kernel_frac_of_hbm_peak": round(alg / (k_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if check_against is not None:
         base, distinct = check_against
-        ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=output)
+        ok, worst = spot_check(obuf, base, fs, freqs, C, N, distinct, output=output, dec=plan.scale_info()["decimation"])
         full = full_output_check(obuf, C, N, S, distinct, output=output)
         res["checked"], res["worst_rel_err"], res["full_output"] = bool(ok and full["ok"]), float("%.3g" % worst), full
     obuf.free()

@@ -106,7 +106,7 @@ def _load():
         "gcwt_debug_level_low_cut": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
         "gcwt_debug_scale_theta_lo": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "gcwt_debug_graph_state": (C.c_int, [vp]),
-        "gcwt_debug_blockconv_groups": (C.c_int, [vp] + [C.POINTER(C.c_int32)] * 5 + [C.c_int]),
+        "gcwt_debug_blockconv_groups": (C.c_int, [vp] + [C.POINTER(C.c_int32)] * 5 + [C.c_int, C.c_int]),
         "gcwt_debug_batch_of": (C.c_int, [vp, C.c_int, i32p, i32p]),
         "gcwt_debug_level_info": (C.c_int, [vp, C.c_int, C.c_int, i32p, i32p, i32p, i32p, i64p]),
         "gcwt_debug_exact_gain": (C.c_int, [vp, C.c_int, i64p, C.c_int64, C.c_int64, C.POINTER(C.c_double)]),

@@ -15,6 +15,8 @@
 
 #include "../../include/ghostcwt.h"
 #include "../../include/ghostcwt_debug.h"
+#include <memory>
+
 #include "host_out.h"
 #include "interp.h"
 #include "kernels.h"
@@ -106,6 +108,11 @@ struct gcwt_plan {
   bool level_streams = true;  // GHOSTCWT_LEVEL_STREAMS=0: everything on `stream`
   bool use_synthp = false;    // option synthp = 1: q = 2 levels with I <= 256 go to the pipelined kernel (synthp.hip); it
                               // ties with k_synthi on the headline and loses at R = 8 (profiles/r05_synth_study.md): off
+  bool use_graphs = true;     // option graphs: small device-resident executes are replayed as a HIP graph
+  int fullband_group = 0;     // option fullband_group: rows per group of the fused full-band row pass (0: the kernel's default)
+  int64_t fullband_cache_cap = 0;   // bytes of full-band responses kept across executes (set at upload: option
+                                    // fullband_cache_mb, else a quarter of the memory free then, at most 16 GiB)
+  bool hfull_cache_full = false;    // a response could not be allocated: the cache stays as it is
   int synthp_help = -1;       // option synthp_help: share (of 128) of a round's tasks the producer waves take (A/B runs; default: by level)
   int synthp_lgnb = -1;       // option synthp_lgnb: blocks per k_synthp workgroup forced (A/B runs)
   int interp_lgnb = -1;       // option interp_lgnb: blocks per k_synthi workgroup forced (A/B runs)
@@ -349,11 +356,14 @@ int gcwt_rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, int
 static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   if (!out || !params) return set_err(GCWT_ERR_INVALID, "NULL argument");
   *out = nullptr;
-  gcwt_plan* p = new (std::nothrow) gcwt_plan();
+  // (held by a unique_ptr until it is handed over: build_host_plan may throw std::bad_alloc, which guarded()
+  // turns into GCWT_ERR_NOMEM after the partly built plan is gone)
+  std::unique_ptr<gcwt_plan> owner(new (std::nothrow) gcwt_plan());
+  gcwt_plan* p = owner.get();
   if (!p) return set_err(GCWT_ERR_NOMEM, "out of host memory");
   std::string err;
   int rc = build_host_plan(*params, &p->hp, &err);
-  if (rc != GCWT_OK) { delete p; return set_err(rc, err); }
+  if (rc != GCWT_OK) return set_err(rc, err);
   // the plan keeps its own copies of the arrays
   p->hp.prm.freqs_hz = p->hp.freqs.data();
   p->hp.prm.epoch_bounds = p->hp.bounds.data();
@@ -373,12 +383,14 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->use_synthp = option_or("synthp", 0) != 0;
   p->synthp_lgnb = (int)option_or("synthp_lgnb", -1);
   p->synthp_help = (int)option_or("synthp_help", -1);
+  p->use_graphs = option_or("graphs", 1) != 0;
+  p->fullband_group = (int)option_or("fullband_group", 0);
   p->synth_kernel = kMeasureBuild && option_or("synth_kernel", 7) == 8 ? 8 : 7;
   p->drop_stores = kMeasureBuild && option_is_set("synth_drop_stores") ? (int)std::max<long long>(1, option_or("synth_drop_stores", 1)) : 0;
   p->clock_probe = kMeasureBuild && option_is_set("clock_probe");
   for (const auto& s : p->hp.scales)
     if (s.method == GCWT_SCALE_DIRECT) p->max_direct_len = std::max(p->max_direct_len, s.length);
-  *out = p;
+  *out = owner.release();
   return GCWT_OK;
 }
 
@@ -420,13 +432,16 @@ int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info) {
       y = std::max<int64_t>(y, (int64_t)rows * kRowLen);
     }
     extra += 8 * 3 * slots * xs;                                        // shifted-band slices, one per level stream
-    if (hp.high_precision && hp.n_direct < hp.prm.n_freqs) extra += 16 * (slots * y + 8192);   // float64 intermediate + twiddles
+    if (hp.high_precision && plan->fast_fft && hp.n_direct + hp.n_blockconv < hp.prm.n_freqs)
+      extra += 16 * (slots * y + 8192);   // float64 intermediate + twiddles (what gcwt_plan_upload allocates: d_y, d_tw64)
+    extra += 8 * (2 * (int64_t)hp.direct_total + (int64_t)hp.n_direct);   // literal taps and tap sums beside the running sums
     int64_t listed = 0;
     for (const LevelPlan& lp : hp.levels) listed += (int64_t)lp.scales.size();
     extra += 4 * (listed + 8) * 256 + 8 * 256 * (int64_t)hp.levels.size();   // gain rows in list order, half-sample twiddles
     extra += 8 * (int64_t)channel_sum_doubles((size_t)C) + 4 * (int64_t)hp.interp_coef.size();
     if (hp.n_fullband > 0)
-      extra += std::min<int64_t>(kFullbandCacheBytes, 8 * (int64_t)hp.n_fullband * hp.max_p * (int64_t)hp.epochs.size());
+      extra += std::min<int64_t>(plan->uploaded ? plan->fullband_cache_cap : kFullbandCacheBytes,
+                                 8 * (int64_t)hp.n_fullband * hp.max_p * (int64_t)hp.epochs.size());
     info->workspace_bytes = hp.workspace_bytes + extra;
   }
   info->out_bytes = (int64_t)hp.out_elem_bytes * hp.prm.n_channels * hp.prm.n_freqs * hp.prm.n_samples;
@@ -824,6 +839,15 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   }
   he = hipStreamSynchronize(p->stream);  // host vectors above go out of scope
   if (he != hipSuccess) return bail(hip_err(he, "plan upload"));
+  if (hp.n_fullband > 0) {
+    // full-band responses kept across executes: a quarter of what is free now (after the workspace), at most
+    // 16 GiB; option fullband_cache_mb sets it (0: none are kept).  Nothing is allocated for it here: a response
+    // enters the cache when its scale is first computed, and a failed allocation closes the cache.
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    p->fullband_cache_cap = std::min<int64_t>(kFullbandCacheBytes, (int64_t)(free_b / 4));
+    if (option_is_set("fullband_cache_mb")) p->fullband_cache_cap = std::max<long long>(0, option_or("fullband_cache_mb", 0)) << 20;
+  }
   p->uploaded = true;
   return GCWT_OK;
 }
@@ -1168,9 +1192,12 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       float2* dst = p->d_hfull + (int64_t)scratch * hp.max_p;
       float2* keep = nullptr;
       const int64_t bytes = (int64_t)sizeof(float2) * P;
-      if (p->hfull_cache_bytes + bytes <= kFullbandCacheBytes) {
+      if (!p->hfull_cache_full && p->hfull_cache_bytes + bytes <= p->fullband_cache_cap) {
         if (hipMalloc((void**)&keep, (size_t)bytes) == hipSuccess) dst = keep;
-        else (void)hipGetLastError();        // no room: compute into the scratch row as before
+        else {                               // no room: compute into the scratch row as before, and stop asking
+          (void)hipGetLastError();
+          p->hfull_cache_full = true;
+        }
       }
       {   // the response enters the cache only once its launch has been accepted: a failed launch must not
           // leave an unfilled buffer behind for later executes to reuse
@@ -1206,7 +1233,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       // natural order; the usual FFT lengths store from the column pass's registers (2.9 GB of traffic per
       // scale at the headline shape; product, two passes and a store kernel moved 8)
       RUN(ST_FULLBAND, launch_fullband_rows(p->d_x, set, P1, P, P, p->d_bc_tw, p->d_tw256, slots, st,
-                                            (int)option_or("fullband_group", 0)));
+                                            p->fullband_group));
       for (int k = 0; k < np; ++k) {
         if (fullband_cols_fused(P1)) {
           RUN(ST_FULLBAND, launch_fullband_cols(mode, set.z[k], dout, P1, P, p->d_tw4096, p->d_tw256, member[k], S,
@@ -1343,7 +1370,7 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   // graph replay: device in and out, nothing to time, no full-band scale (its response cache allocates on the way),
   // and a result small enough for the launches to matter (16 M coefficients)
   const bool graphable = !p->graph_failed && !p->profiling && (flags & GCWT_X_ON_DEVICE) && (flags & GCWT_OUT_ON_DEVICE) &&
-                         hp.n_fullband == 0 && option_or("graphs", 1) != 0 &&
+                         hp.n_fullband == 0 && p->use_graphs &&
                          (int64_t)rows * n_out <= ((int64_t)1 << 24);
   const gcwt_plan::GraphKey key{dx, dout, r0, r1, row_len, reuse};
   bool done = false;
@@ -1563,7 +1590,7 @@ int gcwt_debug_graph_state(const gcwt_plan* p) {
 }
 
 int gcwt_debug_blockconv_groups(const gcwt_plan* p, int32_t* first, int32_t* count, int32_t* hop, int32_t* back,
-                                int32_t* order, int max_groups) {
+                                int32_t* order, int max_groups, int max_order) {
   if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
   const HostPlan& hp = p->hp;
   const int n = (int)hp.bc_groups.size();
@@ -1573,7 +1600,7 @@ int gcwt_debug_blockconv_groups(const gcwt_plan* p, int32_t* first, int32_t* cou
     if (hop) hop[g] = hp.bc_groups[g].hop;
     if (back) back[g] = hp.bc_groups[g].back;
   }
-  if (order) for (int k = 0; k < hp.n_blockconv; ++k) order[k] = hp.bc_order[k];
+  if (order) for (int k = 0; k < hp.n_blockconv && k < max_order; ++k) order[k] = hp.bc_order[k];
   return n;
 }
 

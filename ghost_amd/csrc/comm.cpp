@@ -78,6 +78,8 @@ struct gcwt_comm {
   int rank = 0, n_ranks = 1;
   hipStream_t stream = nullptr;
   double* d_val = nullptr;
+  int device = -1;              // the device that was current when the communicator was made: every later call
+                                // on it selects that device itself (a caller may have moved on to another)
 };
 
 // errors from this file are reported through the same gcwt_last_error() string
@@ -116,6 +118,13 @@ int gcwt_comm_create(gcwt_comm** out, int rank, int n_ranks, const void* id128) 
   if (!r.ok) return cerr_(GCWT_ERR_COMM, "librccl not found or incomplete");
   gcwt_comm* c = new (std::nothrow) gcwt_comm();
   if (!c) return cerr_(GCWT_ERR_NOMEM, "out of host memory");
+  // ncclCommInitRank binds the communicator to the calling thread's current device: take note of it (and make
+  // sure there is one: without a device this is the caller's error, not RCCL's)
+  if (hipGetDevice(&c->device) != hipSuccess || hipSetDevice(c->device) != hipSuccess) {
+    (void)hipGetLastError();
+    delete c;
+    return cerr_(GCWT_ERR_NO_DEVICE, "no current HIP device for the communicator (gcwt_set_device first)");
+  }
   c->rank = rank;
   c->n_ranks = n_ranks;
   ncclUniqueId id;
@@ -135,6 +144,7 @@ int gcwt_comm_create(gcwt_comm** out, int rank, int n_ranks, const void* id128) 
 
 void gcwt_comm_destroy(gcwt_comm* c) {
   if (!c) return;
+  if (c->device >= 0) (void)hipSetDevice(c->device);
   if (c->d_val) (void)hipFree(c->d_val);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->comm) rccl().CommDestroy(c->comm);
@@ -156,6 +166,7 @@ void gcwt_comm_abort(gcwt_comm* c) {
 
 int gcwt_comm_allreduce_max(gcwt_comm* c, double* value) {
   if (!c || !value) return cerr_(GCWT_ERR_INVALID, "NULL argument");
+  if (hipSetDevice(c->device) != hipSuccess) return cerr_(GCWT_ERR_HIP, "the communicator's device cannot be selected");
   if (hipMemcpyAsync(c->d_val, value, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess)
     return cerr_(GCWT_ERR_HIP, "copy to device failed");
   ncclResult_t rc;
@@ -176,8 +187,13 @@ int gcwt_comm_broadcast_bank(gcwt_comm* c, gcwt_plan* plan, int root) {
   if (!c || !plan) return cerr_(GCWT_ERR_INVALID, "NULL argument");
   int rc = gcwt_plan_upload(plan);
   if (rc) return rc;
+  // the plan's bank lives on the plan's device; the communicator must have been made on the same one
+  hipPointerAttribute_t attr;
   size_t bytes = 0;
   float2* bank = gcwt_internal_bank_ptr(plan, &bytes);
+  if (hipPointerGetAttributes(&attr, bank) == hipSuccess && attr.device != c->device)
+    return cerr_(GCWT_ERR_INVALID, "the plan and the communicator are on different devices");
+  if (hipSetDevice(c->device) != hipSuccess) return cerr_(GCWT_ERR_HIP, "the communicator's device cannot be selected");
   hipStream_t st = gcwt_internal_stream(plan);
   const ncclResult_t nr = rccl().Broadcast(bank, bank, bytes, kNcclUint8, root, c->comm, st);
   if (nr != 0) return nccl_fail("ncclBroadcast", nr);

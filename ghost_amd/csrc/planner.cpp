@@ -979,7 +979,11 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     EpochPlan& lead = hp->epochs[first];
     int64_t blocks = 0;
     for (size_t l = 0; l < hp->levels.size(); ++l) blocks += (int64_t)lead.lv[l].nblk * B;
-    const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks + std::min(hp->n_fullband, 4) * lead.p);   // X + x_R (< P) + XB (+ Z), roughly
+    // X + x_R (< P) + XB (+ Z), roughly; precision = high adds the float64 intermediate of the forward transform,
+    // 16 bytes for rows 0 .. P1/2 of the spectrum (every row when full-band scales read all of it)
+    const int64_t y_rows = !hp->high_precision ? 0 : (lead.p1 >= 4 && hp->n_fullband == 0 ? lead.p1 / 2 + 1 : lead.p1);
+    const int64_t per_slot = 8 * C * (lead.p + lead.p + 2 * blocks + std::min(hp->n_fullband, 4) * lead.p) +
+                             16 * C * y_rows * 4096;
     int cap = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBatch, budget / std::max<int64_t>(1, per_slot)));
     cap = (int)std::max<int64_t>(1, std::min<int64_t>(cap, 65535 / C));   // grid.y = segments * channels
     size_t count = 1;

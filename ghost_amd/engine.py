@@ -338,14 +338,15 @@ class CwtPlan:
     def debug_blockconv(self):
         """Groups of the block-convolution scales: [{"scales": rows in order of kernel length, "hop", "back"}]."""
         i32p = C.POINTER(C.c_int32)
-        arr = [np.zeros(64, np.int32) for _ in range(4)]
-        order = np.zeros(max(1, self.info["n_blockconv"]), np.int32)
+        n_bc = max(1, self.info["n_blockconv"])       # at most one group per scale
+        arr = [np.zeros(n_bc, np.int32) for _ in range(4)]
+        order = np.zeros(n_bc, np.int32)
         n = lib.gcwt_debug_blockconv_groups(self._handle, *[a.ctypes.data_as(i32p) for a in arr],
-                                            order.ctypes.data_as(i32p), 64)
+                                            order.ctypes.data_as(i32p), n_bc, n_bc)
         if n < 0:
             check(n)
         return [{"scales": order[arr[0][g]:arr[0][g] + arr[1][g]].tolist(), "hop": int(arr[2][g]), "back": int(arr[3][g])}
-                for g in range(n)]
+                for g in range(min(n, n_bc))]
 
     def debug_interp(self):
         """Per level: None when it is made by the FFT-per-sample kernels, else the interpolating

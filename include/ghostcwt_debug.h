@@ -40,11 +40,12 @@ int gcwt_debug_scale_theta_lo(const gcwt_plan* plan, double* theta_lo);
 /* Small device-resident executes replay a HIP graph from the third call with the same arguments on: 1 = a graph is
  * instantiated, 0 = none (yet), -1 = capture failed once and the plan runs eagerly. */
 int gcwt_debug_graph_state(const gcwt_plan* plan);
-/* Block convolution (GCWT_SCALE_BLOCKCONV): the scales in order of kernel length (`order`, n_blockconv entries)
- * and the groups of consecutive entries that share the spectra of their blocks: blocks of `hop` output
- * samples from the 4096 recording samples that start `back` before them.  Returns the number of groups. */
+/* Block convolution (GCWT_SCALE_BLOCKCONV): the scales in order of kernel length (`order`: n_blockconv entries, at
+ * most max_order are written) and the groups of consecutive entries that share the spectra of their blocks (at
+ * most max_groups are written): blocks of `hop` output samples from the 4096 recording samples that start `back`
+ * before them.  Returns the number of groups. */
 int gcwt_debug_blockconv_groups(const gcwt_plan* plan, int32_t* first, int32_t* count, int32_t* hop,
-                                int32_t* back, int32_t* order, int max_groups);
+                                int32_t* back, int32_t* order, int max_groups, int max_order);
 /* Segments of equal FFT length are launched together: first segment and size of the batch
  * that `segment` belongs to. */
 int gcwt_debug_batch_of(const gcwt_plan* plan, int segment, int32_t* first, int32_t* count);
