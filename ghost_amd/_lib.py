@@ -83,6 +83,7 @@ def _load():
         "gcwt_plan_scale_info": (C.c_int, [vp, i32p, i32p, i32p, i32p, i64p]),
         "gcwt_plan_scale_support": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i32p]),
         "gcwt_plan_set_profiling": (C.c_int, [vp, C.c_int]),
+        "gcwt_plan_precision_report": (C.c_int, [vp, f32p, f32p, i32p]),
         "gcwt_plan_set_row_pitch": (C.c_int, [vp, C.c_int64]),
         "gcwt_plan_upload": (C.c_int, [vp]),
         "gcwt_execute": (C.c_int, [vp, vp, vp, C.c_int]),
@@ -106,6 +107,7 @@ def _load():
         "gcwt_debug_level_low_cut": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
         "gcwt_debug_scale_theta_lo": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "gcwt_debug_graph_state": (C.c_int, [vp]),
+        "gcwt_debug_precision_terms": (C.c_int, [vp, f32p, f32p, f32p]),
         "gcwt_debug_blockconv_groups": (C.c_int, [vp] + [C.POINTER(C.c_int32)] * 5 + [C.c_int, C.c_int]),
         "gcwt_debug_batch_of": (C.c_int, [vp, C.c_int, i32p, i32p]),
         "gcwt_debug_level_info": (C.c_int, [vp, C.c_int, C.c_int, i32p, i32p, i32p, i32p, i64p]),

@@ -76,6 +76,7 @@ struct EpochDev {
   SynthpItem* items_p[2] = {nullptr, nullptr};   // pipelined interpolating kernel (synthp.hip); [1]: levels with I = 4
   SynthpLevel* levels_p = nullptr;
   int n_items_p[2] = {0, 0};
+  PredLevel* pred_levels = nullptr;              // precision = auto / high: what each level's x_R holds (detect.hip)
 };
 
 // full-band responses kept on the device across executes (one P-point row per (scale, FFT length)); counted in
@@ -178,6 +179,28 @@ struct gcwt_plan {
   gcwt_timings last{};
   bool have_timings = false;
   bool have_means = false;
+  // precision = auto / high: the detector (detect.hip).  d_hist: band energies of the spectrum per slot, filled by the
+  // forward row pass; d_pred: per scale, the largest predicted loss over the slots of an execute.
+  bool detect = false;               // the plan predicts (float64 forward transform, no long mode, some spectral scale)
+  float* d_hist = nullptr;
+  float* d_pred = nullptr;
+  int32_t* d_scale_level = nullptr;
+  int32_t* d_scale_length = nullptr;   // the reference kernel's L per scale (capped at 2^30)
+  std::vector<float> last_pred;      // the last execute's predictions (host)
+  float last_worst = 0.f;
+  int last_rerouted = 0;
+  float auto_threshold = 3e-6f;      // option auto_threshold_ppb
+  float kappa_eps = 1.6e-7f;         // predicted loss = kappa_eps sqrt(E_level W_s / E_s); option auto_kappa_ppb
+  float oob_tol = 2.5e-8f;            // ... or oob_tol sqrt(E_out / E_s), what the level leaves out; option auto_oob_ppt (1e-12)
+  int last_batch_slots = 0;          // slots of the last batch that ran (gcwt_debug_precision_terms)
+  int last_batch = 0, last_rows = 0;
+  double last_pt = 0;
+  // scales made again by the exact paths: one sub-plan (precision = exact, those scales only) per set of scales,
+  // its dense result scattered into this plan's rows
+  struct SubPlan { gcwt_plan* plan = nullptr; int32_t* d_rows = nullptr; };
+  std::map<std::vector<int32_t>, SubPlan> sub_plans;
+  float* d_sub_out = nullptr;
+  size_t d_sub_out_bytes = 0;
   // Small device-resident executes are launch-bound (config 1: fifteen kernels of a few microseconds each): the
   // second execute with the same arguments is captured into a graph, later ones replay it
   struct GraphKey {
@@ -216,11 +239,18 @@ void free_dev(gcwt_plan* p) {
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc); fr(p->d_bc_h); fr(p->d_bc_rows); fr(p->d_bc_x); fr(p->d_bc_tw);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
+  fr(p->d_hist); fr(p->d_pred); fr(p->d_scale_level); fr(p->d_scale_length); fr(p->d_sub_out);
+  p->d_sub_out_bytes = 0;
+  for (auto& kv : p->sub_plans) {
+    if (kv.second.d_rows) (void)hipFree(kv.second.d_rows);
+    if (kv.second.plan) gcwt_plan_destroy(kv.second.plan);
+  }
+  p->sub_plans.clear();
   for (auto& kv : p->hfull_cache) (void)hipFree(kv.second);
   p->hfull_cache.clear();
   p->hfull_cache_bytes = 0;
   p->host_out.release();
-  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.items7w); fr(e.levels7); fr(e.items_i); fr(e.levels_i); fr(e.items_p[0]); fr(e.items_p[1]); fr(e.levels_p); }
+  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.items7w); fr(e.levels7); fr(e.items_i); fr(e.levels_i); fr(e.items_p[0]); fr(e.items_p[1]); fr(e.levels_p); fr(e.pred_levels); }
   p->ep_dev.clear();
   if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
@@ -384,6 +414,9 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->synthp_lgnb = (int)option_or("synthp_lgnb", -1);
   p->synthp_help = (int)option_or("synthp_help", -1);
   p->use_graphs = option_or("graphs", 1) != 0;
+  p->auto_threshold = 1e-9f * (float)option_or("auto_threshold_ppb", 3000);
+  p->kappa_eps = 1e-9f * (float)option_or("auto_kappa_ppb", 160);
+  p->oob_tol = 1e-12f * (float)option_or("auto_oob_ppt", 25000);
   p->fullband_group = (int)option_or("fullband_group", 0);
   p->synth_kernel = kMeasureBuild && option_or("synth_kernel", 7) == 8 ? 8 : 7;
   p->drop_stores = kMeasureBuild && option_is_set("synth_drop_stores") ? (int)std::max<long long>(1, option_or("synth_drop_stores", 1)) : 0;
@@ -825,6 +858,45 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     }
   }
 
+  // precision = auto / high: the detector's tables (detect.hip)
+  {
+    bool long_mode = false, any_level = false;
+    for (const EpochPlan& ep : hp.epochs) long_mode = long_mode || ep.long_a > 1;
+    std::vector<int32_t> scale_level((size_t)S, -1);
+    for (int i = 0; i < S; ++i)
+      if (hp.scales[i].method == GCWT_SCALE_SPECTRAL && hp.scales[i].level >= 0) { scale_level[(size_t)i] = hp.scales[i].level; any_level = true; }
+    p->detect = hp.high_precision && !hp.exact_only && p->d_y && !long_mode && any_level;
+    if (p->detect) {
+      const int64_t slots = (int64_t)C * hp.max_batch;
+      int64_t max_rows = 1;                              // rows of the forward row pass: run_pipeline's rows_a
+      for (const EpochPlan& ep : hp.epochs)
+        max_rows = std::max<int64_t>(max_rows, ep.p1);
+      if ((rc = dev_alloc(&p->d_hist, (size_t)(slots * max_rows * kSpecBands)))) return bail(rc);
+      if ((rc = dev_alloc(&p->d_pred, (size_t)S))) return bail(rc);
+      if ((rc = upload_vec(&p->d_scale_level, scale_level, p->stream))) return bail(rc);
+      std::vector<int32_t> scale_length((size_t)S);
+      for (int i = 0; i < S; ++i) scale_length[(size_t)i] = (int32_t)std::min<int64_t>(hp.scales[i].length, (int64_t)1 << 30);
+      if ((rc = upload_vec(&p->d_scale_length, scale_length, p->stream))) return bail(rc);
+      for (size_t e = 0; e < hp.epochs.size(); ++e) {
+        const EpochPlan& ep = hp.epochs[e];
+        if (ep.batch_count == 0) continue;
+        std::vector<PredLevel> pl(hp.levels.size());
+        for (size_t l = 0; l < hp.levels.size(); ++l) {
+          const LevelPlan& lp = hp.levels[l];
+          const LevelPlan& own = hp.levels[lp.xr_owner >= 0 ? (size_t)lp.xr_owner : l];   // whose x_R the level reads
+          pl[l] = {lp.scales.empty() ? 0 : lp.decimation, lp.band_shift, 0.f, 0.f};
+          if (own.taper_hi > 0.0 && own.band_shift == 0) {                                 // run_pipeline: RowTaper
+            const double k1 = own.taper_hi * (double)ep.p / (2.0 * M_PI), k0 = 0.5 * k1;
+            if (k1 - k0 >= 1.0) { pl[l].k0 = (float)k0; pl[l].k1 = (float)k1; }
+          }
+        }
+        if ((rc = upload_vec(&p->ep_dev[e].pred_levels, pl, p->stream))) return bail(rc);
+      }
+      p->last_pred.assign((size_t)S, 0.f);
+      HIP_TRY(hipStreamSynchronize(p->stream));       // the vectors of this block go out of scope
+    }
+  }
+
   hipError_t he = launch_build_bank(p->d_bank, p->d_gain, p->d_bank_sc, p->d_amps, S, B, p->stream);
   if (he != hipSuccess) return bail(hip_err(he, "build_bank"));
   he = launch_scale_windows(p->d_gain, p->d_scale_list, p->n_listed, (float)hp.band_tol, p->d_gain_lv,
@@ -876,6 +948,10 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
   } while (0)
 
   if (!reuse_means) RUN(ST_MEAN, launch_channel_sum(dx, N, C, p->d_sums, st));
+  if (p->detect) {
+    he = hipMemsetAsync(p->d_pred, 0, sizeof(float) * (size_t)S, st);
+    if (he != hipSuccess) return hip_err(he, "predictions reset");
+  }
 
   // samples outside every epoch are zero (transforms.py:185): one launch per gap, or one
   // fill of the whole result when there are many of them
@@ -948,6 +1024,8 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         RUN(ST_FWD, launch_fwd64_rows(p->d_y, p->d_x, rows_a, p->y_stride, P, p->d_tw64, slots,
                                       hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0, st, a, A, Pt));
       }
+      // precision = auto / high: the spectrum's band energies, for the detector (detect.hip)
+      if (p->detect) RUN(ST_FWD, launch_spectrum_bands(p->d_x, P, P1, p->d_hist, slots, st));
     } else if (A > 1) {
       return set_err(GCWT_ERR_UNSUPPORTED, "internal: long mode without the float64 forward transform");
     } else {
@@ -1184,6 +1262,14 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       if (he == hipSuccess) he = hipStreamWaitEvent(st, interp_done, 0);
       if (he != hipSuccess) return hip_err(he, "synthesis join");
     }
+    if (p->detect && p->d_y) {
+      // what the float32 stages cost each scale, predicted from the band energies the forward pass left (detect.hip);
+      // launched behind the synthesis, where it runs in the launch's tail (d_hist is reset by the next batch's forward)
+      he = launch_precision_predict(p->d_hist, P1, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[ep.batch_first].pred_levels, S,
+                                    (int)hp.levels.size(), (double)Pt, p->kappa_eps, p->oob_tol, p->d_pred, nullptr, nullptr, slots, st);
+      if (he != hipSuccess) return hip_err(he, "launch_precision_predict");
+      p->last_batch_slots = slots; p->last_batch = ep.batch_first; p->last_pt = (double)Pt; p->last_rows = P1;
+    }
     if (p->profiling && !hp.levels.empty()) p->last.synth_launches++;
     // full-band scales: W = IFFT_P(X H_s) for every slot of the batch, up to four scales per pass over X
     auto response = [&](int i, int scratch, const float2** h_out) -> int {
@@ -1320,6 +1406,55 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
   return GCWT_OK;
 }
 
+static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int64_t r1, int flags);
+static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params);
+
+// precision = auto: samples [r0, r1) of the scales `over` again, by a plan of precision = exact that holds just
+// them (made on first use, kept per set of scales), from the same device-resident recording; its dense rows are
+// copied over the fast path's.  The sub-plan computes its own channel means (same numbers: same kernel, same x).
+static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t r0, int64_t r1, int64_t row_len,
+                          const std::vector<int32_t>& over) {
+  const HostPlan& hp = p->hp;
+  gcwt_plan::SubPlan& sp = p->sub_plans[over];
+  if (!sp.plan) {
+    std::vector<double> f(over.size());
+    for (size_t i = 0; i < over.size(); ++i) f[i] = hp.freqs[(size_t)over[i]];
+    gcwt_params prm = hp.prm;
+    prm.freqs_hz = f.data();
+    prm.n_freqs = (int32_t)f.size();
+    prm.precision = GCWT_PRECISION_EXACT;
+    prm.device = p->device;
+    int rc = gcwt_plan_create_impl(&sp.plan, &prm);
+    if (rc) { p->sub_plans.erase(over); return rc; }
+    if ((rc = gcwt_plan_upload(sp.plan))) { gcwt_plan_destroy(sp.plan); p->sub_plans.erase(over); return rc; }
+    if (hipMalloc((void**)&sp.d_rows, sizeof(int32_t) * over.size()) != hipSuccess ||
+        hipMemcpy(sp.d_rows, over.data(), sizeof(int32_t) * over.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      gcwt_plan_destroy(sp.plan);
+      if (sp.d_rows) (void)hipFree(sp.d_rows);
+      p->sub_plans.erase(over);
+      return set_err(GCWT_ERR_NOMEM, "no device memory for the rerouted scales' row list");
+    }
+  }
+  const int64_t n_out = r1 - r0;
+  const int64_t pitch = (n_out + 31) & ~(int64_t)31;
+  const int elem = hp.out_elem_bytes / (int)sizeof(float);
+  const size_t need = sizeof(float) * (size_t)elem * (size_t)pitch * over.size() * (size_t)hp.prm.n_channels;
+  if (p->d_sub_out_bytes < need) {
+    if (p->d_sub_out) { (void)hipFree(p->d_sub_out); p->d_sub_out = nullptr; p->d_sub_out_bytes = 0; }
+    HIP_TRY(hipMalloc((void**)&p->d_sub_out, need));
+    p->d_sub_out_bytes = need;
+  }
+  sp.plan->row_pitch = pitch;
+  int rc = execute_range(sp.plan, dx, p->d_sub_out, r0, r1, GCWT_X_ON_DEVICE | GCWT_OUT_ON_DEVICE);
+  if (rc) return rc;
+  hipError_t he = launch_scatter_rows(p->d_sub_out, dout, sp.d_rows, (int)over.size(), hp.prm.n_freqs, hp.prm.n_channels,
+                                      n_out * elem, pitch * elem, row_len * elem, p->stream);
+  if (he != hipSuccess) return hip_err(he, "launch_scatter_rows");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return GCWT_OK;
+}
+
 static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int64_t r1, int flags) {
   if ((flags & GCWT_OUT_F64) && (flags & GCWT_OUT_ON_DEVICE))
     return set_err(GCWT_ERR_INVALID, "GCWT_OUT_F64 applies to host output only");
@@ -1410,6 +1545,24 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
     }
   }
   p->have_means = true;
+  if (p->detect) {
+    // precision = auto / high: read the predictions; auto makes the scales over the threshold again by the exact paths
+    // (a sub-plan with precision = exact for just those scales; its rows replace the fast path's)
+    HIP_TRY(hipMemcpyAsync(p->last_pred.data(), p->d_pred, sizeof(float) * p->last_pred.size(), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    std::vector<int32_t> over;
+    p->last_worst = 0.f;
+    for (size_t i = 0; i < p->last_pred.size(); ++i) {
+      p->last_worst = std::max(p->last_worst, p->last_pred[i]);
+      if (p->last_pred[i] > p->auto_threshold) over.push_back((int32_t)i);
+    }
+    p->last_rerouted = 0;
+    if (hp.auto_precision && !over.empty()) {
+      rc = reroute_scales(p, dx, dout, r0, r1, row_len, over);
+      if (rc) return rc;
+      p->last_rerouted = (int)over.size();
+    }
+  }
   if (!(flags & GCWT_OUT_ON_DEVICE)) {
     // complex rows are float pairs: the same routine moves (and widens) them
     const size_t k = hp.out_elem_bytes / sizeof(float);
@@ -1506,6 +1659,38 @@ int gcwt_direct_kernel(gcwt_plan* p, int scale, float* psi) {
   if (rc) return rc;
   HIP_TRY(hipMemcpy(psi, p->d_psi_lit + s.direct_offset + direct_front_pad(s.length), sizeof(float2) * (size_t)s.length,
                     hipMemcpyDeviceToHost));
+  return GCWT_OK;
+}
+
+int gcwt_plan_precision_report(const gcwt_plan* p, float* predicted, float* worst, int32_t* n_rerouted) {
+  if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  const size_t S = (size_t)p->hp.prm.n_freqs;
+  if (predicted)
+    for (size_t i = 0; i < S; ++i) predicted[i] = i < p->last_pred.size() ? p->last_pred[i] : 0.f;
+  if (worst) *worst = p->last_worst;
+  if (n_rerouted) *n_rerouted = p->last_rerouted;
+  return GCWT_OK;
+}
+
+// test hook: the two terms of the prediction (rounding of the level's stages; what the level leaves out) of workspace
+// slot 0 of the last batch the last execute ran, S floats each, and the level energies (n_levels floats, may be NULL)
+int gcwt_debug_precision_terms(gcwt_plan* p, float* rounding, float* left_out, float* level_energy) {
+  if (!p || !rounding || !left_out) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  if (!p->detect || p->last_batch_slots <= 0) return set_err(GCWT_ERR_INVALID, "no execute with the detector on yet");
+  const int S = p->hp.prm.n_freqs, L = (int)p->hp.levels.size();
+  float *d_sc = nullptr, *d_lv = nullptr, *d_pr = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_sc, sizeof(float) * 2 * (size_t)S * p->last_batch_slots));
+  HIP_TRY(hipMalloc((void**)&d_lv, sizeof(float) * (size_t)L * p->last_batch_slots));
+  HIP_TRY(hipMalloc((void**)&d_pr, sizeof(float) * (size_t)S));
+  HIP_TRY(hipMemsetAsync(d_pr, 0, sizeof(float) * (size_t)S, p->stream));
+  hipError_t he = launch_precision_predict(p->d_hist, p->last_rows, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[p->last_batch].pred_levels, S, L,
+                                           p->last_pt, p->kappa_eps, p->oob_tol, d_pr, d_lv, d_sc, p->last_batch_slots, p->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(rounding, d_sc, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, p->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(left_out, d_sc + S, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, p->stream);
+  if (he == hipSuccess && level_energy) he = hipMemcpyAsync(level_energy, d_lv, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, p->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(p->stream);
+  (void)hipFree(d_sc); (void)hipFree(d_lv); (void)hipFree(d_pr);
+  if (he != hipSuccess) return hip_err(he, "precision terms");
   return GCWT_OK;
 }
 

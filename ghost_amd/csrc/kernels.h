@@ -300,6 +300,38 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
 hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
                              const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st,
                              int comb_a = 0, int comb_n = 1, int64_t p_true = 0);
+
+// precision = auto (detect.hip): what the float32 stages of the decimated path will cost each scale, predicted from
+// the float64 spectrum while it is made.  The positive half of the spectrum is summed into bands, sixteen per octave:
+// bin k >= 1 belongs to band (bits of (float) k >> 19) - 127 * 16, i.e. [2^e (1 + m / 16), 2^e (1 + (m + 1) / 16)).
+constexpr int kSpecBands = 16 * 24;
+__host__ __device__ inline int spec_band(float k) {
+  union { float f; uint32_t u; } b;
+  b.f = k;
+  const int v = (int)(b.u >> 19) - 127 * 16;
+  return v < 0 ? 0 : (v >= kSpecBands ? kSpecBands - 1 : v);
+}
+struct PredLevel {
+  int32_t decimation;       // R: the level's x_R holds the spectrum bins below P / R (after its low cut)
+  int32_t band_shift;       // bins of the level's 256-point grid below zero frequency (shifted bands: no low cut)
+  float k0, k1;             // low cut in spectrum bins: zero below k0, raised to one at k1 (k1 <= k0: none)
+};
+// One workgroup per (slot, level): E_level = the band energies the level's x_R contains, E_s = those a scale's gains let
+// through, W_s = sum G_s^2 / 256 (its share of a white noise floor); pred[s] = max over slots of
+// kappa_eps sqrt(E_level W_s / E_s) -- the float32 rounding of the level transform and block spectra, white at
+// ~2^-24 of the level's content, against the scale's own output -- and oob_tol sqrt(E_out / E_s), E_out what the
+// level's x_R leaves out (the reference's kernel answers to it through its side lobes; the decimated path does
+// not).  scale_level[s] < 0: not on the decimated path.  dbg_scale: [slots][2][S], the two terms.
+// hist: [slots][p1][kSpecBands], the energy |X|^2 of bins 0 < k < P / 2 of the k1-major spectrum x ([slot][p1 rows][4096],
+// bin k1 + p1 k2 at (k1, k2)) summed into bands per (slot, row); plain stores, no reset needed
+hipError_t launch_spectrum_bands(const float2* x, int64_t x_cstride, int p1, float* hist, int n_slots, hipStream_t st);
+hipError_t launch_precision_predict(const float* hist, int n_rows, const float* gain, const int32_t* scale_level,
+                                    const int32_t* scale_length, const PredLevel* levels, int n_scales, int n_levels, double p_true,
+                                    float kappa_eps, float oob_tol, float* pred, float* dbg_level, float* dbg_scale,
+                                    int n_slots, hipStream_t st);
+// rows of a sub-plan's dense result [C][n_sub][row_len] into rows `rows[i]` of the full one [C][n_scales][row_len]
+hipError_t launch_scatter_rows(const float* src, float* dst, const int32_t* rows, int n_sub, int n_scales,
+                               int n_channels, int64_t row_elems, int64_t src_pitch, int64_t dst_pitch, hipStream_t st);
 // shifted band of a level: Xs[k1][j2] = X[k1 + P1 (j2 - u2)] from the positive half of a real signal's
 // k1-major spectrum (kernels.hip: k_shift_gather)
 hipError_t launch_shift_gather(const float2* x, float2* xs, int p1, int q, int u2, int64_t x_row,

@@ -511,9 +511,10 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   if (prm.support_tol > 0) hp->support_tol = prm.support_tol;
   if (hp->support_tol > 1e-2) return fail(GCWT_ERR_INVALID, "support_tol too large");
   if (prm.reserved0 != 0) return fail(GCWT_ERR_INVALID, "gcwt_params.reserved0 must be 0 (caller built against an older ghostcwt.h?)");
-  if (prm.precision < 0 || prm.precision > 3) return fail(GCWT_ERR_INVALID, "bad precision (0 default, 1 fast, 2 high, 3 exact)");
+  if (prm.precision < 0 || prm.precision > 4) return fail(GCWT_ERR_INVALID, "bad precision (0 default = 4 auto, 1 fast, 2 high, 3 exact)");
   hp->high_precision = prm.precision != GCWT_PRECISION_FAST;
   hp->exact_only = prm.precision == GCWT_PRECISION_EXACT;
+  hp->auto_precision = prm.precision == GCWT_PRECISION_DEFAULT || prm.precision == GCWT_PRECISION_AUTO;
   if (hp->exact_only) {                     // every kernel through a float64 spectrum: none in the time domain either
     hp->direct_max_len = 0;
     hp->blockconv_max_len = kBlockConvExactMaxLen;

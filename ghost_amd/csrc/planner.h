@@ -155,6 +155,8 @@ struct HostPlan {
   int n_direct = 0;
   int n_blockconv = 0;
   bool exact_only = false;         // precision = exact: no scale takes a decimated band or the time domain
+  bool auto_precision = false;     // precision = default / auto: scales whose predicted float32 loss is too large are
+                                   // made again by the exact paths (api.cpp); high predicts and reports only
   int direct_max_len = kDirectDefaultLen, blockconv_max_len = kBlockConvMaxLen;   // (options direct_max_len, blockconv)
   std::vector<int> bc_order;       // block-convolution scales by kernel length
   struct BcGroup {                 // consecutive entries of bc_order that share one set of block spectra

@@ -175,9 +175,9 @@ class CwtPlan:
         p.wavelet_flags = int(order) | (_lib.WAVELET_ENERGY if normalization == "energy" else 0)
         # 'high' (default): float64 forward transform and per-level low cut, the reference's dynamic
         # range (it computes in float64: transforms.py:142-143); 'fast': float32 throughout
-        if precision not in (None, "default", "fast", "high", "exact"):
-            raise ValueError("precision must be 'fast', 'high' or 'exact'")
-        p.precision = {None: 0, "default": 0, "fast": 1, "high": 2, "exact": 3}[precision]
+        if precision not in (None, "default", "auto", "fast", "high", "exact"):
+            raise ValueError("precision must be 'auto', 'fast', 'high' or 'exact'")
+        p.precision = {None: 0, "default": 0, "auto": 4, "fast": 1, "high": 2, "exact": 3}[precision]
         p.support_tol = float(support_tol)
         check(lib.gcwt_plan_create(C.byref(self._handle), C.byref(p)))
         self.n_samples, self.n_channels = int(n_samples), int(n_channels)
@@ -228,6 +228,25 @@ class CwtPlan:
         """Row pitch (samples) of device output buffers; 0 = dense.  Use a multiple of 32
         when the row length is not one (see gcwt_plan_set_row_pitch)."""
         check(lib.gcwt_plan_set_row_pitch(self._handle, int(pitch_samples)))
+
+    def precision_report(self):
+        """After an execute with precision 'auto' (the default) or 'high': {"predicted": per scale, the loss to the
+        float32 stages of its decimation level predicted from the recording's spectrum (relative to the scale's own
+        output; 0 for scales on the exact paths), "worst", "rerouted": how many scales the last execute made again by
+        the exact paths}."""
+        pred = np.zeros(self.n_freqs, np.float32)
+        worst, n = C.c_float(0), C.c_int32(0)
+        check(lib.gcwt_plan_precision_report(self._handle, pred.ctypes.data_as(C.POINTER(C.c_float)), C.byref(worst), C.byref(n)))
+        return {"predicted": pred, "worst": float(worst.value), "rerouted": int(n.value)}
+
+    def debug_precision_terms(self):
+        """The two terms of the last execute's prediction (slot 0 of its last batch): float32 rounding of the level's
+        stages, and what the level's slice of the spectrum leaves out; plus the energy each level's x_R held."""
+        a, b = np.zeros(self.n_freqs, np.float32), np.zeros(self.n_freqs, np.float32)
+        lv = np.zeros(max(1, self.info["n_levels"]), np.float32)
+        f32p = C.POINTER(C.c_float)
+        check(lib.gcwt_debug_precision_terms(self._handle, a.ctypes.data_as(f32p), b.ctypes.data_as(f32p), lv.ctypes.data_as(f32p)))
+        return {"rounding": a, "left_out": b, "level_energy": lv}
 
     def timings(self):
         t = _lib.Timings()

@@ -169,10 +169,12 @@ class ContinuousWaveletTransform(WaveletTransform):
         self._wavelet.fs = self._fs                            # transforms.py:179
 
         from ..engine import CwtPlan   # needs the built library; no CPU fallback
-        if precision not in (None, "high", "fast", "exact"):
-            raise ValueError("'precision' must be 'high' (default: the reference's float64 dynamic range in "
-                             "front of the float32 synthesis), 'fast' (float32 throughout) or 'exact' (no decimated "
-                             "path: every scale's float32 stages see only what its own filter lets through)")
+        if precision not in (None, "auto", "high", "fast", "exact"):
+            raise ValueError("'precision' must be 'auto' (default: 'high', with the scales a strong in-band "
+                             "interferer would cost their low bits made again by the exact paths), 'high' (the "
+                             "reference's float64 dynamic range in front of the float32 synthesis), 'fast' (float32 "
+                             "throughout) or 'exact' (no decimated path: every scale's float32 stages see only what "
+                             "its own filter lets through)")
         key = (n_samples, n_channels, float(self._fs), f.tobytes(), float(self._wavelet.gamma),
                float(self._wavelet.beta), epoch_bounds.tobytes(), output, int(device), precision)
         if self._plan is None or self._plan_key != key:
@@ -190,6 +192,21 @@ class ContinuousWaveletTransform(WaveletTransform):
         self._amplitude = self._power = self._coefficients = None
         self._device_result = self._plan.execute_resident(x, self._device_result)
         self._pending = (output, np.dtype(dtype), squeeze)
+        # the detector's verdict (precision 'auto' / 'high': DESIGN.md 3): scales whose decimation level holds far more
+        # than they do -- a mains line inside an analysed band -- were made again by the exact paths ('auto'), or are
+        # reported ('high')
+        self.precision_report = None
+        if precision in (None, "auto", "high"):
+            rep = self.precision_report = self._plan.precision_report()
+            if rep["rerouted"]:
+                logging.warning("{} of {} scales were recomputed by exact FFT convolution: the recording holds up to {:.0f} x "
+                                "more in their decimation bands than in the scales themselves (predicted float32 loss {:.1e} "
+                                "of a scale's peak; precision='high' skips this, 'exact' does it for every scale)"
+                                .format(rep["rerouted"], f.size, rep["worst"] / 1.6e-7, rep["worst"]))
+            elif precision == "high" and rep["worst"] > 3e-6:
+                logging.warning("precision='high': the float32 stages are predicted to cost some scales {:.1e} of their "
+                                "peak (the recording holds far more inside their decimation bands than they do); "
+                                "precision='auto' (the default) recomputes those scales exactly".format(rep["worst"]))
         if verbose:
             self.last_timings = self._plan.timings()
             print("Elapsed time (only wavelet convolution): {} seconds"

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GCWT_ABI_VERSION 4
+#define GCWT_ABI_VERSION 5
 
 typedef enum {
   GCWT_OK = 0,
@@ -120,6 +120,14 @@ typedef enum {
   GCWT_PRECISION_DEFAULT = 0,
   GCWT_PRECISION_FAST = 1,
   GCWT_PRECISION_HIGH = 2,
+  GCWT_PRECISION_AUTO = 4,   /* what DEFAULT means since ABI 5: HIGH, watched -- while the float64 spectrum is made,
+                              * every scale's loss to the float32 stages of its decimation level is predicted from
+                              * the band energies of that spectrum (the level's content against the scale's own), and
+                              * the scales predicted above 3e-6 of their peak (a mains line inside an analysed band at
+                              * more than ~20 x the recording's spread) are made again by EXACT's paths, the others
+                              * keep the fast one: the reference's float64 dynamic range (transforms.py:142-143,
+                              * convolution.py:68-77) without asking for it.  gcwt_plan_precision_report tells what
+                              * happened.  HIGH itself predicts and reports but never reroutes. */
   GCWT_PRECISION_EXACT = 3   /* no decimated path: every scale through the block convolution (kernels up to 1024
                               * taps, block edges faded) or the full-band path -- float64 forward transforms, and
                               * the float32 stages after them only ever see what the scale's own filter lets
@@ -210,6 +218,12 @@ int gcwt_plan_scale_info(const gcwt_plan* plan, int32_t* method, int32_t* decima
 int gcwt_plan_scale_support(const gcwt_plan* plan, double* theta_hi, double* support,
                             int32_t* n_bins);
 int gcwt_plan_set_profiling(gcwt_plan* plan, int enabled);
+/* After an execute of a plan with precision DEFAULT / AUTO / HIGH: predicted[s] (S floats, may be NULL) is the
+ * predicted loss of scale s to the float32 stages of its decimation level, relative to its own output (0 for
+ * scales on the exact paths), *worst the largest of them, *n_rerouted how many scales that execute made again by
+ * the exact paths (AUTO; 0 for HIGH).  The reference needs no such thing: it is float64 end to end
+ * (transforms.py:142-143). */
+int gcwt_plan_precision_report(const gcwt_plan* plan, float* predicted, float* worst, int32_t* n_rerouted);
 /* Row pitch, in samples, of DEVICE output buffers (0 = dense rows of N, or of the block
  * length).  Rows whose byte offset is not a multiple of 128 make every store straddle
  * cache lines; pad rows to a multiple of 32 samples for full speed when N is not one.

@@ -312,6 +312,119 @@ def test_exact_precision_under_a_mains_line_inside_the_band():
     assert rel_err(amp, np.abs(ref)).max() < 0.3 * TOL
 
 
+@pytest.mark.parametrize("amp", [30.0, 100.0, 1000.0])
+def test_default_call_keeps_the_gate_under_a_mains_line(amp, caplog):
+    """The default precision ('auto': 'high', watched) on LFP with a 60 Hz line of 30 .. 1000 x the recording's
+    spread inside the analysed band -- where 'high' alone is over the gate from ~30 x (3.6e-5 at 100 x, 2.9e-4 at
+    1000 x: profiles/r04_dynamic_range.md): the detector predicts, from the band energies of the float64 spectrum,
+    which scales the float32 stages of their decimation level would cost their low bits, those are made again by the
+    exact paths, and the public call logs what it did.  The reference is float64 end to end and needs none of this
+    (transforms.py:142-143, convolution.py:68-77).  Amplitude (the default output) and complex coefficients."""
+    import logging
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp_channel
+    from ghost_amd.wave import ContinuousWaveletTransform
+    fs, n = 1000.0, 250000
+    f = np.geomspace(200.0, 2.0, 100)
+    t = np.arange(n) / fs
+    base = lfp_channel(n, fs, 3).astype(np.float64)
+    win = np.sin(np.pi * np.arange(n) / n) ** 2
+    x = (base + amp * base.std() * win * np.sin(2 * np.pi * 60.0 * t)).astype(np.float32)
+    ref = orc.cwt_complex(x.astype(np.float64), fs, f, n_threads=8)
+    with caplog.at_level(logging.WARNING):
+        cwt = ContinuousWaveletTransform()
+        cwt.transform(x, fs=fs, freqs=f)
+    got = cwt.amplitude[::-1]                    # freqs= gives ascending rows (transforms.py:154)
+    e_auto = rel_err(got, np.abs(ref)).max()
+    rep = cwt.precision_report
+    assert e_auto < TOL, (amp, e_auto)
+    assert rep["rerouted"] > 0 and "recomputed by exact FFT convolution" in caplog.text
+    # the prediction is what the fast path alone would have cost: within a factor 2.5 of the measured worst row
+    p = CwtPlan(n, 1, fs, f, output="complex", precision="high")
+    high = p.execute(x[None])[0]
+    rh = p.precision_report()
+    e_high = rel_err(high, ref)
+    assert rh["rerouted"] == 0 and e_high.max() > min(3.0, amp / 30.0) * 0.5 * TOL
+    worst = int(np.argmax(e_high))
+    assert 0.4 < e_high[worst] / rh["predicted"][worst] < 2.5, (e_high[worst], rh["predicted"][worst])
+    p.close()
+    # complex coefficients through the same rerouting
+    p = CwtPlan(n, 1, fs, f, output="complex")
+    c = p.execute(x[None])[0]
+    assert rel_err(c, ref).max() < TOL and p.precision_report()["rerouted"] == rep["rerouted"]
+    # a block request (window edges on no multiple of 4) gives the same numbers as the whole
+    blk = p.execute_block(x[None], 100001, 30003)
+    np.testing.assert_array_equal(blk[0], c[:, 100001:130004])
+    p.close()
+    print("60 Hz at %g x: auto %.2e (rerouted %d of %d), high %.2e predicted %.2e" % (amp, e_auto, rep["rerouted"], f.size, e_high.max(), rh["worst"]))
+
+
+def test_default_call_leaves_benign_recordings_on_the_fast_path(caplog):
+    """Pink LFP, brown and 1/f^3 noise: nothing is predicted over the threshold, nothing is rerouted, nothing is logged;
+    a drift of 1000 x the spread below every band is caught through the part of the spectrum the levels leave out (the
+    reference's L-tap kernels answer to it through their side lobes: transforms.py:187-204).  Two channels of which one
+    carries a line: the scales are rerouted for both (the rows of a scale are made by one launch)."""
+    import logging
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import spectrum_class, lfp_channel
+    from ghost_amd.wave import ContinuousWaveletTransform
+    fs, n = 1000.0, 200000
+    f = np.geomspace(200.0, 2.0, 100)
+    for name in ("pink_lfp", "brown", "f3"):
+        x = spectrum_class(name, n, fs).astype(np.float32)
+        with caplog.at_level(logging.WARNING):
+            cwt = ContinuousWaveletTransform()
+            cwt.transform(x, fs=fs, freqs=f)
+        assert cwt.precision_report["rerouted"] == 0 and cwt.precision_report["worst"] < 1e-6, name
+        assert "recomputed" not in caplog.text
+    x = spectrum_class("drift1000", n, fs).astype(np.float32)
+    ref = orc.cwt_amplitude(x.astype(np.float64), fs, f, n_threads=8)
+    p = CwtPlan(n, 1, fs, f)
+    got = p.execute(x[None])[0]
+    assert p.precision_report()["rerouted"] > 0 and rel_err(got, ref).max() < 0.3 * TOL
+    p.close()
+    # two channels, one clean: both get the rerouted scales, both meet the gate
+    t = np.arange(n) / fs
+    clean = lfp_channel(n, fs, 5).astype(np.float64)
+    dirty = clean[::-1] + 300.0 * clean.std() * np.sin(np.pi * np.arange(n) / n) ** 2 * np.sin(2 * np.pi * 60.0 * t)
+    xs = np.stack([clean, dirty]).astype(np.float32)
+    p = CwtPlan(n, 2, fs, f)
+    got = p.execute(xs)
+    assert p.precision_report()["rerouted"] > 0
+    for ch in range(2):
+        assert rel_err(got[ch], orc.cwt_amplitude(xs[ch].astype(np.float64), fs, f, n_threads=8)).max() < TOL
+    p.close()
+
+
+def test_explicit_high_precision_only_warns(caplog, option):
+    """precision='high' asked for by name never reroutes: it reports, and the public call warns when the prediction is
+    over the threshold; the threshold is an option (auto_threshold_ppb) for those who want the exact paths sooner."""
+    import logging
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import spectrum_class
+    from ghost_amd.wave import ContinuousWaveletTransform
+    fs, n = 1000.0, 100000
+    f = np.geomspace(200.0, 2.0, 50)
+    x = spectrum_class("line100", n, fs).astype(np.float32)
+    with caplog.at_level(logging.WARNING):
+        cwt = ContinuousWaveletTransform()
+        cwt.transform(x, fs=fs, freqs=f, precision="high")
+    assert cwt.precision_report["rerouted"] == 0 and cwt.precision_report["worst"] > 3e-6
+    assert "precision='high'" in caplog.text and "recomputed" not in caplog.text
+    clean = spectrum_class("pink_lfp", n, fs).astype(np.float32)
+    p = CwtPlan(n, 1, fs, f)
+    p.execute(clean[None])
+    worst = p.precision_report()["worst"]
+    assert p.precision_report()["rerouted"] == 0 and 0 < worst < 1e-6
+    p.close()
+    option("auto_threshold_ppb", max(1, int(0.5 * worst * 1e9)))          # below what pink LFP predicts: everything goes
+    p = CwtPlan(n, 1, fs, f)
+    got = p.execute(clean[None])[0]
+    assert p.precision_report()["rerouted"] > 0
+    assert rel_err(got, orc.cwt_amplitude(clean.astype(np.float64), fs, f)).max() < TOL
+    p.close()
+
+
 def test_public_call_float64_input_with_a_huge_offset():
     """A float64 recording whose DC level is 1e7 x its fluctuation (float32 would quantise it to steps the size of
     the signal): `transform()` removes the mean in the input's own precision before the cast to the device's float32

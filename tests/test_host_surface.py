@@ -35,7 +35,7 @@ def test_abi_exports_every_declared_symbol():
     so = ctypes.CDLL(_lib.LIB_PATH)
     missing = [s for s in sorted(declared) if not hasattr(so, s)]
     assert not missing, missing
-    assert _lib.lib.gcwt_abi_version() == 4
+    assert _lib.lib.gcwt_abi_version() == 5
 
 
 def test_morse_scalars_and_lengths(golden):
