@@ -8,4 +8,4 @@ __all__ = ['chirpz_dft'] + list(_gpu.__all__)
 
 def chirpz_dft(x):
     """fourier.py:9-52 on the device."""
-    return chirpz_dft_hip(x)
+    return chirpz_dft_hip(x, precision='high')

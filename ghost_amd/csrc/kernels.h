@@ -220,6 +220,11 @@ hipError_t launch_synthp(int mode, const SynthpArgs& a, int n_items, int n_chann
 hipError_t launch_synth8(int mode, int ncol, const Synth7Args& a, int n_items, int n_channels,
                          hipStream_t st);
 
+// the operator layer in float64 (ops64.hip): host in, host out; out holds (re, im) pairs
+hipError_t dft_f64(const double* x, int64_t n, int is_complex, int inverse, double* out);
+hipError_t fastconv_f64(const double* signal, int64_t n, int signal_is_complex, const double* kernel, int64_t m,
+                        int kernel_is_complex, int64_t first, int64_t count, double* out);
+
 // a rectangle of a device-resident result to the host (result_io.hip; include/ghostcwt.h: gcwt_rows_to_host)
 hipError_t rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, int64_t row_elems, void* dst,
                         int64_t dst_pitch, bool widen, bool pinned);

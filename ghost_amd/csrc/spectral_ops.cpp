@@ -185,4 +185,36 @@ int gcwt_analytic_signal(const float* signal, int64_t n, int64_t fft_length, flo
   return guarded([&] { return analytic_impl(signal, n, fft_length, out, device); });
 }
 
+// ---- the same operators in float64 (ops64.hip): the reference's own arithmetic and result dtype ----
+int gcwt_dft_f64(const double* x, int64_t n, int is_complex, int inverse, double* out, int device) {
+  return guarded([&] {
+    if (!x || !out || n < 1) return fail(GCWT_ERR_INVALID, "bad arguments");
+    if (n > ((int64_t)1 << 23)) return fail(GCWT_ERR_UNSUPPORTED, "float64 DFT lengths up to 2^23");
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return fail(GCWT_ERR_NO_DEVICE, "cannot select the device");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) { (void)hipGetLastError(); return fail(GCWT_ERR_NO_DEVICE, "no HIP device"); }
+    const hipError_t e = gcwt::dft_f64(x, n, is_complex, inverse, out);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? GCWT_ERR_NOMEM : GCWT_ERR_HIP, std::string("float64 DFT: ") + hipGetErrorString(e));
+    return (int)GCWT_OK;
+  });
+}
+
+int gcwt_fastconv_f64(const double* signal, int64_t n, int signal_is_complex, const double* kernel, int64_t m,
+                      int kernel_is_complex, int mode, double* out, int device) {
+  return guarded([&] {
+    if (!signal || !kernel || !out || n < 1 || m < 1 || mode < 0 || mode > 2) return fail(GCWT_ERR_INVALID, "bad arguments");
+    if (mode == 2 && n < m) return fail(GCWT_ERR_INVALID, "'valid' needs a signal at least as long as the kernel");
+    if (n + m - 1 > ((int64_t)1 << 24)) return fail(GCWT_ERR_UNSUPPORTED, "float64 convolutions up to 2^24 samples of result (the float32 operator chunks: gcwt_conv_plan_*)");
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return fail(GCWT_ERR_NO_DEVICE, "cannot select the device");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) { (void)hipGetLastError(); return fail(GCWT_ERR_NO_DEVICE, "no HIP device"); }
+    // 'same' is centred as convolution.py:85 does it: (total - n) // 2 samples dropped in front
+    const int64_t first = mode == 0 ? 0 : (mode == 1 ? (m - 1) / 2 : m - 1);
+    const int64_t cnt = mode == 0 ? n + m - 1 : (mode == 1 ? n : n - m + 1);
+    const hipError_t e = gcwt::fastconv_f64(signal, n, signal_is_complex, kernel, m, kernel_is_complex, first, cnt, out);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? GCWT_ERR_NOMEM : GCWT_ERR_HIP, std::string("float64 convolution: ") + hipGetErrorString(e));
+    return (int)GCWT_OK;
+  });
+}
+
 }  // extern "C"

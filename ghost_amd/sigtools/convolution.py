@@ -145,10 +145,28 @@ def _plan_for(n, m, fft_length, device):
     return plan
 
 
-def fastconv_hip(signal, kernel, *, mode=None, fft_length=None, device=-1):
+lib.gcwt_fastconv_f64.restype = C.c_int
+lib.gcwt_fastconv_f64.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int]
+
+
+def _fastconv_f64(signal, kernel, mode, device):
+    """float64 on the device: the reference's arithmetic and result (convolution.py:68: complex128 chunks)."""
+    sc, kc = np.iscomplexobj(signal), np.iscomplexobj(kernel)
+    x = np.ascontiguousarray(signal, dtype=np.complex128 if sc else np.float64)
+    k = np.ascontiguousarray(kernel, dtype=np.complex128 if kc else np.float64)
+    n, m = x.shape[0], k.shape[0]
+    out = np.empty({"full": n + m - 1, "same": n, "valid": n - m + 1}[mode], dtype=np.complex128)
+    check(lib.gcwt_fastconv_f64(x.ctypes.data_as(C.c_void_p), n, 1 if sc else 0, k.ctypes.data_as(C.c_void_p), m,
+                                1 if kc else 0, {"full": 0, "same": 1, "valid": 2}[mode],
+                                out.ctypes.data_as(C.c_void_p), int(device)))
+    return out if (sc or kc) else out.real.copy()
+
+
+def fastconv_hip(signal, kernel, *, mode=None, fft_length=None, device=-1, precision=None):
     """Linear convolution of a real 1-D ``signal`` with a real or complex 1-D ``kernel``.
     ``mode``: 'full', 'same' (default, centred as convolution.py:85) or 'valid';
-    ``fft_length`` as in the reference (a power of two here)."""
+    ``fft_length`` as in the reference (a power of two here).  precision='high': float64 arithmetic and a float64 /
+    complex128 result, what the reference returns (one FFT of the whole result, up to 2**24 samples)."""
     signal = np.asarray(signal)
     kernel = np.asarray(kernel)
     if signal.ndim != 1:
@@ -161,11 +179,14 @@ def fastconv_hip(signal, kernel, *, mode=None, fft_length=None, device=-1):
     mode = _check_mode(mode, n, m)
     if fft_length is not None and fft_length < m:
         raise ValueError("FFT length must be at least the kernel size")
+    from .fourier import _check_precision
+    if _check_precision(precision) == "high":
+        return _fastconv_f64(signal, kernel, mode, device)
     plan = _plan_for(n, m, fft_length, int(device))
     return plan.set_kernel(kernel).execute(signal, mode=mode)
 
 
-def fastconv_freq_hip(signal_td, kernel_fd, kernel_len, *, mode=None, device=-1):
+def fastconv_freq_hip(signal_td, kernel_fd, kernel_len, *, mode=None, device=-1, precision=None):
     """Convolution with a kernel given by its DFT (any length >= ``kernel_len``), as
     ``fastconv_freq_scipy(signal_td, kernel_fd, kernel_len, mode=...)``.  When the DFT is
     on a power-of-two grid the plan can take (4096 .. 2^22 bins) it is used as it is and the
@@ -180,6 +201,12 @@ def fastconv_freq_hip(signal_td, kernel_fd, kernel_len, *, mode=None, device=-1)
         raise ValueError("Kernel must be 1D")
     n, m, f = signal_td.shape[0], int(kernel_len), kernel_fd.shape[0]
     mode = _check_mode(mode, n, m)
+    from .fourier import _check_precision, _dft
+    if _check_precision(precision) == "high":
+        # the kernel's taps from its DFT (any length) in float64 on the device, then the float64 convolution
+        kernel_td = _dft(np.asarray(kernel_fd, dtype=np.complex128), True, device, "high")[:m]
+        herm = np.abs(kernel_fd[1:] - np.conj(kernel_fd[:0:-1])).max() <= 1e-12 * np.abs(kernel_fd).max() if f > 1 else True
+        return _fastconv_f64(signal_td, kernel_td.real.copy() if herm else kernel_td, mode, device)
     if f >= 4096 and f <= (1 << 22) and (f & (f - 1)) == 0 and f >= m:
         # real taps <=> Hermitian spectrum: hand back float32 like fastconv_hip does
         herm = np.abs(kernel_fd[1:] - np.conj(kernel_fd[:0:-1])).max() <= 1e-6 * np.abs(kernel_fd).max()

@@ -312,6 +312,17 @@ int gcwt_dft(const float* x, int64_t n, int is_complex, int inverse, float* out,
 int gcwt_analytic_signal(const float* signal, int64_t n, int64_t fft_length, float* out,
                          int device);
 
+/* The same operators in float64, the reference's own arithmetic and result dtype (complex128 from float64 FFTs:
+ * ghost/sigtools/convolution.py:68-87, fourier.py:9-52, analytic.py:22-112) -- for callers that compare element by
+ * element, down to a result's zero crossings.  Host memory in and out; out: (re, im) pairs of doubles.
+ * gcwt_dft_f64: any n <= 2^23 (powers of two directly, other lengths by the chirp-z identity, phases reduced in
+ * integers).  gcwt_fastconv_f64: signal and kernel real or complex; mode 0 'full', 1 'same' (centred as
+ * convolution.py:85), 2 'valid'; n + m - 1 <= 2^24.  The analytic signal is two gcwt_dft_f64 calls around the
+ * one-sided mask (ghost_amd.sigtools.analytic_signal_hip(precision='high')). */
+int gcwt_dft_f64(const double* x, int64_t n, int is_complex, int inverse, double* out, int device);
+int gcwt_fastconv_f64(const double* signal, int64_t n, int signal_is_complex, const double* kernel, int64_t m,
+                      int kernel_is_complex, int mode, double* out, int device);
+
 /* Multi-GPU control plane (one process per GPU; RCCL over xGMI).  The data path
  * has no collective: channels are sharded.  The filter bank is broadcast once
  * from rank 0 as BASELINE.json asks; barrier/all-reduce exist for bench timing. */
