@@ -67,6 +67,7 @@ def _load():
         "gcwt_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
         "gcwt_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
         "gcwt_set_device": (C.c_int, [C.c_int]),
+        "gcwt_current_device": (C.c_int, [C.POINTER(C.c_int)]),
         "gcwt_device_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
         "gcwt_device_free": (C.c_int, [vp]),
         "gcwt_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),

@@ -187,6 +187,7 @@ struct gcwt_plan {
   int32_t* d_scale_level = nullptr;
   int32_t* d_scale_length = nullptr;   // the reference kernel's L per scale (capped at 2^30)
   std::vector<float> last_pred;      // the last execute's predictions (host)
+  float* h_pred = nullptr;           // ... as they arrive: page-locked, so that the 4 S bytes do not go through a staging copy
   float last_worst = 0.f;
   int last_rerouted = 0;
   float auto_threshold = 3e-6f;      // option auto_threshold_ppb
@@ -239,6 +240,7 @@ void free_dev(gcwt_plan* p) {
   fr(p->d_tw256); fr(p->d_level_tw); fr(p->d_sums); fr(p->d_scale_list); fr(p->d_scale_aux); fr(p->d_interp_coef); fr(p->d_bank_sc); fr(p->d_direct_sc); fr(p->d_bc_h); fr(p->d_bc_rows); fr(p->d_bc_x); fr(p->d_bc_tw);
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
+  if (p->h_pred) { (void)hipHostFree(p->h_pred); p->h_pred = nullptr; }
   fr(p->d_hist); fr(p->d_pred); fr(p->d_scale_level); fr(p->d_scale_length); fr(p->d_sub_out);
   p->d_sub_out_bytes = 0;
   for (auto& kv : p->sub_plans) {
@@ -345,6 +347,11 @@ int gcwt_device_pci_bus_id(int device, char* buf, size_t buflen) {
 }
 
 int gcwt_set_device(int device) { HIP_TRY(hipSetDevice(device)); return GCWT_OK; }
+int gcwt_current_device(int* device) {
+  if (!device) return set_err(GCWT_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipGetDevice(device));
+  return GCWT_OK;
+}
 
 int gcwt_device_memory(size_t* free_bytes, size_t* total_bytes) {
   if (!free_bytes || !total_bytes) return set_err(GCWT_ERR_INVALID, "NULL argument");
@@ -893,6 +900,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
         if ((rc = upload_vec(&p->ep_dev[e].pred_levels, pl, p->stream))) return bail(rc);
       }
       p->last_pred.assign((size_t)S, 0.f);
+      HIP_TRY(hipHostMalloc((void**)&p->h_pred, sizeof(float) * (size_t)S, hipHostMallocDefault));
       HIP_TRY(hipStreamSynchronize(p->stream));       // the vectors of this block go out of scope
     }
   }
@@ -1548,8 +1556,9 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   if (p->detect) {
     // precision = auto / high: read the predictions; auto makes the scales over the threshold again by the exact paths
     // (a sub-plan with precision = exact for just those scales; its rows replace the fast path's)
-    HIP_TRY(hipMemcpyAsync(p->last_pred.data(), p->d_pred, sizeof(float) * p->last_pred.size(), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_pred, p->d_pred, sizeof(float) * p->last_pred.size(), hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    std::copy(p->h_pred, p->h_pred + p->last_pred.size(), p->last_pred.begin());
     std::vector<int32_t> over;
     p->last_worst = 0.f;
     for (size_t i = 0; i < p->last_pred.size(); ++i) {

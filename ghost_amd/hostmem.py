@@ -8,6 +8,7 @@ dropped, so that the next result of that size reuses memory that is already mapp
 what the pool keeps (and the size of a single pinned request); beyond it callers fall back to pageable arrays.
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -55,10 +56,51 @@ def _take(nbytes):
             n, ptr = _free.pop(best)
             _kept -= n
             return _Block(ptr, n)
-    ptr = C.c_void_p()
-    if lib.gcwt_host_alloc(C.byref(ptr), need) != 0 or not ptr.value:
-        return None
+    # the pages are placed where the allocating thread runs: for the time of the allocation it stays on the host cores
+    # of the current device's NUMA node (a copy across sockets runs at half the link's rate), best effort
+    old = _beside_device()
+    try:
+        ptr = C.c_void_p()
+        if lib.gcwt_host_alloc(C.byref(ptr), need) != 0 or not ptr.value:
+            return None
+    finally:
+        if old is not None:
+            try:
+                os.sched_setaffinity(0, old)
+            except OSError:
+                pass
     return _Block(ptr.value, need)
+
+
+_node_cpus = {}
+
+
+def _beside_device():
+    """Moves the calling thread onto the cores of the current device's NUMA node (within the process's affinity);
+    returns the previous affinity to restore, or None when nothing was changed."""
+    try:
+        dev = C.c_int(-1)
+        if lib.gcwt_current_device(C.byref(dev)) != 0:
+            return None
+        if dev.value not in _node_cpus:
+            from .dist import parse_cpulist
+            buf = C.create_string_buffer(64)
+            cpus = None
+            if lib.gcwt_device_pci_bus_id(dev.value, buf, 64) == 0:
+                with open("/sys/bus/pci/devices/%s/numa_node" % buf.value.decode().lower()) as fh:
+                    node = int(fh.read().strip())
+                if node >= 0:
+                    with open("/sys/devices/system/node/node%d/cpulist" % node) as fh:
+                        cpus = parse_cpulist(fh.read())
+            _node_cpus[dev.value] = cpus
+        cpus = _node_cpus[dev.value]
+        old = os.sched_getaffinity(0)
+        if not cpus or not (cpus & old) or (cpus & old) == old:
+            return None
+        os.sched_setaffinity(0, cpus & old)
+        return old
+    except Exception:
+        return None
 
 
 def empty(shape, dtype):

@@ -178,6 +178,7 @@ int gcwt_device_name(int device, char* buf, size_t buflen);
  * rank's host threads beside its GPU. */
 int gcwt_device_pci_bus_id(int device, char* buf, size_t buflen);
 int gcwt_set_device(int device);
+int gcwt_current_device(int* device);
 int gcwt_device_malloc(void** ptr, size_t bytes);
 int gcwt_device_free(void* ptr);
 int gcwt_memcpy_h2d(void* dst, const void* src, size_t bytes);

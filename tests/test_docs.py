@@ -36,7 +36,7 @@ def test_design_numbers_match_the_tracked_profiles():
 
 def test_profiles_named_in_design_exist():
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
-    for name in set(re.findall(r"profiles/(r04_[A-Za-z0-9_.{},]+?\.(?:json|md|txt|csv))", text)):
+    for name in set(re.findall(r"profiles/((?:r0\d|history)_[A-Za-z0-9_.{},]+?\.(?:json|md|txt|csv))", text)):
         if "{" in name:
             continue
         assert os.path.exists(os.path.join(ROOT, "profiles", name)), name
@@ -47,5 +47,15 @@ def test_readme_quotes_the_tracked_headline():
     text = open(os.path.join(ROOT, "README.md")).read()
     m = re.search(r"<!-- gen:measured -->(.*?)<!-- /gen -->", text, re.S)
     assert m
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read().strip().splitlines()[-1])
+    rnd = re.search(r"profiles/(r\d+)_bench.json", m.group(1)).group(1)
+    line = json.loads(open(os.path.join(ROOT, "profiles", rnd + "_bench.json")).read().strip().splitlines()[-1])
     assert "%.0f Msamples/s" % line["value"] in m.group(1) and "%.3f" % line["roofline"]["frac"] in m.group(1)
+
+
+def test_design_is_short_and_narrow():
+    """The design document describes the current design (at most 400 lines of at most 120 columns,
+    tables excepted); history lives under profiles/."""
+    lines = open(os.path.join(ROOT, "DESIGN.md")).read().splitlines()
+    assert len(lines) <= 400, len(lines)
+    wide = [i + 1 for i, l in enumerate(lines) if len(l) > 120 and not l.startswith("|") and not l.startswith("profiles/")]
+    assert not wide, wide
