@@ -879,7 +879,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       for (const EpochPlan& ep : hp.epochs)
         max_rows = std::max<int64_t>(max_rows, ep.p1);
       if ((rc = dev_alloc(&p->d_hist, (size_t)(slots * max_rows * kSpecBands)))) return bail(rc);
-      if ((rc = dev_alloc(&p->d_pred, (size_t)S))) return bail(rc);
+      if ((rc = dev_alloc(&p->d_pred, (size_t)S * hp.epochs.size()))) return bail(rc);
       if ((rc = upload_vec(&p->d_scale_level, scale_level, p->stream))) return bail(rc);
       std::vector<int32_t> scale_length((size_t)S);
       for (int i = 0; i < S; ++i) scale_length[(size_t)i] = (int32_t)std::min<int64_t>(hp.scales[i].length, (int64_t)1 << 30);
@@ -900,7 +900,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
         if ((rc = upload_vec(&p->ep_dev[e].pred_levels, pl, p->stream))) return bail(rc);
       }
       p->last_pred.assign((size_t)S, 0.f);
-      HIP_TRY(hipHostMalloc((void**)&p->h_pred, sizeof(float) * (size_t)S, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc((void**)&p->h_pred, sizeof(float) * (size_t)S * hp.epochs.size(), hipHostMallocDefault));
       HIP_TRY(hipStreamSynchronize(p->stream));       // the vectors of this block go out of scope
     }
   }
@@ -957,7 +957,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
 
   if (!reuse_means) RUN(ST_MEAN, launch_channel_sum(dx, N, C, p->d_sums, st));
   if (p->detect) {
-    he = hipMemsetAsync(p->d_pred, 0, sizeof(float) * (size_t)S, st);
+    he = hipMemsetAsync(p->d_pred, 0, sizeof(float) * (size_t)S * hp.epochs.size(), st);
     if (he != hipSuccess) return hip_err(he, "predictions reset");
   }
 
@@ -994,12 +994,14 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     const size_t count = (size_t)std::max(1, ep.batch_count);
     SegIn sin{};
     SegOut sout{};
+    PredSegs psegs{};
     int nb = 0;
     for (size_t i = 0; i < count; ++i) {
       const EpochPlan& m = hp.epochs[e0 + i];
       // output window of the segment, segment-local: its core, cut to the range
       const int64_t w_lo = std::max(m.core0, r0) - m.start, w_hi = std::min(m.core1, r1) - m.start;
       if (w_hi <= w_lo) continue;
+      psegs.seg[nb] = (int32_t)(e0 + i);
       sin.x_off[nb] = m.start;
       sin.n_valid[nb] = m.ne;
       sin.n_lead[nb] = m.lead;
@@ -1012,7 +1014,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     }
     e0 += count;
     if (nb == 0) continue;
-    sin.n_channels = sout.n_channels = C;
+    sin.n_channels = sout.n_channels = psegs.n_channels = C;
     const int slots = C * nb;
     // P, P1: the STORED spectrum (rows of 4096 bins); Pt: the segment's true FFT length.  They differ in long mode
     // only (planner.h, EpochPlan::long_a: Pt = A P, the spectrum's low half combined from A interleaved transforms)
@@ -1274,7 +1276,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       // what the float32 stages cost each scale, predicted from the band energies the forward pass left (detect.hip);
       // launched behind the synthesis, where it runs in the launch's tail (d_hist is reset by the next batch's forward)
       he = launch_precision_predict(p->d_hist, P1, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[ep.batch_first].pred_levels, S,
-                                    (int)hp.levels.size(), (double)Pt, p->kappa_eps, p->oob_tol, p->d_pred, nullptr, nullptr, slots, st);
+                                    (int)hp.levels.size(), (double)Pt, p->kappa_eps, p->oob_tol, p->d_pred, nullptr, nullptr, slots, psegs, st);
       if (he != hipSuccess) return hip_err(he, "launch_precision_predict");
       p->last_batch_slots = slots; p->last_batch = ep.batch_first; p->last_pt = (double)Pt; p->last_rows = P1;
     }
@@ -1417,10 +1419,10 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
 static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int64_t r1, int flags);
 static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params);
 
-// precision = auto: samples [r0, r1) of the scales `over` again, by a plan of precision = exact that holds just
+// precision = auto: samples [r0, r1) of the scales `over` again (dout's rows start at sample out_r0), by a plan of precision = exact that holds just
 // them (made on first use, kept per set of scales), from the same device-resident recording; its dense rows are
 // copied over the fast path's.  The sub-plan computes its own channel means (same numbers: same kernel, same x).
-static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t r0, int64_t r1, int64_t row_len,
+static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t out_r0, int64_t r0, int64_t r1, int64_t row_len,
                           const std::vector<int32_t>& over) {
   const HostPlan& hp = p->hp;
   gcwt_plan::SubPlan& sp = p->sub_plans[over];
@@ -1456,8 +1458,8 @@ static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t r0
   sp.plan->row_pitch = pitch;
   int rc = execute_range(sp.plan, dx, p->d_sub_out, r0, r1, GCWT_X_ON_DEVICE | GCWT_OUT_ON_DEVICE);
   if (rc) return rc;
-  hipError_t he = launch_scatter_rows(p->d_sub_out, dout, sp.d_rows, (int)over.size(), hp.prm.n_freqs, hp.prm.n_channels,
-                                      n_out * elem, pitch * elem, row_len * elem, p->stream);
+  hipError_t he = launch_scatter_rows(p->d_sub_out, dout + (r0 - out_r0) * elem, sp.d_rows, (int)over.size(), hp.prm.n_freqs,
+                                      hp.prm.n_channels, n_out * elem, pitch * elem, row_len * elem, p->stream);
   if (he != hipSuccess) return hip_err(he, "launch_scatter_rows");
   HIP_TRY(hipStreamSynchronize(p->stream));
   return GCWT_OK;
@@ -1556,20 +1558,40 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   if (p->detect) {
     // precision = auto / high: read the predictions; auto makes the scales over the threshold again by the exact paths
     // (a sub-plan with precision = exact for just those scales; its rows replace the fast path's)
-    HIP_TRY(hipMemcpyAsync(p->h_pred, p->d_pred, sizeof(float) * p->last_pred.size(), hipMemcpyDeviceToHost, p->stream));
+    const size_t n_seg = hp.epochs.size(), Sz = (size_t)hp.prm.n_freqs;
+    HIP_TRY(hipMemcpyAsync(p->h_pred, p->d_pred, sizeof(float) * Sz * n_seg, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    std::copy(p->h_pred, p->h_pred + p->last_pred.size(), p->last_pred.begin());
-    std::vector<int32_t> over;
+    // The verdict is per segment (epoch or time block), so that a block request and the whole transform decide alike
+    // for the samples they share: segment e's scales over the threshold are made again for e's own core, runs of
+    // neighbouring segments with the same set in one go.
+    std::fill(p->last_pred.begin(), p->last_pred.end(), 0.f);
+    std::vector<std::vector<int32_t>> over(n_seg);
+    std::vector<char> any((size_t)Sz, 0);
+    for (size_t e = 0; e < n_seg; ++e)
+      for (size_t i = 0; i < Sz; ++i) {
+        const float v = p->h_pred[e * Sz + i];
+        p->last_pred[i] = std::max(p->last_pred[i], v);
+        if (v > p->auto_threshold) { over[e].push_back((int32_t)i); any[i] = 1; }
+      }
     p->last_worst = 0.f;
-    for (size_t i = 0; i < p->last_pred.size(); ++i) {
-      p->last_worst = std::max(p->last_worst, p->last_pred[i]);
-      if (p->last_pred[i] > p->auto_threshold) over.push_back((int32_t)i);
-    }
+    for (float v : p->last_pred) p->last_worst = std::max(p->last_worst, v);
     p->last_rerouted = 0;
-    if (hp.auto_precision && !over.empty()) {
-      rc = reroute_scales(p, dx, dout, r0, r1, row_len, over);
-      if (rc) return rc;
-      p->last_rerouted = (int)over.size();
+    if (hp.auto_precision) {
+      for (size_t e = 0; e < n_seg;) {
+        size_t e1 = e + 1;
+        if (over[e].empty()) { e = e1; continue; }
+        int64_t a = std::max(hp.epochs[e].core0, r0), b = std::min(hp.epochs[e].core1, r1);
+        while (e1 < n_seg && over[e1] == over[e] && hp.epochs[e1].core0 >= hp.epochs[e1 - 1].core1) {   // (segments come in time order)
+          b = std::min(hp.epochs[e1].core1, r1);
+          ++e1;
+        }
+        if (b > a) {
+          rc = reroute_scales(p, dx, dout, r0, a, b, row_len, over[e]);
+          if (rc) return rc;
+        }
+        e = e1;
+      }
+      for (char c : any) p->last_rerouted += c;
     }
   }
   if (!(flags & GCWT_OUT_ON_DEVICE)) {
@@ -1692,8 +1714,10 @@ int gcwt_debug_precision_terms(gcwt_plan* p, float* rounding, float* left_out, f
   HIP_TRY(hipMalloc((void**)&d_lv, sizeof(float) * (size_t)L * p->last_batch_slots));
   HIP_TRY(hipMalloc((void**)&d_pr, sizeof(float) * (size_t)S));
   HIP_TRY(hipMemsetAsync(d_pr, 0, sizeof(float) * (size_t)S, p->stream));
+  PredSegs dbg_segs{};                       // (every slot to row 0 of the scratch predictions)
+  dbg_segs.n_channels = p->hp.prm.n_channels;
   hipError_t he = launch_precision_predict(p->d_hist, p->last_rows, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[p->last_batch].pred_levels, S, L,
-                                           p->last_pt, p->kappa_eps, p->oob_tol, d_pr, d_lv, d_sc, p->last_batch_slots, p->stream);
+                                           p->last_pt, p->kappa_eps, p->oob_tol, d_pr, d_lv, d_sc, p->last_batch_slots, dbg_segs, p->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(rounding, d_sc, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, p->stream);
   if (he == hipSuccess) he = hipMemcpyAsync(left_out, d_sc + S, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, p->stream);
   if (he == hipSuccess && level_energy) he = hipMemcpyAsync(level_energy, d_lv, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, p->stream);

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_precision_predict(const float* __restri
                                                            const PredLevel* __restrict__ levels, int n_scales,
                                                            int n_levels, float p_true, float kappa_eps, float oob_tol,
                                                            float* __restrict__ pred, float* __restrict__ dbg_level,
-                                                           float* __restrict__ dbg_scale) {
+                                                           float* __restrict__ dbg_scale, const PredSegs segs) {
   __shared__ float h[kSpecBands];
   __shared__ float hout[kSpecBands];   // what the current level leaves out of band b: (1 - weight) h
   __shared__ float dens[256];
@@ -147,7 +147,8 @@ __global__ void __launch_bounds__(256) k_precision_predict(const float* __restri
         const float p2 = e_s > 0.f ? oob_tol * sqrtf(e_out / e_s) : 0.f;
         const float p = fmaxf(p1, p2);
         if (dbg_scale) { dbg_scale[((int64_t)slot * 2) * n_scales + s] = p1; dbg_scale[((int64_t)slot * 2 + 1) * n_scales + s] = p2; }
-        atomicMax(reinterpret_cast<unsigned*>(pred) + s, __float_as_uint(p));   // (p >= 0: the bit patterns order like the values)
+        // the largest over the segment's channels (p >= 0: the bit patterns order like the values)
+        atomicMax(reinterpret_cast<unsigned*>(pred) + (int64_t)segs.seg[slot / segs.n_channels] * n_scales + s, __float_as_uint(p));
       }
     }
     __syncthreads();
@@ -179,10 +180,10 @@ hipError_t launch_spectrum_bands(const float2* x, int64_t x_cstride, int p1, flo
 hipError_t launch_precision_predict(const float* hist, int n_rows, const float* gain, const int32_t* scale_level,
                                     const int32_t* scale_length, const PredLevel* levels, int n_scales, int n_levels, double p_true,
                                     float kappa_eps, float oob_tol, float* pred, float* dbg_level, float* dbg_scale,
-                                    int n_slots, hipStream_t st) {
+                                    int n_slots, const PredSegs& segs, hipStream_t st) {
   if (n_slots <= 0 || n_scales <= 0 || n_levels <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_precision_predict, dim3(n_slots, n_levels), dim3(256), 0, st, hist, n_rows, gain, scale_level, scale_length, levels, n_scales,
-                     n_levels, (float)p_true, kappa_eps, oob_tol, pred, dbg_level, dbg_scale);
+                     n_levels, (float)p_true, kappa_eps, oob_tol, pred, dbg_level, dbg_scale, segs);
   return hipGetLastError();
 }
 

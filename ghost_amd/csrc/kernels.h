@@ -316,6 +316,10 @@ __host__ __device__ inline int spec_band(float k) {
   const int v = (int)(b.u >> 19) - 127 * 16;
   return v < 0 ? 0 : (v >= kSpecBands ? kSpecBands - 1 : v);
 }
+struct PredSegs {           // slot = g * n_channels + channel belongs to the plan's segment seg[g]: pred is [segments][S]
+  int32_t seg[kSegBatch];
+  int32_t n_channels, pad;
+};
 struct PredLevel {
   int32_t decimation;       // R: the level's x_R holds the spectrum bins below P / R (after its low cut)
   int32_t band_shift;       // bins of the level's 256-point grid below zero frequency (shifted bands: no low cut)
@@ -333,7 +337,7 @@ hipError_t launch_spectrum_bands(const float2* x, int64_t x_cstride, int p1, flo
 hipError_t launch_precision_predict(const float* hist, int n_rows, const float* gain, const int32_t* scale_level,
                                     const int32_t* scale_length, const PredLevel* levels, int n_scales, int n_levels, double p_true,
                                     float kappa_eps, float oob_tol, float* pred, float* dbg_level, float* dbg_scale,
-                                    int n_slots, hipStream_t st);
+                                    int n_slots, const PredSegs& segs, hipStream_t st);
 // rows of a sub-plan's dense result [C][n_sub][row_len] into rows `rows[i]` of the full one [C][n_scales][row_len]
 hipError_t launch_scatter_rows(const float* src, float* dst, const int32_t* rows, int n_sub, int n_scales,
                                int n_channels, int64_t row_elems, int64_t src_pitch, int64_t dst_pitch, hipStream_t st);
