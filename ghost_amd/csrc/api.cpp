@@ -184,6 +184,7 @@ struct gcwt_plan {
   bool detect = false;               // the plan predicts (float64 forward transform, no long mode, some spectral scale)
   float* d_hist = nullptr;
   float* d_pred = nullptr;
+  hipStream_t det_stream = nullptr;  // the predictions are made beside the level passes and the synthesis, not behind them
   int32_t* d_scale_level = nullptr;
   int32_t* d_scale_length = nullptr;   // the reference kernel's L per scale (capped at 2^30)
   std::vector<float> last_pred;      // the last execute's predictions (host)
@@ -259,6 +260,7 @@ void free_dev(gcwt_plan* p) {
   p->ev_pool.clear();
   if (p->stream) { (void)hipStreamDestroy(p->stream); p->stream = nullptr; }
   for (auto& q : p->aux) if (q) { (void)hipStreamDestroy(q); q = nullptr; }
+  if (p->det_stream) { (void)hipStreamDestroy(p->det_stream); p->det_stream = nullptr; }
   p->uploaded = false;
 }
 
@@ -541,6 +543,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   int rc;
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   for (auto& q : p->aux) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&p->det_stream, hipStreamNonBlocking));
   auto bail = [&](int code) { free_dev(p); return code; };
   bool he_sync_tables = false;
 
@@ -1034,8 +1037,22 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         RUN(ST_FWD, launch_fwd64_rows(p->d_y, p->d_x, rows_a, p->y_stride, P, p->d_tw64, slots,
                                       hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0, st, a, A, Pt));
       }
-      // precision = auto / high: the spectrum's band energies, for the detector (detect.hip)
-      if (p->detect) RUN(ST_FWD, launch_spectrum_bands(p->d_x, P, P1, p->d_hist, slots, st));
+      // precision = auto / high: the spectrum's band energies, then -- on a stream of its own, beside the level passes
+      // and the synthesis -- what the float32 stages will cost each scale (detect.hip); joined at the end of the batch
+      if (p->detect) {
+        RUN(ST_FWD, launch_spectrum_bands(p->d_x, P, P1, p->d_hist, slots, st));
+        hipEvent_t bands_done;
+        int rc_ = get_event(p, &bands_done);
+        if (rc_) return rc_;
+        he = hipEventRecord(bands_done, st);
+        if (he == hipSuccess) he = hipStreamWaitEvent(p->det_stream, bands_done, 0);
+        if (he != hipSuccess) return hip_err(he, "detector fork");
+        he = launch_precision_predict(p->d_hist, P1, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[ep.batch_first].pred_levels, S,
+                                      (int)hp.levels.size(), (double)Pt, p->kappa_eps, p->oob_tol, p->d_pred, nullptr, nullptr, slots, psegs,
+                                      p->det_stream);
+        if (he != hipSuccess) return hip_err(he, "launch_precision_predict");
+        p->last_batch_slots = slots; p->last_batch = ep.batch_first; p->last_pt = (double)Pt; p->last_rows = P1;
+      }
     } else if (A > 1) {
       return set_err(GCWT_ERR_UNSUPPORTED, "internal: long mode without the float64 forward transform");
     } else {
@@ -1272,13 +1289,13 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       if (he == hipSuccess) he = hipStreamWaitEvent(st, interp_done, 0);
       if (he != hipSuccess) return hip_err(he, "synthesis join");
     }
-    if (p->detect && p->d_y) {
-      // what the float32 stages cost each scale, predicted from the band energies the forward pass left (detect.hip);
-      // launched behind the synthesis, where it runs in the launch's tail (d_hist is reset by the next batch's forward)
-      he = launch_precision_predict(p->d_hist, P1, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[ep.batch_first].pred_levels, S,
-                                    (int)hp.levels.size(), (double)Pt, p->kappa_eps, p->oob_tol, p->d_pred, nullptr, nullptr, slots, psegs, st);
-      if (he != hipSuccess) return hip_err(he, "launch_precision_predict");
-      p->last_batch_slots = slots; p->last_batch = ep.batch_first; p->last_pt = (double)Pt; p->last_rows = P1;
+    if (p->detect && p->d_y) {             // join: the batch is done when its predictions are (d_hist is free again)
+      hipEvent_t pred_done;
+      int rc_ = get_event(p, &pred_done);
+      if (rc_) return rc_;
+      he = hipEventRecord(pred_done, p->det_stream);
+      if (he == hipSuccess) he = hipStreamWaitEvent(st, pred_done, 0);
+      if (he != hipSuccess) return hip_err(he, "detector join");
     }
     if (p->profiling && !hp.levels.empty()) p->last.synth_launches++;
     // full-band scales: W = IFFT_P(X H_s) for every slot of the batch, up to four scales per pass over X
@@ -1551,6 +1568,7 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
     if (rc) {   // a failure between a fork and its join: nothing may still be running on any of the plan's streams
       (void)hipStreamSynchronize(p->stream);
       for (auto& q : p->aux) (void)hipStreamSynchronize(q);
+      if (p->det_stream) (void)hipStreamSynchronize(p->det_stream);
       return rc;
     }
   }
