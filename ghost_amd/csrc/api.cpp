@@ -114,6 +114,7 @@ struct gcwt_plan {
   int64_t fullband_cache_cap = 0;   // bytes of full-band responses kept across executes (set at upload: option
                                     // fullband_cache_mb, else a quarter of the memory free then, at most 16 GiB)
   bool hfull_cache_full = false;    // a response could not be allocated: the cache stays as it is
+  int synth7_order = 0;       // option synth7_order: order of the k_synth7 work items (A/B runs)
   int synthp_help = -1;       // option synthp_help: share (of 128) of a round's tasks the producer waves take (A/B runs; default: by level)
   int synthp_lgnb = -1;       // option synthp_lgnb: blocks per k_synthp workgroup forced (A/B runs)
   int interp_lgnb = -1;       // option interp_lgnb: blocks per k_synthi workgroup forced (A/B runs)
@@ -199,7 +200,8 @@ struct gcwt_plan {
   double last_pt = 0;
   // scales made again by the exact paths: one sub-plan (precision = exact, those scales only) per set of scales,
   // its dense result scattered into this plan's rows
-  struct SubPlan { gcwt_plan* plan = nullptr; int32_t* d_rows = nullptr; };
+  struct SubPlan { gcwt_plan* plan = nullptr; int32_t* d_rows = nullptr; uint64_t used = 0; };
+  uint64_t sub_clock = 0;            // (at most kMaxSubPlans are kept: the least recently used one goes)
   std::map<std::vector<int32_t>, SubPlan> sub_plans;
   float* d_sub_out = nullptr;
   size_t d_sub_out_bytes = 0;
@@ -423,6 +425,7 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->synthp_lgnb = (int)option_or("synthp_lgnb", -1);
   p->synthp_help = (int)option_or("synthp_help", -1);
   p->use_graphs = option_or("graphs", 1) != 0;
+  p->synth7_order = (int)option_or("synth7_order", 0);
   p->auto_threshold = 1e-9f * (float)option_or("auto_threshold_ppb", 3000);
   p->kappa_eps = 1e-9f * (float)option_or("auto_kappa_ppb", 160);
   p->oob_tol = 1e-12f * (float)option_or("auto_oob_ppt", 25000);
@@ -481,6 +484,11 @@ int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info) {
     for (const LevelPlan& lp : hp.levels) listed += (int64_t)lp.scales.size();
     extra += 4 * (listed + 8) * 256 + 8 * 256 * (int64_t)hp.levels.size();   // gain rows in list order, half-sample twiddles
     extra += 8 * (int64_t)channel_sum_doubles((size_t)C) + 4 * (int64_t)hp.interp_coef.size();
+    if (hp.high_precision && !hp.exact_only) {             // the detector's band sums and predictions (precision auto / high)
+      int64_t max_rows = 1;
+      for (const EpochPlan& ep : hp.epochs) max_rows = std::max<int64_t>(max_rows, ep.p1);
+      extra += 4 * (slots * max_rows * kSpecBands + (int64_t)hp.prm.n_freqs * (int64_t)hp.epochs.size());
+    }
     if (hp.n_fullband > 0)
       extra += std::min<int64_t>(plan->uploaded ? plan->fullband_cache_cap : kFullbandCacheBytes,
                                  8 * (int64_t)hp.n_fullband * hp.max_p * (int64_t)hp.epochs.size());
@@ -723,6 +731,24 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       if (level_kernel(p, lp) != LK_SYNTH7) continue;
       for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
         for (int rt = 0; rt < n_rtiles; ++rt) (lp.halo > 48 ? items7w : items7).push_back({(int32_t)l, b0, rt, 0});
+    }
+    // order of the k_synth7 items (option synth7_order, A/B runs): 0 as listed (levels in plan order, R = 2 first),
+    // 1 reversed, 2 the levels' items dealt in turn
+    if (p->synth7_order == 1) std::reverse(items7.begin(), items7.end());
+    else if (p->synth7_order == 2) {
+      std::vector<std::vector<Synth7Item>> by(hp.levels.size());
+      for (const auto& it : items7) by[(size_t)it.level].push_back(it);
+      std::vector<Synth7Item> mixed;
+      std::vector<double> pos(by.size(), 0.0);
+      size_t left = items7.size();
+      while (left) {                                   // always the level that is furthest behind its share
+        size_t best = by.size(); double frac = 2.0;
+        for (size_t l = 0; l < by.size(); ++l)
+          if (pos[l] < (double)by[l].size() && pos[l] / (double)by[l].size() < frac) { frac = pos[l] / (double)by[l].size(); best = l; }
+        mixed.push_back(by[best][(size_t)pos[best]]);
+        pos[best] += 1.0; --left;
+      }
+      items7.swap(mixed);
     }
     p->ep_dev[e].n_items7 = (int)items7.size();
     p->ep_dev[e].n_items7w = (int)items7w.size();
@@ -1442,7 +1468,17 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params);
 static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t out_r0, int64_t r0, int64_t r1, int64_t row_len,
                           const std::vector<int32_t>& over) {
   const HostPlan& hp = p->hp;
+  constexpr size_t kMaxSubPlans = 4;      // each holds an exact plan's workspace (GBs at the headline shape)
+  if (!p->sub_plans.count(over) && p->sub_plans.size() >= kMaxSubPlans) {
+    auto lru = p->sub_plans.begin();
+    for (auto it = p->sub_plans.begin(); it != p->sub_plans.end(); ++it)
+      if (it->second.used < lru->second.used) lru = it;
+    if (lru->second.d_rows) (void)hipFree(lru->second.d_rows);
+    if (lru->second.plan) gcwt_plan_destroy(lru->second.plan);
+    p->sub_plans.erase(lru);
+  }
   gcwt_plan::SubPlan& sp = p->sub_plans[over];
+  sp.used = ++p->sub_clock;
   if (!sp.plan) {
     std::vector<double> f(over.size());
     for (size_t i = 0; i < over.size(); ++i) f[i] = hp.freqs[(size_t)over[i]];

@@ -425,6 +425,30 @@ def test_explicit_high_precision_only_warns(caplog, option):
     p.close()
 
 
+def test_rerouted_scale_sets_come_and_go():
+    """One plan, six recordings with a line in six different places: six different sets of scales to make again.  A
+    plan keeps the exact sub-plans of the four sets used last (each holds an exact plan's workspace); the fifth and
+    sixth push the oldest out, and going back to the first set builds it again -- every result within the gate."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp_channel
+    fs, n = 1000.0, 60000
+    f = np.geomspace(200.0, 3.0, 40)
+    base = lfp_channel(n, fs, 7).astype(np.float64)
+    t = np.arange(n) / fs
+    win = np.sin(np.pi * np.arange(n) / n) ** 2
+    p = CwtPlan(n, 1, fs, f)
+    sets = []
+    for hz in (150.0, 90.0, 55.0, 33.0, 19.0, 11.0, 150.0):
+        x = (base + 300.0 * base.std() * win * np.sin(2 * np.pi * hz * t)).astype(np.float32)
+        got = p.execute(x[None])[0]
+        rep = p.precision_report()
+        assert rep["rerouted"] > 0
+        sets.append(tuple(np.nonzero(rep["predicted"] > 3e-6)[0]))
+        assert rel_err(got, orc.cwt_amplitude(x.astype(np.float64), fs, f)).max() < TOL, hz
+    assert len(set(sets)) >= 5 and sets[0] == sets[-1]
+    p.close()
+
+
 def test_public_call_float64_input_with_a_huge_offset():
     """A float64 recording whose DC level is 1e7 x its fluctuation (float32 would quantise it to steps the size of
     the signal): `transform()` removes the mean in the input's own precision before the cast to the device's float32

@@ -708,3 +708,25 @@ def test_named_options_replace_the_environment(monkeypatch):
 
 
 from ctypes import byref as C_byref, c_double as C_double, c_void_p as C_void_p   # noqa: E402
+
+
+def test_pinned_result_pool_falls_back_without_a_device():
+    """ghost_amd.hostmem hands out page-locked arrays when it can; without a GPU (or over its limit) it returns None and
+    callers allocate pageable memory instead -- nothing raises, nothing is kept."""
+    from ghost_amd import hostmem
+    from ghost_amd.engine import device_count
+    a = hostmem.empty((4, 1000), np.float64)
+    if device_count() == 0:
+        assert a is None
+    else:
+        assert a.shape == (4, 1000) and hostmem.is_pinned(a) and hostmem.is_pinned(a[1:3, ::2])
+        del a
+    old = hostmem.limit_bytes
+    try:
+        hostmem.limit_bytes = 100
+        assert hostmem.empty((1000,), np.float32) is None
+    finally:
+        hostmem.limit_bytes = old
+    assert not hostmem.is_pinned(np.zeros(3))
+    assert hostmem.empty((0, 5), np.float32) is None
+    hostmem.trim()
