@@ -99,6 +99,8 @@ class DeviceResult:
         dtype = np.dtype(narrow if dtype is None else dtype)
         if dtype not in (np.dtype(narrow), np.dtype(wide)):
             raise ValueError("dtype must be %s or %s" % (np.dtype(narrow), np.dtype(wide)))
+        if isinstance(scales, (int, np.integer)):
+            scales = slice(int(scales), int(scales) + 1) if scales != -1 else slice(-1, None)
         sl = range(s)[slice(None) if scales is None else scales]
         if sl.step != 1 and len(sl) > 1:
             raise ValueError("scales must be a contiguous range")

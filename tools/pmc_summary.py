@@ -6,7 +6,8 @@ kern = sys.argv[3] if len(sys.argv) > 3 else "k_synth7<0, 32, false>"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 vals = {}
 for d in ("1", "2", "3"):
-    for f in glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_%s" % (tag, d), "*", "*counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_%s" % (tag, d), "*", "*counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:                  # the newest run of this pass
         acc = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             if kern.replace(" ", "") in row["Kernel_Name"].replace(" ", ""):
