@@ -76,6 +76,8 @@ __global__ void __launch_bounds__(256) k_precision_predict(const float* __restri
   __shared__ float h[kSpecBands];
   __shared__ float hout[kSpecBands];   // what the current level leaves out of band b: (1 - weight) h
   __shared__ float dens[256];
+  __shared__ float gmin[kSpecBands];
+  __shared__ int band_of[256];
   __shared__ float red[4];
   const int tid = threadIdx.x, slot = blockIdx.x;
   for (int i = tid; i < kSpecBands; i += 256) {                  // the rows' band sums, added in row order
@@ -115,13 +117,20 @@ __global__ void __launch_bounds__(256) k_precision_predict(const float* __restri
       float lo, hi;
       band_edges(b, &lo, &hi);
       dens[tid] = h[b] / fmaxf(1.0f, hi - lo) * per_bin;
+      band_of[tid] = b;
     }
     __syncthreads();
     for (int s = 0; s < n_scales; ++s) {
       if (scale_level[s] != l) continue;                         // workgroup-uniform
       const float g = gain[(int64_t)s * 256 + tid];
       const float g2 = g * g;
-      const float e_s = block_sum(g2 * dens[tid], red);
+      // the scale's own energy, conservatively: a band's content counts with the SMALLEST gain the scale has on the
+      // band's bins (a line may sit anywhere in its band, and a steep skirt -- gamma = 6 -- drops tenfold across one)
+      gmin[band_of[tid]] = 3.0e38f;
+      __syncthreads();
+      atomicMin(reinterpret_cast<unsigned*>(gmin) + band_of[tid], __float_as_uint(g2));
+      __syncthreads();
+      const float e_s = block_sum(gmin[band_of[tid]] * dens[tid], red);
       const float w_s = block_sum(g2, red) * (1.0f / 256.0f);
       // what the level leaves out, as the reference's L-tap kernel answers to it: flat side lobes above the band;
       // below it the response of a zero-mean kernel rises linearly from zero frequency to its first side lobe at

@@ -114,6 +114,9 @@ for case in range(n_cases):
         print("   per scale: " + ", ".join("%.4g Hz L %d R %d m %d %.1e" % (f[i], si["length"][i], si["decimation"][i], si["method"][i], e_s[i])
                                            for i in range(f.size)), flush=True)
         print("   epochs", eb, "kw", {k: v for k, v in kw.items() if k != "epoch_bounds"}, flush=True)
+        if kw.get("precision") in (None, "auto", "high"):
+            rep = p.precision_report()
+            print("   predicted " + ", ".join("%.1e" % v for v in rep["predicted"]) + "  rerouted %d" % rep["rerouted"], flush=True)
     worst = max(worst, err / (tol / TOL))
     if err > tol or not same:
         print("FAILED", dict(fs=fs, n=n, eb=eb, f=f.tolist(), kw=kw, block=(a, ln), gamma_beta=(gamma, beta)))
