@@ -192,7 +192,10 @@ struct gcwt_plan {
   float* h_pred = nullptr;           // ... as they arrive: page-locked, so that the 4 S bytes do not go through a staging copy
   float last_worst = 0.f;
   int last_rerouted = 0;
-  float auto_threshold = 3e-6f;      // option auto_threshold_ppb
+  float auto_threshold = 1.5e-6f;    // option auto_threshold_ppb.  The prediction is an r.m.s. figure calibrated on noise-like rows
+                                     // (1.6e-7 D); a row that is nearly a sinusoid (narrow wavelets, gamma = 6) has a crest
+                                     // factor three times smaller, so its gate metric reads three times the prediction: the
+                                     // threshold leaves a factor 6.7 to the 1e-5 gate (benign recordings predict 2 - 4e-7)
   float kappa_eps = 1.6e-7f;         // predicted loss = kappa_eps sqrt(E_level W_s / E_s); option auto_kappa_ppb
   float oob_tol = 2.5e-8f;            // ... or oob_tol sqrt(E_out / E_s), what the level leaves out; option auto_oob_ppt (1e-12)
   int last_batch_slots = 0;          // slots of the last batch that ran (gcwt_debug_precision_terms)
@@ -426,7 +429,7 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->synthp_help = (int)option_or("synthp_help", -1);
   p->use_graphs = option_or("graphs", 1) != 0;
   p->synth7_order = (int)option_or("synth7_order", 0);
-  p->auto_threshold = 1e-9f * (float)option_or("auto_threshold_ppb", 3000);
+  p->auto_threshold = 1e-9f * (float)option_or("auto_threshold_ppb", 1500);
   p->kappa_eps = 1e-9f * (float)option_or("auto_kappa_ppb", 160);
   p->oob_tol = 1e-12f * (float)option_or("auto_oob_ppt", 25000);
   p->fullband_group = (int)option_or("fullband_group", 0);

@@ -203,7 +203,7 @@ class ContinuousWaveletTransform(WaveletTransform):
                                 "more in their decimation bands than in the scales themselves (predicted float32 loss {:.1e} "
                                 "of a scale's peak; precision='high' skips this, 'exact' does it for every scale)"
                                 .format(rep["rerouted"], f.size, rep["worst"] / 1.6e-7, rep["worst"]))
-            elif precision == "high" and rep["worst"] > 3e-6:
+            elif precision == "high" and rep["worst"] > 1.5e-6:
                 logging.warning("precision='high': the float32 stages are predicted to cost some scales {:.1e} of their "
                                 "peak (the recording holds far more inside their decimation bands than they do); "
                                 "precision='auto' (the default) recomputes those scales exactly".format(rep["worst"]))

@@ -123,8 +123,8 @@ typedef enum {
   GCWT_PRECISION_AUTO = 4,   /* what DEFAULT means since ABI 5: HIGH, watched -- while the float64 spectrum is made,
                               * every scale's loss to the float32 stages of its decimation level is predicted from
                               * the band energies of that spectrum (the level's content against the scale's own), and
-                              * the scales predicted above 3e-6 of their peak (a mains line inside an analysed band at
-                              * more than ~20 x the recording's spread) are made again by EXACT's paths, the others
+                              * the scales predicted above 1.5e-6 of their peak (a mains line inside an analysed band at
+                              * more than ~10 x the recording's spread) are made again by EXACT's paths, the others
                               * keep the fast one: the reference's float64 dynamic range (transforms.py:142-143,
                               * convolution.py:68-77) without asking for it.  gcwt_plan_precision_report tells what
                               * happened.  HIGH itself predicts and reports but never reroutes. */

@@ -409,7 +409,7 @@ def test_explicit_high_precision_only_warns(caplog, option):
     with caplog.at_level(logging.WARNING):
         cwt = ContinuousWaveletTransform()
         cwt.transform(x, fs=fs, freqs=f, precision="high")
-    assert cwt.precision_report["rerouted"] == 0 and cwt.precision_report["worst"] > 3e-6
+    assert cwt.precision_report["rerouted"] == 0 and cwt.precision_report["worst"] > 1.5e-6
     assert "precision='high'" in caplog.text and "recomputed" not in caplog.text
     clean = spectrum_class("pink_lfp", n, fs).astype(np.float32)
     p = CwtPlan(n, 1, fs, f)
@@ -443,7 +443,7 @@ def test_rerouted_scale_sets_come_and_go():
         got = p.execute(x[None])[0]
         rep = p.precision_report()
         assert rep["rerouted"] > 0
-        sets.append(tuple(np.nonzero(rep["predicted"] > 3e-6)[0]))
+        sets.append(tuple(np.nonzero(rep["predicted"] > 1.5e-6)[0]))
         assert rel_err(got, orc.cwt_amplitude(x.astype(np.float64), fs, f)).max() < TOL, hz
     assert len(set(sets)) >= 5 and sets[0] == sets[-1]
     p.close()
