@@ -1069,13 +1069,21 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       // precision = auto / high: the spectrum's band energies, then -- on a stream of its own, beside the level passes
       // and the synthesis -- what the float32 stages will cost each scale (detect.hip); joined at the end of the batch
       if (p->detect) {
-        RUN(ST_FWD, launch_spectrum_bands(p->d_x, P, P1, p->d_hist, slots, st));
+        // (a small batch does not fill the chip: there the band pass goes to the detector's stream as well and the
+        // chain of dependent kernels is as long as without the detector; a large one competes for bandwidth wherever
+        // it runs, and beside the level passes it cost them more than it took: profiles/r05_auto_precision.md 3)
+        const bool beside = (int64_t)slots * P <= ((int64_t)1 << 24);
+        if (!beside) RUN(ST_FWD, launch_spectrum_bands(p->d_x, P, P1, p->d_hist, slots, st));
         hipEvent_t bands_done;
         int rc_ = get_event(p, &bands_done);
         if (rc_) return rc_;
         he = hipEventRecord(bands_done, st);
         if (he == hipSuccess) he = hipStreamWaitEvent(p->det_stream, bands_done, 0);
         if (he != hipSuccess) return hip_err(he, "detector fork");
+        if (beside) {
+          he = launch_spectrum_bands(p->d_x, P, P1, p->d_hist, slots, p->det_stream);
+          if (he != hipSuccess) return hip_err(he, "launch_spectrum_bands");
+        }
         he = launch_precision_predict(p->d_hist, P1, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[ep.batch_first].pred_levels, S,
                                       (int)hp.levels.size(), (double)Pt, p->kappa_eps, p->oob_tol, p->d_pred, nullptr, nullptr, slots, psegs,
                                       p->det_stream);
