@@ -205,7 +205,7 @@ struct gcwt_plan {
   // its dense result scattered into this plan's rows
   struct SubPlan { gcwt_plan* plan = nullptr; int32_t* d_rows = nullptr; uint64_t used = 0; };
   uint64_t sub_clock = 0;            // (at most kMaxSubPlans are kept: the least recently used one goes)
-  std::map<std::vector<int32_t>, SubPlan> sub_plans;
+  std::map<std::vector<int32_t>, SubPlan> sub_plans;   // key: the scales, then the sub-plan's channel count (all, or 1)
   float* d_sub_out = nullptr;
   size_t d_sub_out_bytes = 0;
   // Small device-resident executes are launch-bound (config 1: fifteen kernels of a few microseconds each): the
@@ -911,7 +911,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       for (const EpochPlan& ep : hp.epochs)
         max_rows = std::max<int64_t>(max_rows, ep.p1);
       if ((rc = dev_alloc(&p->d_hist, (size_t)(slots * max_rows * kSpecBands)))) return bail(rc);
-      if ((rc = dev_alloc(&p->d_pred, (size_t)S * hp.epochs.size()))) return bail(rc);
+      if ((rc = dev_alloc(&p->d_pred, (size_t)S * (size_t)C * hp.epochs.size()))) return bail(rc);
       if ((rc = upload_vec(&p->d_scale_level, scale_level, p->stream))) return bail(rc);
       std::vector<int32_t> scale_length((size_t)S);
       for (int i = 0; i < S; ++i) scale_length[(size_t)i] = (int32_t)std::min<int64_t>(hp.scales[i].length, (int64_t)1 << 30);
@@ -932,7 +932,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
         if ((rc = upload_vec(&p->ep_dev[e].pred_levels, pl, p->stream))) return bail(rc);
       }
       p->last_pred.assign((size_t)S, 0.f);
-      HIP_TRY(hipHostMalloc((void**)&p->h_pred, sizeof(float) * (size_t)S * hp.epochs.size(), hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc((void**)&p->h_pred, sizeof(float) * (size_t)S * (size_t)C * hp.epochs.size(), hipHostMallocDefault));
       HIP_TRY(hipStreamSynchronize(p->stream));       // the vectors of this block go out of scope
     }
   }
@@ -989,7 +989,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
 
   if (!reuse_means) RUN(ST_MEAN, launch_channel_sum(dx, N, C, p->d_sums, st));
   if (p->detect) {
-    he = hipMemsetAsync(p->d_pred, 0, sizeof(float) * (size_t)S * hp.epochs.size(), st);
+    he = hipMemsetAsync(p->d_pred, 0, sizeof(float) * (size_t)S * (size_t)C * hp.epochs.size(), st);
     if (he != hipSuccess) return hip_err(he, "predictions reset");
   }
 
@@ -1477,10 +1477,14 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params);
 // them (made on first use, kept per set of scales), from the same device-resident recording; its dense rows are
 // copied over the fast path's.  The sub-plan computes its own channel means (same numbers: same kernel, same x).
 static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t out_r0, int64_t r0, int64_t r1, int64_t row_len,
-                          const std::vector<int32_t>& over) {
+                          const std::vector<int32_t>& over, int channel) {
+  // channel >= 0: that channel alone, by a one-channel sub-plan (a recording with one bad electrode pays for one)
   const HostPlan& hp = p->hp;
+  const int nch = channel >= 0 ? 1 : hp.prm.n_channels;
+  std::vector<int32_t> key = over;
+  key.push_back(nch);
   constexpr size_t kMaxSubPlans = 4;      // each holds an exact plan's workspace (GBs at the headline shape)
-  if (!p->sub_plans.count(over) && p->sub_plans.size() >= kMaxSubPlans) {
+  if (!p->sub_plans.count(key) && p->sub_plans.size() >= kMaxSubPlans) {
     auto lru = p->sub_plans.begin();
     for (auto it = p->sub_plans.begin(); it != p->sub_plans.end(); ++it)
       if (it->second.used < lru->second.used) lru = it;
@@ -1488,7 +1492,7 @@ static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t ou
     if (lru->second.plan) gcwt_plan_destroy(lru->second.plan);
     p->sub_plans.erase(lru);
   }
-  gcwt_plan::SubPlan& sp = p->sub_plans[over];
+  gcwt_plan::SubPlan& sp = p->sub_plans[key];
   sp.used = ++p->sub_clock;
   if (!sp.plan) {
     std::vector<double> f(over.size());
@@ -1496,34 +1500,37 @@ static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t ou
     gcwt_params prm = hp.prm;
     prm.freqs_hz = f.data();
     prm.n_freqs = (int32_t)f.size();
+    prm.n_channels = nch;
     prm.precision = GCWT_PRECISION_EXACT;
     prm.device = p->device;
     int rc = gcwt_plan_create_impl(&sp.plan, &prm);
-    if (rc) { p->sub_plans.erase(over); return rc; }
-    if ((rc = gcwt_plan_upload(sp.plan))) { gcwt_plan_destroy(sp.plan); p->sub_plans.erase(over); return rc; }
+    if (rc) { p->sub_plans.erase(key); return rc; }
+    if ((rc = gcwt_plan_upload(sp.plan))) { gcwt_plan_destroy(sp.plan); p->sub_plans.erase(key); return rc; }
     if (hipMalloc((void**)&sp.d_rows, sizeof(int32_t) * over.size()) != hipSuccess ||
         hipMemcpy(sp.d_rows, over.data(), sizeof(int32_t) * over.size(), hipMemcpyHostToDevice) != hipSuccess) {
       (void)hipGetLastError();
       gcwt_plan_destroy(sp.plan);
       if (sp.d_rows) (void)hipFree(sp.d_rows);
-      p->sub_plans.erase(over);
+      p->sub_plans.erase(key);
       return set_err(GCWT_ERR_NOMEM, "no device memory for the rerouted scales' row list");
     }
   }
   const int64_t n_out = r1 - r0;
   const int64_t pitch = (n_out + 31) & ~(int64_t)31;
   const int elem = hp.out_elem_bytes / (int)sizeof(float);
-  const size_t need = sizeof(float) * (size_t)elem * (size_t)pitch * over.size() * (size_t)hp.prm.n_channels;
+  const size_t need = sizeof(float) * (size_t)elem * (size_t)pitch * over.size() * (size_t)nch;
   if (p->d_sub_out_bytes < need) {
     if (p->d_sub_out) { (void)hipFree(p->d_sub_out); p->d_sub_out = nullptr; p->d_sub_out_bytes = 0; }
     HIP_TRY(hipMalloc((void**)&p->d_sub_out, need));
     p->d_sub_out_bytes = need;
   }
   sp.plan->row_pitch = pitch;
-  int rc = execute_range(sp.plan, dx, p->d_sub_out, r0, r1, GCWT_X_ON_DEVICE | GCWT_OUT_ON_DEVICE);
+  const int64_t ch0 = channel >= 0 ? channel : 0;
+  int rc = execute_range(sp.plan, dx + ch0 * hp.prm.n_samples, p->d_sub_out, r0, r1, GCWT_X_ON_DEVICE | GCWT_OUT_ON_DEVICE);
   if (rc) return rc;
-  hipError_t he = launch_scatter_rows(p->d_sub_out, dout + (r0 - out_r0) * elem, sp.d_rows, (int)over.size(), hp.prm.n_freqs,
-                                      hp.prm.n_channels, n_out * elem, pitch * elem, row_len * elem, p->stream);
+  float* dst = dout + (ch0 * hp.prm.n_freqs * row_len + (r0 - out_r0)) * elem;
+  hipError_t he = launch_scatter_rows(p->d_sub_out, dst, sp.d_rows, (int)over.size(), hp.prm.n_freqs, nch, n_out * elem,
+                                      pitch * elem, row_len * elem, p->stream);
   if (he != hipSuccess) return hip_err(he, "launch_scatter_rows");
   HIP_TRY(hipStreamSynchronize(p->stream));
   return GCWT_OK;
@@ -1623,36 +1630,58 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   if (p->detect) {
     // precision = auto / high: read the predictions; auto makes the scales over the threshold again by the exact paths
     // (a sub-plan with precision = exact for just those scales; its rows replace the fast path's)
-    const size_t n_seg = hp.epochs.size(), Sz = (size_t)hp.prm.n_freqs;
-    HIP_TRY(hipMemcpyAsync(p->h_pred, p->d_pred, sizeof(float) * Sz * n_seg, hipMemcpyDeviceToHost, p->stream));
+    const size_t n_seg = hp.epochs.size(), Sz = (size_t)hp.prm.n_freqs, Cz = (size_t)hp.prm.n_channels;
+    HIP_TRY(hipMemcpyAsync(p->h_pred, p->d_pred, sizeof(float) * Sz * Cz * n_seg, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    // The verdict is per segment (epoch or time block), so that a block request and the whole transform decide alike
-    // for the samples they share: segment e's scales over the threshold are made again for e's own core, runs of
-    // neighbouring segments with the same set in one go.
+    // The verdict is per segment (epoch or time block) and channel, so that a block request and the whole transform
+    // decide alike for the samples they share.  A segment's scales over the threshold (on any of its flagged
+    // channels) are made again for the segment's own core: for every channel when half of them or more are flagged,
+    // else for the flagged channels one by one (a one-channel sub-plan: a recording with one bad electrode pays for
+    // one); runs of neighbouring segments with the same verdict go in one request.
     std::fill(p->last_pred.begin(), p->last_pred.end(), 0.f);
-    std::vector<std::vector<int32_t>> over(n_seg);
-    std::vector<char> any((size_t)Sz, 0);
-    for (size_t e = 0; e < n_seg; ++e)
-      for (size_t i = 0; i < Sz; ++i) {
-        const float v = p->h_pred[e * Sz + i];
-        p->last_pred[i] = std::max(p->last_pred[i], v);
-        if (v > p->auto_threshold) { over[e].push_back((int32_t)i); any[i] = 1; }
+    struct Verdict {
+      std::vector<int32_t> scales, channels;
+      bool operator==(const Verdict& o) const { return scales == o.scales && channels == o.channels; }
+    };
+    std::vector<Verdict> vd(n_seg);
+    std::vector<char> any(Sz, 0);
+    for (size_t e = 0; e < n_seg; ++e) {
+      std::vector<char> sc(Sz, 0);
+      for (size_t c = 0; c < Cz; ++c) {
+        bool flagged = false;
+        for (size_t i = 0; i < Sz; ++i) {
+          const float v = p->h_pred[(e * Cz + c) * Sz + i];
+          p->last_pred[i] = std::max(p->last_pred[i], v);
+          if (v > p->auto_threshold) { sc[i] = 1; any[i] = 1; flagged = true; }
+        }
+        if (flagged) vd[e].channels.push_back((int32_t)c);
       }
+      for (size_t i = 0; i < Sz; ++i)
+        if (sc[i]) vd[e].scales.push_back((int32_t)i);
+      if (2 * vd[e].channels.size() >= Cz) vd[e].channels.clear();            // empty list with scales: every channel
+    }
     p->last_worst = 0.f;
     for (float v : p->last_pred) p->last_worst = std::max(p->last_worst, v);
     p->last_rerouted = 0;
     if (hp.auto_precision) {
       for (size_t e = 0; e < n_seg;) {
         size_t e1 = e + 1;
-        if (over[e].empty()) { e = e1; continue; }
+        if (vd[e].scales.empty()) { e = e1; continue; }
         int64_t a = std::max(hp.epochs[e].core0, r0), b = std::min(hp.epochs[e].core1, r1);
-        while (e1 < n_seg && over[e1] == over[e] && hp.epochs[e1].core0 >= hp.epochs[e1 - 1].core1) {   // (segments come in time order)
+        while (e1 < n_seg && vd[e1] == vd[e] && hp.epochs[e1].core0 >= hp.epochs[e1 - 1].core1) {   // (segments come in time order)
           b = std::min(hp.epochs[e1].core1, r1);
           ++e1;
         }
         if (b > a) {
-          rc = reroute_scales(p, dx, dout, r0, a, b, row_len, over[e]);
-          if (rc) return rc;
+          if (vd[e].channels.empty()) {
+            rc = reroute_scales(p, dx, dout, r0, a, b, row_len, vd[e].scales, -1);
+            if (rc) return rc;
+          } else {
+            for (int32_t c : vd[e].channels) {
+              rc = reroute_scales(p, dx, dout, r0, a, b, row_len, vd[e].scales, c);
+              if (rc) return rc;
+            }
+          }
         }
         e = e1;
       }

@@ -156,8 +156,9 @@ __global__ void __launch_bounds__(256) k_precision_predict(const float* __restri
         const float p2 = e_s > 0.f ? oob_tol * sqrtf(e_out / e_s) : 0.f;
         const float p = fmaxf(p1, p2);
         if (dbg_scale) { dbg_scale[((int64_t)slot * 2) * n_scales + s] = p1; dbg_scale[((int64_t)slot * 2 + 1) * n_scales + s] = p2; }
-        // the largest over the segment's channels (p >= 0: the bit patterns order like the values)
-        atomicMax(reinterpret_cast<unsigned*>(pred) + (int64_t)segs.seg[slot / segs.n_channels] * n_scales + s, __float_as_uint(p));
+        // pred[segment][channel][scale]: one writer each (a scale belongs to one level)
+        const int g = slot / segs.n_channels, ch = slot - g * segs.n_channels;
+        pred[((int64_t)segs.seg[g] * segs.n_channels + ch) * n_scales + s] = p;
       }
     }
     __syncthreads();

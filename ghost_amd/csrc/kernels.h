@@ -316,7 +316,7 @@ __host__ __device__ inline int spec_band(float k) {
   const int v = (int)(b.u >> 19) - 127 * 16;
   return v < 0 ? 0 : (v >= kSpecBands ? kSpecBands - 1 : v);
 }
-struct PredSegs {           // slot = g * n_channels + channel belongs to the plan's segment seg[g]: pred is [segments][S]
+struct PredSegs {           // slot = g * n_channels + channel belongs to the plan's segment seg[g]: pred is [segments][C][S]
   int32_t seg[kSegBatch];
   int32_t n_channels, pad;
 };

@@ -363,7 +363,7 @@ def test_default_call_leaves_benign_recordings_on_the_fast_path(caplog):
     """Pink LFP, brown and 1/f^3 noise: nothing is predicted over the threshold, nothing is rerouted, nothing is logged;
     a drift of 1000 x the spread below every band is caught through the part of the spectrum the levels leave out (the
     reference's L-tap kernels answer to it through their side lobes: transforms.py:187-204).  Two channels of which one
-    carries a line: the scales are rerouted for both (the rows of a scale are made by one launch)."""
+    carries a line: half of the channels are flagged, so the scales are rerouted for both."""
     import logging
     from ghost_amd.engine import CwtPlan
     from ghost_amd.synthetic import spectrum_class, lfp_channel
@@ -394,6 +394,39 @@ def test_default_call_leaves_benign_recordings_on_the_fast_path(caplog):
     for ch in range(2):
         assert rel_err(got[ch], orc.cwt_amplitude(xs[ch].astype(np.float64), fs, f, n_threads=8)).max() < TOL
     p.close()
+
+
+def test_one_bad_electrode_pays_for_one():
+    """Four channels, one with a mains line at 300 x: the verdict is per (segment, channel), the flagged scales are made
+    again for that channel alone (a one-channel exact sub-plan) and the clean channels keep the fast path's numbers to
+    the bit; with three of four flagged, every channel goes.  Block requests decide alike."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp_channel
+    fs, n = 1000.0, 200000
+    f = np.geomspace(200.0, 2.0, 60)
+    t = np.arange(n) / fs
+    line = np.sin(np.pi * np.arange(n) / n) ** 2 * np.sin(2 * np.pi * 60.0 * t)
+    chans = [lfp_channel(n, fs, 11 + c).astype(np.float64) for c in range(4)]
+    for dirty in ([2], [0, 1, 3]):
+        xs = np.stack([c + (300.0 * c.std() * line if i in dirty else 0.0) for i, c in enumerate(chans)]).astype(np.float32)
+        ph = CwtPlan(n, 4, fs, f, precision="high")
+        high = ph.execute(xs)
+        ph.close()
+        p = CwtPlan(n, 4, fs, f)
+        got = p.execute(xs)
+        rep = p.precision_report()
+        assert rep["rerouted"] > 0
+        for ch in range(4):
+            ref = orc.cwt_amplitude(xs[ch].astype(np.float64), fs, f, n_threads=8)
+            assert rel_err(got[ch], ref).max() < TOL, (dirty, ch)
+            same = np.array_equal(got[ch], high[ch])
+            if len(dirty) == 1:
+                assert same == (ch not in dirty), (dirty, ch)
+            else:
+                assert not same, (dirty, ch)
+        blk = p.execute_block(xs, 70001, 20002)
+        np.testing.assert_array_equal(blk, got[:, :, 70001:90003])
+        p.close()
 
 
 def test_explicit_high_precision_only_warns(caplog, option):
