@@ -786,10 +786,10 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       if (lp.interp_q < 2 || lp.interp_q > kInterpMaxPhases || (lp.interp_q & (lp.interp_q - 1)) ||
           lp.interp_factor * lp.interp_q != lp.decimation || lp.interp_factor < 4 ||
           lp.interp_factor > kInterpMaxFactor || lp.scales.size() > 256 || lp.halo < 16 ||
-          lp.hop != hp.block - 2 * lp.halo || lp.hop < 1 || hp.block != 256)
+          lp.hop != hp.block - 2 * lp.halo || lp.hop < 1 || hp.block != 256 || (lp.interp_taps != 6 && lp.interp_taps != 8))
         return bail(set_err(GCWT_ERR_INVALID, "internal: interpolated level outside the kernel's limits"));
       lvi[l] = {lp.decimation, lp.interp_q, lgq, lp.interp_factor, lp.hop, lp.halo, ep.lv[l].nblk,
-                (int32_t)lp.scales.size(), scale_off[l], ep.lv[l].blk_lo, lgnb, 0, lp.twiddle_offset,
+                (int32_t)lp.scales.size(), scale_off[l], ep.lv[l].blk_lo, lgnb, lp.interp_taps, lp.twiddle_offset,
                 ep.lv[l].xr_offset, ep.lv[l].m - 1, lp.coef_offset};
       pending.push_back({l, lgnb});
     }

@@ -146,11 +146,11 @@ struct SynthiItem {
 struct SynthiLevel {
   int32_t decimation, q, log2q, factor;   // R, phases per (block, scale), I = R / q
   int32_t hop, halo, nblk, n_scales, scale_offset, blk_base;
-  int32_t log2nb, pad1; // 1 << log2nb consecutive blocks per workgroup
+  int32_t log2nb, taps; // 1 << log2nb consecutive blocks per workgroup; interpolator taps: 8, or 6 (the rows' middle six)
   int64_t tw_offset;    // into level_tw
   int64_t xr_offset;    // per-channel offset of this level's decimated signal x_R (complex elems)
   int64_t m_mask;       // M - 1, M = P / R samples of x_R (circular index)
-  int64_t coef_offset;  // into coef: [2][I][T] floats
+  int64_t coef_offset;  // into coef: [2][I][kInterpTaps] floats
 };
 struct SynthiArgs {
   const float2* tw256;

@@ -311,24 +311,16 @@ static void analyse_scale(const HostPlan& hp, ScalePlan* sp, const double* amp) 
 // the interpolation adds: max over bins of |G_s[k]| / peak times the interpolator's error at that
 // bin's distance from the demodulation centre.  A level whose bound exceeds interp_tol stays on
 // the FFT-per-sample kernels.
-static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp, std::vector<float>* coef_out) {
-  constexpr int T = kInterpTaps;
+// One candidate: q phases per (block, scale) through the block transform, T taps between them (6 or 8; the table
+// rows are kInterpTaps wide either way, the six in the middle).  true: designed and within the tolerance.
+static bool design_interp_level(HostPlan* hp, LevelPlan* lp, int q, int T, std::vector<float>* coef_out) {
   const int B = hp->block, R = lp->decimation;
-  lp->interp_q = 0;
-  if (hp->prm.out_mode == GCWT_OUT_COMPLEX_C64) return;   // the demodulation would have to be undone per sample
-  // Below R = 16 the q = 2 phases through the block transform are a quarter or more of the
-  // FFT-per-sample work and the interpolation does not pay (profiles/r03_synth_study.md);
-  // GHOSTCWT_INTERP_MIN_R moves the line, GHOSTCWT_INTERP_Q sets the phases per scale (A/B runs).
-  int min_r = 16, q = 2;
-  min_r = (int)std::max<long long>(8, option_or("interp_min_r", min_r));     // (measure build only)
-  q = option_or("interp_q", q) == 4 ? 4 : 2;
-  if (R < min_r || R < 4 * q || lp->scales.empty()) return;     // I = R / q >= 4: a lane makes 4 samples of one interval
+  if (R < 4 * q) return false;                             // I = R / q >= 4: a lane makes 4 samples of one interval
   while (R / q > kInterpMaxFactor) q *= 2;
-  if (q > kInterpMaxPhases) return;                        // a pass of the kernel has 16 columns
-  if (lp->scales.size() > 256) return;                     // the kernel parks a level's scale list in LDS
+  if (q > kInterpMaxPhases) return false;                  // a pass of the kernel has 16 columns
   const int I = R / q;
   for (int sidx : lp->scales)
-    if (hp->scales[sidx].n_bins > 4096) return;            // 'energy' members with very long kernels: the gain
+    if (hp->scales[sidx].n_bins > 4096) return false;            // 'energy' members with very long kernels: the gain
                                                            // probes below would take seconds
   // gains on the level's grid, band edges and demodulation bins
   std::vector<std::vector<double>> gains(lp->scales.size(), std::vector<double>((size_t)B));
@@ -351,7 +343,7 @@ static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp, std::vector<
       g[(size_t)k] = ((double)k < lo_k || (double)k > hi_k) ? 0.0 : ge;    // the design sees the band and its skirt
       pk = std::max(pk, g[(size_t)k]);
     }
-    if (!(pk > 0.0)) return;
+    if (!(pk > 0.0)) return false;
     int klo = B, khi = -1;
     for (int k = 0; k < B; ++k) {
       gains_all[n][(size_t)k] /= pk;
@@ -371,7 +363,7 @@ static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp, std::vector<
   for (int d = 0; d < B; ++d)
     if (genv[(size_t)(B + d)] > 1e-4) hw = (double)d + 1.0;
   const double alpha = hw / (0.5 * B) / (double)q;
-  if (alpha > 0.9) return;
+  if (alpha > 0.9) return false;
   // The same level geometry comes back with every plan of a recording (one transform() per call):
   // a small process-wide cache keyed by what the design depends on -- the envelope, to float
   // precision -- saves the fit (the bound below is recomputed: it depends on the scales).
@@ -422,11 +414,41 @@ static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp, std::vector<
   bound *= probe_margin;
   lp->interp_err = bound;
   lp->interp_alpha = alpha;
-  if (!(bound <= hp->interp_tol)) return;
+  if (!(bound <= hp->interp_tol)) return false;
   lp->interp_q = q;
+  lp->interp_taps = T;
   lp->interp_factor = I;
   lp->coef_offset = 0;                    // within coef_out: the caller places it in HostPlan::interp_coef
-  for (double v : c) coef_out->push_back((float)v);
+  // rows of kInterpTaps floats: tap j of T sits at j + (kInterpTaps - T) / 2, i.e. at the same z sample
+  coef_out->clear();
+  const int pad = (kInterpTaps - T) / 2;
+  for (size_t row = 0; row < (size_t)2 * I; ++row)
+    for (int j = 0; j < kInterpTaps; ++j)
+      coef_out->push_back(j >= pad && j < pad + T ? (float)c[row * T + (size_t)(j - pad)] : 0.f);
+  return true;
+}
+
+static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp, std::vector<float>* coef_out) {
+  const int R = lp->decimation;
+  lp->interp_q = 0;
+  if (hp->prm.out_mode == GCWT_OUT_COMPLEX_C64) return;   // the demodulation would have to be undone per sample
+  // Below R = 16 the q = 2 phases through the block transform are a quarter or more of the
+  // FFT-per-sample work and the interpolation does not pay (profiles/r03_synth_study.md);
+  // GHOSTCWT_INTERP_MIN_R moves the line, GHOSTCWT_INTERP_Q / _TAPS fix the phases per scale and the taps (A/B runs).
+  const int min_r = (int)std::max<long long>(8, option_or("interp_min_r", 16));     // (measure build only)
+  if (R < min_r || lp->scales.empty()) return;
+  if (lp->scales.size() > 256) return;                     // the kernel parks a level's scale list in LDS
+  // From R = 32 up four phases and six taps: a quarter fewer multiply-adds per stored sample for twice the (small)
+  // transform work, and the closer spacing makes the shorter filter the more accurate one (profiles/r05_synth_study.md
+  // 5); eight taps, then two phases, where the bound says otherwise.  The pipelined kernel (option synthp) is written for
+  // two phases and eight taps.
+  const long long oq = option_or("interp_q", 0), ot = option_or("interp_taps", 0);
+  std::vector<std::pair<int, int>> cands;
+  if (oq || ot) cands.push_back({oq == 4 ? 4 : 2, ot == 6 ? 6 : 8});
+  else if (R < 32 || option_or("synthp", 0) != 0) cands.push_back({2, 8});
+  else cands = {{4, 6}, {4, 8}, {2, 8}};
+  for (const auto& cd : cands)
+    if (design_interp_level(hp, lp, cd.first, cd.second, coef_out)) return;
 }
 
 // The same levels come back with every plan of a recording (ContinuousWaveletTransform.transform() makes one per
@@ -435,7 +457,7 @@ static void plan_interp_level_uncached(HostPlan* hp, LevelPlan* lp, std::vector<
 // process-wide, keyed by everything it depends on.
 namespace {
 struct InterpDesign {
-  int q, factor;
+  int q, taps, factor;
   double alpha, err;
   std::vector<int> demod;
   std::vector<float> coef;       // empty when the level is not interpolated
@@ -447,7 +469,8 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp, std::vector<float>* c
   static std::map<std::vector<double>, InterpDesign> cache;
   std::vector<double> key{(double)hp->block, (double)lp->decimation, (double)lp->band_shift, (double)hp->prm.out_mode,
                           hp->prm.gamma, hp->prm.beta, (double)hp->prm.wavelet_flags, hp->interp_tol,
-                          (double)option_or("interp_min_r", 16), (double)option_or("interp_q", 2)};
+                          (double)option_or("interp_min_r", 16), (double)option_or("interp_q", 0),
+                          (double)option_or("interp_taps", 0), (double)option_or("synthp", 0)};
   for (int sidx : lp->scales) { key.push_back(hp->scales[sidx].omega); key.push_back((double)hp->scales[sidx].length); }
   {
     std::lock_guard<std::mutex> lock(mu);
@@ -455,6 +478,7 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp, std::vector<float>* c
     if (it != cache.end()) {
       const InterpDesign& d = it->second;
       lp->interp_q = d.coef.empty() ? 0 : d.q;
+      lp->interp_taps = d.taps;
       lp->interp_factor = d.factor;
       lp->interp_alpha = d.alpha;
       lp->interp_err = d.err;
@@ -467,7 +491,7 @@ static void plan_interp_level(HostPlan* hp, LevelPlan* lp, std::vector<float>* c
     }
   }
   plan_interp_level_uncached(hp, lp, coef_out);
-  InterpDesign d{lp->interp_q, lp->interp_factor, lp->interp_alpha, lp->interp_err, {}, {}};
+  InterpDesign d{lp->interp_q, lp->interp_taps, lp->interp_factor, lp->interp_alpha, lp->interp_err, {}, {}};
   for (int sidx : lp->scales) d.demod.push_back(hp->scales[sidx].demod_bin);
   if (lp->interp_q > 0) d.coef = *coef_out;
   else coef_out->clear();

@@ -82,6 +82,7 @@ struct LevelPlan {
   // Interpolating synthesis (synthi.hip, interp.h; amplitude and power only): the level's scales
   // are made at q x the level's rate and brought to the full rate by a T-tap polyphase FIR.
   int interp_q = 0;                // phases of the 256-point inverse FFT per (block, scale); 0: not interpolated
+  int interp_taps = 8;             // taps of the interpolator: 8, or 6 (the middle six of the table's rows)
   int interp_factor = 0;           // I = R / q
   int64_t coef_offset = 0;         // into HostPlan::interp_coef: [2][I][T] floats (odd / even kernel lengths)
   double interp_alpha = 0;         // design band of the interpolator, fraction of the oversampled Nyquist

@@ -6,7 +6,7 @@
 // scale) goes through that transform only for q of its R phases (q = 2; 4 / 8 where R / 2 would
 // exceed the largest interpolation factor) -- the scale's complex output z at q x the level's
 // rate, demodulated to its band centre so that it is a low-pass signal -- and the R / q = I
-// samples between two of those come from an 8-tap polyphase FIR with real coefficients
+// samples between two of those come from an 8-tap (q = 2) or 6-tap (q = 4) polyphase FIR with real coefficients
 // (interp.h: minimax design under the envelope of the level's gains; what it adds is bounded per
 // level from the scales' own gains, planner.cpp: plan_interp_level, and stays below 2e-7 of a
 // scale's peak).  |.| does not see the demodulation.  Per stored sample: 8 packed FMAs + |.|
@@ -59,21 +59,53 @@ constexpr int kExElems = kZElems > 16 * kPlaneI ? kZElems : 16 * kPlaneI;   // .
 constexpr int kGainRowI = 16 * 20;
 constexpr int kLdsBytes = kExElems * 8 + 256 * 8 + kSlotsMax * kGainRowI * 4 + 2 * 256 * 4;
 
-// acc += z * c.x  /  acc += z * c.y: complex z, real coefficient broadcast to both halves
-__device__ __forceinline__ v2f fir_mul_lo(v2f z, v2f c) {
+// Two neighbouring samples share an accumulator pair: re = (re_0, re_1), im = (im_0, im_1), the tap's coefficients
+// of both samples side by side in one register pair, z's real or imaginary part broadcast to both halves -- so that
+// |.|^2 of two samples is one packed multiply and one packed multiply-add.
+__device__ __forceinline__ v2f fir_mul_re(v2f z, v2f c) {
   v2f r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(z), "v"(c));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(z), "v"(c));
   return r;
 }
-__device__ __forceinline__ v2f fir_fma_lo(v2f acc, v2f z, v2f c) {
+__device__ __forceinline__ v2f fir_mul_im(v2f z, v2f c) {
   v2f r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(z), "v"(c), "v"(acc));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(z), "v"(c));
   return r;
 }
-__device__ __forceinline__ v2f fir_fma_hi(v2f acc, v2f z, v2f c) {
+__device__ __forceinline__ v2f fir_fma_re(v2f acc, v2f z, v2f c) {
   v2f r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(z), "v"(c), "v"(acc));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(z), "v"(c), "v"(acc));
   return r;
+}
+__device__ __forceinline__ v2f fir_fma_im(v2f acc, v2f z, v2f c) {
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(z), "v"(c), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ v2f pk_mul(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) {
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// taps J0 .. J1 - 1 of the table's rows on the z values around a lane's four samples
+template <int J0, int J1>
+__device__ __forceinline__ void fir_taps(const v2f* zp, const v2f (&cf)[2][kT], v2f (&are)[2], v2f (&aim)[2]) {
+  {
+    const v2f w = zp[J0];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) { are[pr] = fir_mul_re(w, cf[pr][J0]); aim[pr] = fir_mul_im(w, cf[pr][J0]); }
+  }
+#pragma unroll
+  for (int j = J0 + 1; j < J1; ++j) {
+    const v2f w = zp[j];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) { are[pr] = fir_fma_re(are[pr], w, cf[pr][j]); aim[pr] = fir_fma_im(aim[pr], w, cf[pr][j]); }
+  }
 }
 }  // namespace
 
@@ -181,6 +213,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
 
   // phase B geometry: lane-tasks of 4 consecutive samples, 64 of them per wave-task
   const int I = lv.factor;
+  const bool six = lv.taps == 6;
   int lgi4 = 0;
   while ((4 << lgi4) < I) ++lgi4;                             // I / 4 = 1 << lgi4
   const int tps = hop * (R >> 2);                             // lane-tasks per (block, scale)
@@ -197,7 +230,7 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
   const int s_base = (int)(n_b - w_lo);                       // window-relative sample of the block's first
   const int pass_end = it.pass0 + it.n_pass;   // of the (n_scales + ns - 1) >> lgns passes of the level's walk
   int cur_par = -1;                       // which coefficients cf holds: kernels of odd (0) / even (1) length, (wt mod 4 class) << 1
-  v2f cf[4][kT / 2];
+  v2f cf[2][kT];                          // [pair of samples][tap]: the tap's coefficients of samples 2 pair, 2 pair + 1
   __syncthreads();
 
   for (int pass = it.pass0; pass < pass_end; ++pass) {
@@ -283,10 +316,10 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
           const int sigma = (wt0 * 64 + lane) & ((1 << lgi4) - 1);
           const float4* const cp = reinterpret_cast<const float4*>(coef_lv + ((int64_t)par * I + sigma * 4) * kT);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float4 u0 = cp[2 * i], u1 = cp[2 * i + 1];
-            cf[i][0] = (v2f){u0.x, u0.y}; cf[i][1] = (v2f){u0.z, u0.w};
-            cf[i][2] = (v2f){u1.x, u1.y}; cf[i][3] = (v2f){u1.z, u1.w};
+          for (int pr = 0; pr < 2; ++pr) {
+            const float4 a0 = cp[4 * pr], a1 = cp[4 * pr + 1], b0 = cp[4 * pr + 2], b1 = cp[4 * pr + 3];
+            cf[pr][0] = (v2f){a0.x, b0.x}; cf[pr][1] = (v2f){a0.y, b0.y}; cf[pr][2] = (v2f){a0.z, b0.z}; cf[pr][3] = (v2f){a0.w, b0.w};
+            cf[pr][4] = (v2f){a1.x, b1.x}; cf[pr][5] = (v2f){a1.y, b1.y}; cf[pr][6] = (v2f){a1.z, b1.z}; cf[pr][7] = (v2f){a1.w, b1.w};
           }
           cur_par = key;
         }
@@ -312,24 +345,16 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
           const bool whole = wt * 64 + 64 <= tps && s_first >= 0 && (int64_t)s_first + 256 <= w_len;
           if (whole || k < tps) {
             const v2f* const zp = zs + (k >> lgi4);
-            // tap by tap: four accumulators live, two z values at a time
-            v2f acc[4];
-            {
-              const v2f w0 = zp[0], w1 = zp[1];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[i] = fir_fma_hi(fir_mul_lo(w0, cf[i][0]), w1, cf[i][0]);
-            }
-#pragma unroll
-            for (int j = 1; j < kT / 2; ++j) {
-              const v2f w0 = zp[2 * j], w1 = zp[2 * j + 1];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[i] = fir_fma_hi(fir_fma_lo(acc[i], w0, cf[i][j]), w1, cf[i][j]);
-            }
+            // tap by tap: two (re, im) accumulator pairs live
+            v2f are[2], aim[2];
+            if (six) fir_taps<1, kT - 1>(zp, cf, are, aim);   // level-uniform: the rows' middle six taps
+            else fir_taps<0, kT>(zp, cf, are, aim);
             float res[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float p2v = __builtin_fmaf(acc[i].y, acc[i].y, acc[i].x * acc[i].x);
-              res[i] = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2v) : p2v;
+            for (int pr = 0; pr < 2; ++pr) {
+              const v2f p2v = pk_fma(aim[pr], aim[pr], pk_mul(are[pr], are[pr]));
+              res[2 * pr] = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2v.x) : p2v.x;
+              res[2 * pr + 1] = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2v.y) : p2v.y;
             }
             const int s0 = s_blk + 4 * k;                     // window-relative sample of res[0]
             if (whole) {                                      // wave-uniform: no lane looks at its own range
