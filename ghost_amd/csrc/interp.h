@@ -16,7 +16,7 @@
 
 namespace gcwt {
 
-constexpr int kInterpTaps = 8;       // T
+constexpr int kInterpTaps = 8;       // T at most, and the width of a coefficient row (six taps sit in its middle)
 constexpr int kInterpMaxFactor = 1024;  // I = R / q at most: a lane's coefficient set is (4 (wave-task mod 4) .. + lane) & (I/4 - 1),
                                         // and a wave's wave-tasks stay in one class mod 4 (synthi.hip)
 #ifndef GCWT_SYNTHI_COLS
