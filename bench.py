@@ -797,7 +797,7 @@ def config2_leg(fs, freqs, dev, lib, check, no_check=False, steps=20, warmup=3):
                      "transform_plus_1s_slice_ms": round(float(np.median(t_slice[1:])) * 1e3, 2)}
         del cwt
     res["transform_end_to_end"] = dict(api, note="host array in, transform() and then the whole `amplitude` on the host (page-locked result from the pool of "
-                                            "ghost_amd.hostmem, float64 widened on the device); transform_returns_ms: the call alone (rows left on the "
+                                            "ghost_amd.hostmem, float64 sent as float32 and widened by host threads as it lands); transform_returns_ms: the call alone (rows left on the "
                                             "device); transform_plus_1s_slice_ms: transform() + fetch() of 1000 samples of every scale.  PCIe-inclusive: never the headline value")
     return res
 

@@ -3,8 +3,9 @@
 // result stays on the device after transform() and is brought over when -- and as far as -- it is asked for:
 //   * into page-locked memory (gcwt_host_alloc) the DMA engines write at the link's rate, no staging copy and no
 //     page faults (a fresh 856 MB NumPy array costs more in first-touch faults than the 428 MB cost on the wire);
-//   * float64 results are widened on the device (one pass at HBM rate) and cross the link as they are: no host
-//     thread touches them;
+//   * float64 results cross the link as float32 -- half the bytes -- and a standing pool of host threads widens each
+//     tile into the destination with streaming stores while the next tiles are on the wire (host_out.cpp); option
+//     host_widen = 0 widens on the device instead and sends float64 (17 against 10.5 ms for 800 MB on a 55 GB/s link);
 //   * any rectangle of (row, sample) goes by itself: rows `src_pitch` apart on the device, `dst_pitch` on the host.
 // Destinations that are not page-locked go through the plan-independent staging ring (host_out.cpp).
 #include <hip/hip_runtime.h>
@@ -14,6 +15,7 @@
 
 #include "host_out.h"
 #include "kernels.h"
+#include "options.h"
 
 namespace gcwt {
 
@@ -78,6 +80,8 @@ hipError_t rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, i
     if (e != hipSuccess) return e;
     return hipStreamSynchronize(s.stream);
   }
+  if (option_or("host_widen", 1) != 0)     // float32 over the link, widened by host threads (0: on the device, below)
+    return s.ring.drain(d_src, (size_t)src_pitch, (size_t)n_rows, (size_t)row_elems, dst, true, s.stream, (size_t)dst_pitch);
   // float64: chunks of whole rows (or pieces of one long row) widened into the staging buffer, then over the link;
   // the stream keeps widen(c + 1) behind copy(c), and a widening pass is a hundredth of its copy
   if (!s.d_stage) {

@@ -188,7 +188,7 @@ class ContinuousWaveletTransform(WaveletTransform):
         start_time = time.time()
         # The rows stay on the device (engine.DeviceResult); what the reference keeps as whole host arrays
         # (transforms.py:203-204, 496-527) is brought over by the first access to the attribute: into page-locked
-        # memory at the link's rate, float64 (the reference's dtype) widened on the device.
+        # memory at the link's rate; float64 (the reference's dtype) crosses as float32 and is widened as it lands.
         self._amplitude = self._power = self._coefficients = None
         self._device_result = self._plan.execute_resident(x, self._device_result)
         self._pending = (output, np.dtype(dtype), squeeze)

@@ -195,8 +195,8 @@ int gcwt_host_free(void* ptr);
 /* A rectangle of a device-resident result (gcwt_execute with GCWT_OUT_ON_DEVICE) to the host: n_rows rows of
  * row_elems float32 (complex results: two per sample), src_pitch elements apart on the device, to rows dst_pitch
  * elements apart in dst.  flags: GCWT_OUT_F64 -- dst is float64, the reference's result dtype (transforms.py:185,
- * 203-204), widened on the device; GCWT_HOST_PINNED -- dst is page-locked (else it goes through a pinned
- * staging ring and dst_pitch must equal row_elems).  What ContinuousWaveletTransform.amplitude does on first
+ * 203-204): float32 over the link, widened by a standing pool of host threads; GCWT_HOST_PINNED -- dst is
+ * page-locked (else it goes through a pinned staging ring and dst_pitch must equal row_elems).  What ContinuousWaveletTransform.amplitude does on first
  * access, and how any (scale, sample) range of a result is read without moving the rest (transforms.py:496-527). */
 int gcwt_rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, int64_t row_elems, void* dst,
                       int64_t dst_pitch, int flags);
