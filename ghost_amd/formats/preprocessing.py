@@ -10,7 +10,9 @@ Deliberate differences from the reference ("deviations"):
 * nelpy epochs are the cumulative sum of ``lengths`` (reference forgets the
   cumsum, :102-103);
 * ``n_signals=None`` on the decorator lets multi-signal input through, which the
-  multichannel extension of ``transform`` uses.
+  multichannel extension of ``transform`` uses;
+* timestamps the adapter makes itself are a regular grid: their one segment is known without the scan, and with
+  ``defer_abscissa=True`` the grid is handed on as a ``RegularGrid`` that becomes an array when somebody reads it.
 """
 import logging
 from functools import wraps
@@ -19,7 +21,7 @@ import numpy as np
 
 from ..utils import get_contiguous_segments
 
-__all__ = ["standardize_asa", "is_asa_like"]
+__all__ = ["standardize_asa", "is_asa_like", "RegularGrid"]
 
 _ASA_ATTRS = ("n_signals", "fs", "abscissa_vals", "lengths", "_data_colsig", "_data_rowsig")
 
@@ -29,8 +31,25 @@ def is_asa_like(obj):
     return all(hasattr(obj, a) for a in _ASA_ATTRS)
 
 
+class RegularGrid:
+    """Timestamps ``arange(n) / rate`` that nobody has asked for yet (``standardize_asa(defer_abscissa=True)``):
+    a callee that only keeps them for later -- ``ContinuousWaveletTransform.time`` -- need not pay for a million
+    divisions per call.  ``np.asarray(grid)`` makes them."""
+    __slots__ = ("n", "rate")
+
+    def __init__(self, n, rate):
+        self.n, self.rate = int(n), rate
+
+    def __len__(self):
+        return self.n
+
+    def __array__(self, dtype=None, copy=None):
+        t = np.arange(self.n, dtype=np.float64) / self.rate
+        return t if dtype is None else t.astype(dtype, copy=False)
+
+
 def standardize_asa(func=None, *, x, abscissa_vals=None, fs=None, n_signals=None,
-                    rowsig=None, class_method=None):
+                    rowsig=None, class_method=None, defer_abscissa=False):
     logger = logging.getLogger("ghost")
 
     if not isinstance(x, str):
@@ -109,9 +128,11 @@ def standardize_asa(func=None, *, x, abscissa_vals=None, fs=None, n_signals=None
                     kwargs[fs] = fs_in
                 if abscissa_vals is not None:
                     rate = 1 if fs_in is None else fs_in
-                    if t_in is None:
+                    generated = t_in is None
+                    if generated:
                         logger.info("'%s' not passed in; generating from data", abscissa_vals)
-                        t_in = np.arange(data_out.shape[0], dtype=np.float64) / rate
+                        t_in = (RegularGrid(data_out.shape[0], rate) if defer_abscissa
+                                else np.arange(data_out.shape[0], dtype=np.float64) / rate)
                     else:
                         if not isinstance(t_in, np.ndarray):
                             raise TypeError("Expected '{}' to be a numpy.ndarray but got {}"
@@ -127,9 +148,14 @@ def standardize_asa(func=None, *, x, abscissa_vals=None, fs=None, n_signals=None
                     if fs_in is None:
                         logging.warning("'%s' not passed in; assuming default of 1 Hz", fs)
                     kwargs[abscissa_vals] = t_in
-                    kwargs["epoch_bounds"] = get_contiguous_segments(
-                        t_in, step=1 / rate, assume_sorted=fs_in is None, index=True,
-                        inclusive=False)
+                    if generated and len(t_in) > 0:
+                        # a regular grid made here has no gaps: what get_contiguous_segments would find, without
+                        # the scan (sortedness test + two differences over every sample: 0.8 ms per million)
+                        kwargs["epoch_bounds"] = np.array([[0, len(t_in)]], dtype=int)
+                    else:
+                        kwargs["epoch_bounds"] = get_contiguous_segments(
+                            t_in, step=1 / rate, assume_sorted=fs_in is None, index=True,
+                            inclusive=False)
 
             if positional:
                 args = tuple(data_out if i == pos else a for i, a in enumerate(args))

@@ -89,9 +89,9 @@ class ContinuousWaveletTransform(WaveletTransform):
     _transform_one._public_name = _transform_any._public_name = "transform"
     # the reference decorates transform() itself (transforms.py:57-58)
     _transform_one = pre.standardize_asa(x="data", fs="fs", n_signals=1, class_method=True,
-                                         abscissa_vals="timestamps")(_transform_one)
+                                         abscissa_vals="timestamps", defer_abscissa=True)(_transform_one)
     _transform_any = pre.standardize_asa(x="data", fs="fs", n_signals=None, class_method=True,
-                                         abscissa_vals="timestamps")(_transform_any)
+                                         abscissa_vals="timestamps", defer_abscissa=True)(_transform_any)
 
     def _run(self, data, *, squeeze, timestamps=None, fs=None, freq_limits=None, freqs=None,
              voices_per_octave=None, parallel=None, verbose=None, output=None, dtype=None,
@@ -315,7 +315,7 @@ class ContinuousWaveletTransform(WaveletTransform):
             data = (data - data.mean()) / data.std()
         data = data[freq_slice, time_slice]
         mult, xlabel = scales[timescale]
-        timevec = np.array(self._time[time_slice], dtype=np.float64) * mult
+        timevec = np.array(self.time[time_slice], dtype=np.float64) * mult
         freqvec = self._frequencies[freq_slice]
         if flags["relative_time"]:
             if flags["center_time"]:
@@ -359,7 +359,7 @@ class ContinuousWaveletTransform(WaveletTransform):
 
     def _restrict_plot_time(self, limits):
         limits = np.atleast_1d(np.asarray(limits).squeeze())
-        tstart, tstop = np.searchsorted(self._time, limits)
+        tstart, tstop = np.searchsorted(self.time, limits)
         return slice(tstart, tstop)
 
     def _restrict_plot_freq(self, limits):
@@ -434,6 +434,8 @@ class ContinuousWaveletTransform(WaveletTransform):
 
     @property
     def time(self):
+        if isinstance(self._time, pre.RegularGrid):        # made by the adapter, not asked for until now
+            self._time = np.asarray(self._time)
         return self._time
 
     @time.setter
