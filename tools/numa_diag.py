@@ -29,3 +29,20 @@ for it in range(4):
     lib.gcwt_rows_to_host(src.ptr, 1000000, 100, 1000000, a.ctypes.data_as(C.c_void_p), 1000000, 16)
     dt = time.perf_counter() - t0
 print("D2H 400 MB into it: %.1f ms = %.1f GB/s" % (1e3 * dt, 0.4 / dt))
+# float64 through the staging ring (float32 over the link, widened by the worker pool), and the workers alone
+b = hostmem.empty((100, 1000000), np.float64)
+for it in range(3):
+    t0 = time.perf_counter()
+    lib.gcwt_rows_to_host(src.ptr, 1000000, 100, 1000000, b.ctypes.data_as(C.c_void_p), 1000000, 16 | 8)
+    dt = time.perf_counter() - t0
+print("D2H 400 MB widened into 800 MB: %.1f ms" % (1e3 * dt))
+from concurrent.futures import ThreadPoolExecutor
+a32 = np.asarray(a)
+def job(k, n=8):
+    r0, r1 = 100 * k // n, 100 * (k + 1) // n
+    b[r0:r1] = a32[r0:r1]
+with ThreadPoolExecutor(8) as ex:
+    for it in range(3):
+        t0 = time.perf_counter(); list(ex.map(job, range(8))); dt = time.perf_counter() - t0
+print("numpy widening alone, 8 threads, pinned -> pinned: %.1f ms = %.1f GB/s written" % (1e3 * dt, 0.8 / dt))
+print("threads of this process run on cpus:", sorted(os.sched_getaffinity(0))[:4], "... current cpu", os.sched_getcpu() if hasattr(os, "sched_getcpu") else "?")
