@@ -201,13 +201,12 @@ struct gcwt_plan {
   int last_batch_slots = 0;          // slots of the last batch that ran (gcwt_debug_precision_terms)
   int last_batch = 0, last_rows = 0;
   double last_pt = 0;
-  // scales made again by the exact paths: one sub-plan (precision = exact, those scales only) per set of scales,
-  // its dense result scattered into this plan's rows
-  struct SubPlan { gcwt_plan* plan = nullptr; int32_t* d_rows = nullptr; uint64_t used = 0; };
-  uint64_t sub_clock = 0;            // (at most kMaxSubPlans are kept: the least recently used one goes)
-  std::map<std::vector<int32_t>, SubPlan> sub_plans;   // key: the scales, then the sub-plan's channel count (all, or 1)
-  float* d_sub_out = nullptr;
-  size_t d_sub_out_bytes = 0;
+  // scales made again by the exact paths: a sub-plan with precision = exact over ALL the scales, for every channel [0] or
+  // for one [1], made on first need; a run of it is masked to the scales wanted and writes straight into this plan's rows
+  gcwt_plan* sub_plan[2] = {nullptr, nullptr};
+  // a masked run (this plan IS such a sub-plan): run_mask[scale] != 0 -> make the row; nothing else is touched
+  const unsigned char* run_mask = nullptr;
+  unsigned char* d_run_mask = nullptr;
   // Small device-resident executes are launch-bound (config 1: fifteen kernels of a few microseconds each): the
   // second execute with the same arguments is captured into a graph, later ones replay it
   struct GraphKey {
@@ -247,13 +246,9 @@ void free_dev(gcwt_plan* p) {
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
   if (p->h_pred) { (void)hipHostFree(p->h_pred); p->h_pred = nullptr; }
-  fr(p->d_hist); fr(p->d_pred); fr(p->d_scale_level); fr(p->d_scale_length); fr(p->d_sub_out);
-  p->d_sub_out_bytes = 0;
-  for (auto& kv : p->sub_plans) {
-    if (kv.second.d_rows) (void)hipFree(kv.second.d_rows);
-    if (kv.second.plan) gcwt_plan_destroy(kv.second.plan);
-  }
-  p->sub_plans.clear();
+  fr(p->d_hist); fr(p->d_pred); fr(p->d_scale_level); fr(p->d_scale_length); fr(p->d_run_mask);
+  for (gcwt_plan*& sub : p->sub_plan)
+    if (sub) { gcwt_plan_destroy(sub); sub = nullptr; }
   for (auto& kv : p->hfull_cache) (void)hipFree(kv.second);
   p->hfull_cache.clear();
   p->hfull_cache_bytes = 0;
@@ -994,8 +989,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
   }
 
   // samples outside every epoch are zero (transforms.py:185): one launch per gap, or one
-  // fill of the whole result when there are many of them
-  {
+  // fill of the whole result when there are many of them (a masked run writes into rows that are finished but for
+  // the marked scales: their gaps are zero already)
+  const unsigned char* const hmask = p->run_mask;
+  const unsigned char* const dmask = hmask ? p->d_run_mask : nullptr;
+  if (!hmask) {
     std::vector<std::pair<int64_t, int64_t>> eps, gaps;
     for (size_t i = 0; i + 1 < hp.bounds.size(); i += 2) eps.push_back({hp.bounds[i], hp.bounds[i + 1]});
     std::sort(eps.begin(), eps.end());
@@ -1017,7 +1015,12 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     }
   }
 
-  const bool any_fft = hp.n_direct + hp.n_blockconv < S;
+  bool any_fft = hp.n_direct + hp.n_blockconv < S;
+  if (hmask) {                       // a masked run needs the spectrum only for a marked scale that reads it
+    any_fft = false;
+    for (int i = 0; i < S; ++i)
+      any_fft = any_fft || (hmask[i] && hp.scales[i].method != GCWT_SCALE_DIRECT && hp.scales[i].method != GCWT_SCALE_BLOCKCONV);
+  }
   const bool fast_fft = p->fast_fft;
   for (size_t e0 = 0; any_fft && e0 < hp.epochs.size();) {
     // one batch: segments e0 .. e0 + count - 1 share the FFT length and the level grids;
@@ -1370,7 +1373,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     for (int i = 0; i < S && hp.n_fullband > 0;) {
       int member[kFullbandSet], np = 0;
       for (; i < S && np < p->z_sets; ++i)
-        if (hp.scales[i].method == GCWT_SCALE_FULLBAND) member[np++] = i;
+        if (hp.scales[i].method == GCWT_SCALE_FULLBAND && (!hmask || hmask[i])) member[np++] = i;
       if (np == 0) break;
       FullbandSet set{};
       set.n = np;
@@ -1397,14 +1400,19 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       }
     }
   }
-  if (hp.n_direct > 0) {
+  bool direct_wanted = hp.n_direct > 0;
+  if (hmask) {
+    direct_wanted = false;
+    for (int i = 0; i < S; ++i) direct_wanted = direct_wanted || (hmask[i] && hp.scales[i].method == GCWT_SCALE_DIRECT);
+  }
+  if (direct_wanted) {
     DirectEpochs eps{};
     eps.n_channels = C;
     int ne = 0;
     auto flush = [&]() -> int {
       if (ne > 0)
         RUN(ST_DIRECT, launch_direct(mode, dx, dout, p->d_psi, p->d_direct_sc, hp.n_direct, p->d_sums,
-                                     inv_n, N, S, eps, ne, r0, row_len, p->max_direct_len, p->d_psi_tail, st));
+                                     inv_n, N, S, eps, ne, r0, row_len, p->max_direct_len, p->d_psi_tail, st, dmask));
       ne = 0;
       return GCWT_OK;
     };
@@ -1426,6 +1434,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     // block convolution: per group of scales, per batch of epochs, per chunk of blocks -- the blocks' spectra,
     // then every scale of the group from them
     for (const HostPlan::BcGroup& g : hp.bc_groups) {
+      if (hmask) {                     // masked run: a group none of whose scales is marked makes no block spectra either
+        bool wanted = false;
+        for (int k = g.first; k < g.first + g.count; ++k) wanted = wanted || hmask[hp.bc_order[(size_t)k]];
+        if (!wanted) continue;
+      }
       BcBlocks bl{};
       bl.n_channels = C;
       bl.hop = g.hop;
@@ -1441,7 +1454,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
           RUN(ST_BLOCKCONV, launch_bc_forward(dx, p->d_bc_x, bl, b0, nblk, N, p->d_tw64, p->d_sums, inv_n, st));
           RUN(ST_BLOCKCONV, launch_bc_scales(mode, p->d_bc_x, dout, p->d_bc_h + (int64_t)g.first * kRowLen,
                                              p->d_bc_rows + g.first, g.count, p->d_bc_tw, p->d_tw256, bl, b0, nblk,
-                                             S, r0, row_len, st));
+                                             S, r0, row_len, st, dmask));
         }
         ne = 0;
         return GCWT_OK;
@@ -1478,62 +1491,47 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params);
 // copied over the fast path's.  The sub-plan computes its own channel means (same numbers: same kernel, same x).
 static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t out_r0, int64_t r0, int64_t r1, int64_t row_len,
                           const std::vector<int32_t>& over, int channel) {
-  // channel >= 0: that channel alone, by a one-channel sub-plan (a recording with one bad electrode pays for one)
+  // channel >= 0: that channel alone, by the one-channel sub-plan (a recording with one bad electrode pays for one).
+  // The sub-plans hold every scale and a run is masked to `over`: whatever the verdicts of a recording's segments
+  // are -- every epoch its own set -- two plans serve them all, and a scale's numbers do not depend on the set it
+  // is asked for in (a plan per set cost 35 ms each time a set came back after four others).
   const HostPlan& hp = p->hp;
+  const int S = hp.prm.n_freqs;
   const int nch = channel >= 0 ? 1 : hp.prm.n_channels;
-  std::vector<int32_t> key = over;
-  key.push_back(nch);
-  constexpr size_t kMaxSubPlans = 4;      // each holds an exact plan's workspace (GBs at the headline shape)
-  if (!p->sub_plans.count(key) && p->sub_plans.size() >= kMaxSubPlans) {
-    auto lru = p->sub_plans.begin();
-    for (auto it = p->sub_plans.begin(); it != p->sub_plans.end(); ++it)
-      if (it->second.used < lru->second.used) lru = it;
-    if (lru->second.d_rows) (void)hipFree(lru->second.d_rows);
-    if (lru->second.plan) gcwt_plan_destroy(lru->second.plan);
-    p->sub_plans.erase(lru);
-  }
-  gcwt_plan::SubPlan& sp = p->sub_plans[key];
-  sp.used = ++p->sub_clock;
-  if (!sp.plan) {
-    std::vector<double> f(over.size());
-    for (size_t i = 0; i < over.size(); ++i) f[i] = hp.freqs[(size_t)over[i]];
+  gcwt_plan*& sub = p->sub_plan[channel >= 0 ? 1 : 0];
+  if (!sub) {
+    std::vector<double> f(hp.freqs.begin(), hp.freqs.end());
     gcwt_params prm = hp.prm;
     prm.freqs_hz = f.data();
     prm.n_freqs = (int32_t)f.size();
     prm.n_channels = nch;
     prm.precision = GCWT_PRECISION_EXACT;
     prm.device = p->device;
-    int rc = gcwt_plan_create_impl(&sp.plan, &prm);
-    if (rc) { p->sub_plans.erase(key); return rc; }
-    if ((rc = gcwt_plan_upload(sp.plan))) { gcwt_plan_destroy(sp.plan); p->sub_plans.erase(key); return rc; }
-    if (hipMalloc((void**)&sp.d_rows, sizeof(int32_t) * over.size()) != hipSuccess ||
-        hipMemcpy(sp.d_rows, over.data(), sizeof(int32_t) * over.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    int rc = gcwt_plan_create_impl(&sub, &prm);
+    if (rc) { sub = nullptr; return rc; }
+    const HostPlan& sh = sub->hp;
+    if ((int)sh.scales.size() != S || sh.n_direct + sh.n_blockconv + sh.n_fullband != S) {
+      gcwt_plan_destroy(sub); sub = nullptr;
+      return set_err(GCWT_ERR_INVALID, "internal: the exact sub-plan keeps a decimated scale");
+    }
+    if ((rc = gcwt_plan_upload(sub))) { gcwt_plan_destroy(sub); sub = nullptr; return rc; }
+    if (hipMalloc((void**)&sub->d_run_mask, (size_t)S) != hipSuccess) {
       (void)hipGetLastError();
-      gcwt_plan_destroy(sp.plan);
-      if (sp.d_rows) (void)hipFree(sp.d_rows);
-      p->sub_plans.erase(key);
-      return set_err(GCWT_ERR_NOMEM, "no device memory for the rerouted scales' row list");
+      gcwt_plan_destroy(sub); sub = nullptr;
+      return set_err(GCWT_ERR_NOMEM, "no device memory for the rerouted scales' mask");
     }
   }
-  const int64_t n_out = r1 - r0;
-  const int64_t pitch = (n_out + 31) & ~(int64_t)31;
+  std::vector<unsigned char> mask((size_t)S, 0);
+  for (int32_t i : over) mask[(size_t)i] = 1;
+  HIP_TRY(hipMemcpy(sub->d_run_mask, mask.data(), (size_t)S, hipMemcpyHostToDevice));
   const int elem = hp.out_elem_bytes / (int)sizeof(float);
-  const size_t need = sizeof(float) * (size_t)elem * (size_t)pitch * over.size() * (size_t)nch;
-  if (p->d_sub_out_bytes < need) {
-    if (p->d_sub_out) { (void)hipFree(p->d_sub_out); p->d_sub_out = nullptr; p->d_sub_out_bytes = 0; }
-    HIP_TRY(hipMalloc((void**)&p->d_sub_out, need));
-    p->d_sub_out_bytes = need;
-  }
-  sp.plan->row_pitch = pitch;
   const int64_t ch0 = channel >= 0 ? channel : 0;
-  int rc = execute_range(sp.plan, dx + ch0 * hp.prm.n_samples, p->d_sub_out, r0, r1, GCWT_X_ON_DEVICE | GCWT_OUT_ON_DEVICE);
-  if (rc) return rc;
-  float* dst = dout + (ch0 * hp.prm.n_freqs * row_len + (r0 - out_r0)) * elem;
-  hipError_t he = launch_scatter_rows(p->d_sub_out, dst, sp.d_rows, (int)over.size(), hp.prm.n_freqs, nch, n_out * elem,
-                                      pitch * elem, row_len * elem, p->stream);
-  if (he != hipSuccess) return hip_err(he, "launch_scatter_rows");
-  HIP_TRY(hipStreamSynchronize(p->stream));
-  return GCWT_OK;
+  float* dst = dout + (ch0 * S * row_len + (r0 - out_r0)) * elem;
+  sub->row_pitch = row_len;
+  sub->run_mask = mask.data();
+  const int rc = execute_range(sub, dx + ch0 * hp.prm.n_samples, dst, r0, r1, GCWT_X_ON_DEVICE | GCWT_OUT_ON_DEVICE);
+  sub->run_mask = nullptr;
+  return rc;
 }
 
 static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int64_t r1, int flags) {
@@ -1586,7 +1584,7 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
   // graph replay: device in and out, nothing to time, no full-band scale (its response cache allocates on the way),
   // and a result small enough for the launches to matter (16 M coefficients)
   const bool graphable = !p->graph_failed && !p->profiling && (flags & GCWT_X_ON_DEVICE) && (flags & GCWT_OUT_ON_DEVICE) &&
-                         hp.n_fullband == 0 && p->use_graphs &&
+                         hp.n_fullband == 0 && p->use_graphs && !p->run_mask &&
                          (int64_t)rows * n_out <= ((int64_t)1 << 24);
   const gcwt_plan::GraphKey key{dx, dout, r0, r1, row_len, reuse};
   bool done = false;

@@ -165,22 +165,6 @@ __global__ void __launch_bounds__(256) k_precision_predict(const float* __restri
   }
 }
 
-__global__ void __launch_bounds__(256) k_scatter_rows(const float* __restrict__ src, float* __restrict__ dst,
-                                                      const int32_t* __restrict__ rows, int n_sub, int n_scales,
-                                                      int64_t row_elems, int64_t src_pitch, int64_t dst_pitch, int vec) {
-  const int i = blockIdx.y % n_sub, ch = blockIdx.y / n_sub;
-  const float* s = src + ((int64_t)ch * n_sub + i) * src_pitch;
-  float* d = dst + ((int64_t)ch * n_scales + rows[i]) * dst_pitch;
-  const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (vec) {                                                     // both pitches and both bases are multiples of 16 bytes
-    const int64_t n4 = row_elems >> 2;
-    for (int64_t k = t0; k < n4; k += stride) reinterpret_cast<float4*>(d)[k] = reinterpret_cast<const float4*>(s)[k];
-    for (int64_t k = (n4 << 2) + t0; k < row_elems; k += stride) d[k] = s[k];
-  } else {
-    for (int64_t k = t0; k < row_elems; k += stride) d[k] = s[k];
-  }
-}
-
 hipError_t launch_spectrum_bands(const float2* x, int64_t x_cstride, int p1, float* hist, int n_slots, hipStream_t st) {
   if (n_slots <= 0 || p1 <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_spectrum_bands, dim3((unsigned)p1, (unsigned)n_slots), dim3(256), 0, st, x, x_cstride, p1, hist);
@@ -195,23 +179,6 @@ hipError_t launch_precision_predict(const float* hist, int n_rows, const float* 
   hipLaunchKernelGGL(k_precision_predict, dim3(n_slots, n_levels), dim3(256), 0, st, hist, n_rows, gain, scale_level, scale_length, levels, n_scales,
                      n_levels, (float)p_true, kappa_eps, oob_tol, pred, dbg_level, dbg_scale, segs);
   return hipGetLastError();
-}
-
-hipError_t launch_scatter_rows(const float* src, float* dst, const int32_t* rows, int n_sub, int n_scales,
-                               int n_channels, int64_t row_elems, int64_t src_pitch, int64_t dst_pitch, hipStream_t st) {
-  if (n_sub <= 0 || n_channels <= 0 || row_elems <= 0) return hipSuccess;
-  const int vec = !((src_pitch | dst_pitch) & 3) && !((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15);
-  const unsigned gx = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (row_elems / 4 + 255) / 256));
-  for (int c0 = 0; c0 < n_channels;) {                           // (grid.y is 16 bits wide)
-    const int nc = std::min(n_channels - c0, std::max(1, 65535 / n_sub));
-    hipLaunchKernelGGL(k_scatter_rows, dim3(gx, (unsigned)(n_sub * nc)), dim3(256), 0, st,
-                       src + (int64_t)c0 * n_sub * src_pitch, dst + (int64_t)c0 * n_scales * dst_pitch, rows, n_sub,
-                       n_scales, row_elems, src_pitch, dst_pitch, vec);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    c0 += nc;
-  }
-  return hipSuccess;
 }
 
 }  // namespace gcwt

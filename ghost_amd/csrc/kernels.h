@@ -338,9 +338,6 @@ hipError_t launch_precision_predict(const float* hist, int n_rows, const float* 
                                     const int32_t* scale_length, const PredLevel* levels, int n_scales, int n_levels, double p_true,
                                     float kappa_eps, float oob_tol, float* pred, float* dbg_level, float* dbg_scale,
                                     int n_slots, const PredSegs& segs, hipStream_t st);
-// rows of a sub-plan's dense result [C][n_sub][row_len] into rows `rows[i]` of the full one [C][n_scales][row_len]
-hipError_t launch_scatter_rows(const float* src, float* dst, const int32_t* rows, int n_sub, int n_scales,
-                               int n_channels, int64_t row_elems, int64_t src_pitch, int64_t dst_pitch, hipStream_t st);
 // shifted band of a level: Xs[k1][j2] = X[k1 + P1 (j2 - u2)] from the positive half of a real signal's
 // k1-major spectrum (kernels.hip: k_shift_gather)
 hipError_t launch_shift_gather(const float2* x, float2* xs, int p1, int q, int u2, int64_t x_row,
@@ -360,7 +357,8 @@ struct DirectEpochs {                // time-domain scales: epochs handled by on
 hipError_t launch_direct(int mode, const float* x, float* out, const float2* psi,
                          const DirectScale* sc, int n_direct, const double* sums, double inv_n,
                          int64_t n_samples, int n_scales, const DirectEpochs& eps, int n_epochs,
-                         int64_t col0, int64_t row_len, int64_t max_len, const float2* tail, hipStream_t st);
+                         int64_t col0, int64_t row_len, int64_t max_len, const float2* tail, hipStream_t st,
+                         const unsigned char* mask = nullptr);   // mask[scale row]: 0 = leave the row alone
 // Block convolution (overlap-save; kernels.hip: k_bc_scales and fwd64.hip: k_bc_forward describe the path): the blocks of up to kSegBatch epochs that
 // one launch handles.  Blocks are `hop` samples long and aligned to multiples of `hop` in recording time; block
 // q of an epoch produces samples [q hop, (q + 1) hop) cut to [g_lo, g_hi) from the 4096 recording samples that
@@ -384,7 +382,8 @@ hipError_t launch_bc_forward(const float* x, float2* xb, const BcBlocks& bl, int
 // rows[s] the output rows, twt[256 j + 16 t + a] = exp(+2 pi i (t + 16 j) a / 4096)
 hipError_t launch_bc_scales(int mode, const float2* xb, float* out, const float2* h, const int32_t* rows,
                             int n_group_scales, const float2* twt, const float2* tw256, const BcBlocks& bl,
-                            int blk0, int nblk, int n_scales, int64_t col0, int64_t row_len, hipStream_t st);
+                            int blk0, int nblk, int n_scales, int64_t col0, int64_t row_len, hipStream_t st,
+                            const unsigned char* mask = nullptr);
 hipError_t launch_level_small(const float2* x, float2* xr, int n1, int q, int64_t p1_stride,
                               int64_t x_cstride, int64_t xr_cstride, const float2* tw4096,
                               int n_channels, hipStream_t st, RowTaper taper = RowTaper());

@@ -987,7 +987,8 @@ __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb,
                                                    const cf* __restrict__ h, const int32_t* __restrict__ rows,
                                                    int n_group_scales, const cf* __restrict__ twt,
                                                    const cf* __restrict__ tw256, const BcBlocks bl, int blk0,
-                                                   int n_scales, int64_t col0, int64_t row_len) {
+                                                   int n_scales, int64_t col0, int64_t row_len,
+                                                   const unsigned char* __restrict__ mask) {
   // twt[256 j + tid] = W_4096^(+(t + 16 j) a): the middle twiddles in the order the threads meet them
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) cf buf[16 * kExColD];
@@ -1029,6 +1030,7 @@ __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb,
   // written with float2 operators the loop spent a quarter of its instructions on moves); it leaves output k in
   // register dft16_pos(k).
   for (int s = 0; s < n_group_scales; ++s) {
+    if (mask && !mask[rows[s]]) continue;   // masked run: the marked rows only (workgroup-uniform)
     const v2f* __restrict__ hs = reinterpret_cast<const v2f*>(h) + (int64_t)s * kRowLenDev + at;
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = cmulv(xv[j], hs[256 * j]);
@@ -1421,7 +1423,8 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
                                                 const double* __restrict__ sums, double inv_n,
                                                 int64_t n_samples, int n_scales,
                                                 const DirectEpochs eps, int64_t col0,
-                                                int64_t row_len, int halo, const cf* __restrict__ tail) {
+                                                int64_t row_len, int halo, const cf* __restrict__ tail,
+                                                const unsigned char* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kElem = MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1;
   constexpr int kStageWave = 512 * kElem + 32 * kElem;        // floats of one wave's transposition area
@@ -1454,6 +1457,7 @@ __global__ void __launch_bounds__(256) k_direct(const float* __restrict__ x, flo
   const int64_t wave_left = (eps.g_hi[e] - g0 - 512 * wave) * kElem;    // floats of this wave inside the range
   for (int d = 0; d < n_direct; ++d) {
     const DirectScale p = sc[d];
+    if (mask && !mask[p.scale]) continue;        // a masked run (api.cpp: reroute_scales) makes the marked rows only
     const cf* taps = psi + p.offset;
     const int top = (int)((p.length - 1) / 2) + p.front;            // = 7 (mod 8)
     const int n_groups = (int)((p.length + p.front + 7) >> 3);
@@ -1924,7 +1928,8 @@ hipError_t launch_fullband_cols(int mode, const cf* z, float* out, int p1, int64
 
 hipError_t launch_bc_scales(int mode, const cf* xb, float* out, const cf* h, const int32_t* rows,
                             int n_group_scales, const cf* twt, const cf* tw256, const BcBlocks& bl, int blk0,
-                            int nblk, int n_scales, int64_t col0, int64_t row_len, hipStream_t st) {
+                            int nblk, int n_scales, int64_t col0, int64_t row_len, hipStream_t st,
+                            const unsigned char* mask) {
   if (nblk <= 0 || n_group_scales <= 0) return hipSuccess;
   if (bl.n_epochs < 1 || bl.n_epochs > kSegBatch || bl.hop < 1 || bl.back < 0 || bl.hop + bl.back > kRowLenDev ||
       blk0 < 0 || blk0 + nblk > bl.blk_first[bl.n_epochs] || (int64_t)nblk * bl.n_channels > 0x7fffffff)
@@ -1932,7 +1937,7 @@ hipError_t launch_bc_scales(int mode, const cf* xb, float* out, const cf* h, con
   const dim3 grid((unsigned)(nblk * bl.n_channels)), block(256);
 #define GCWT_BC(M)                                                                                        \
   hipLaunchKernelGGL((k_bc_scales<M>), grid, block, 0, st, xb, out, h, rows, n_group_scales, twt, tw256, \
-                     bl, blk0, n_scales, col0, row_len)
+                     bl, blk0, n_scales, col0, row_len, mask)
   if (mode == GCWT_OUT_AMPLITUDE_F32) GCWT_BC(GCWT_OUT_AMPLITUDE_F32);
   else if (mode == GCWT_OUT_POWER_F32) GCWT_BC(GCWT_OUT_POWER_F32);
   else GCWT_BC(GCWT_OUT_COMPLEX_C64);
@@ -1966,7 +1971,8 @@ hipError_t launch_synth(int mode, const SynthArgs& a, int n_items, int n_channel
 hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, const DirectScale* sc,
                          int n_direct, const double* sums, double inv_n, int64_t n_samples,
                          int n_scales, const DirectEpochs& eps, int n_epochs, int64_t col0,
-                         int64_t row_len, int64_t max_len, const cf* tail, hipStream_t st) {
+                         int64_t row_len, int64_t max_len, const cf* tail, hipStream_t st,
+                         const unsigned char* mask) {
   int64_t longest = 0;
   for (int e = 0; e < n_epochs; ++e) longest = std::max(longest, eps.g_hi[e] - eps.g_lo[e]);
   if (n_direct == 0 || n_epochs == 0 || longest <= 0) return hipSuccess;
@@ -1979,7 +1985,7 @@ hipError_t launch_direct(int mode, const float* x, float* out, const cf* psi, co
   dim3 grid((unsigned)((longest + kDirectTile - 1) / kDirectTile), 1, eps.n_channels * n_epochs), block(256);
 #define GCWT_DIRECT(M)                                                                       \
   hipLaunchKernelGGL((k_direct<M>), grid, block, lds, st, x, out, psi, sc, n_direct, sums,   \
-                     inv_n, n_samples, n_scales, eps, col0, row_len, halo, tail)
+                     inv_n, n_samples, n_scales, eps, col0, row_len, halo, tail, mask)
   if (mode == GCWT_OUT_AMPLITUDE_F32) GCWT_DIRECT(GCWT_OUT_AMPLITUDE_F32);
   else if (mode == GCWT_OUT_POWER_F32) GCWT_DIRECT(GCWT_OUT_POWER_F32);
   else GCWT_DIRECT(GCWT_OUT_COMPLEX_C64);

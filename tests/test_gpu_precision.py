@@ -459,9 +459,9 @@ def test_explicit_high_precision_only_warns(caplog, option):
 
 
 def test_rerouted_scale_sets_come_and_go():
-    """One plan, six recordings with a line in six different places: six different sets of scales to make again.  A
-    plan keeps the exact sub-plans of the four sets used last (each holds an exact plan's workspace); the fifth and
-    sixth push the oldest out, and going back to the first set builds it again -- every result within the gate."""
+    """One plan, six recordings with a line in six different places: six different sets of scales to make again, all
+    by one exact sub-plan that holds every scale and runs masked to the set wanted (a scale's numbers do not depend on
+    the set it is asked for in) -- every result within the gate, the first recording's bits back when it returns."""
     from ghost_amd.engine import CwtPlan
     from ghost_amd.synthetic import lfp_channel
     fs, n = 1000.0, 60000
@@ -470,7 +470,7 @@ def test_rerouted_scale_sets_come_and_go():
     t = np.arange(n) / fs
     win = np.sin(np.pi * np.arange(n) / n) ** 2
     p = CwtPlan(n, 1, fs, f)
-    sets = []
+    sets, first = [], None
     for hz in (150.0, 90.0, 55.0, 33.0, 19.0, 11.0, 150.0):
         x = (base + 300.0 * base.std() * win * np.sin(2 * np.pi * hz * t)).astype(np.float32)
         got = p.execute(x[None])[0]
@@ -478,8 +478,57 @@ def test_rerouted_scale_sets_come_and_go():
         assert rep["rerouted"] > 0
         sets.append(tuple(np.nonzero(rep["predicted"] > 1.5e-6)[0]))
         assert rel_err(got, orc.cwt_amplitude(x.astype(np.float64), fs, f)).max() < TOL, hz
+        if first is None:
+            first = got.copy()
     assert len(set(sets)) >= 5 and sets[0] == sets[-1]
+    np.testing.assert_array_equal(got, first)
     p.close()
+
+
+def test_every_epoch_its_own_verdict():
+    """Ten epochs, the mains line 3 .. 300 x the spread in a different strength on each (and absent from two): the
+    segments' verdicts differ, each epoch's marked scales are made again for its own samples by masked runs of the one
+    sub-plan, epochs without a verdict keep the fast path's bits, a block request across epoch borders gives the whole
+    transform's numbers, and a later execute costs no more than a few times precision='high' (a sub-plan per set of
+    scales took 300 ms here: 12 sets, 4 kept)."""
+    import time
+    from ghost_amd.engine import CwtPlan, DeviceBuffer
+    from ghost_amd.synthetic import lfp_channel
+    fs, n, n_ep = 1000.0, 400000, 10
+    f = np.geomspace(200.0, 2.0, 60)
+    t = np.arange(n) / fs
+    rng = np.random.default_rng(11)
+    x = np.stack([lfp_channel(n, fs, 30 + c) for c in range(2)]).astype(np.float64)
+    amp = np.zeros(n)
+    edges = np.linspace(0, n, n_ep + 1).astype(int)
+    for k in range(n_ep):
+        amp[edges[k]:edges[k + 1]] = 0.0 if k in (3, 7) else 3.0 * 100.0 ** rng.random()
+    x = (x + (x.std() * amp * np.sin(2 * np.pi * 60.0 * t))[None]).astype(np.float32)
+    eb = [[int(a) + 3, int(b)] for a, b in zip(edges[:-1], edges[1:])]
+    ph = CwtPlan(n, 2, fs, f, epoch_bounds=eb, precision="high")
+    high = ph.execute(x)
+    p = CwtPlan(n, 2, fs, f, epoch_bounds=eb)
+    got = p.execute(x)
+    assert p.precision_report()["rerouted"] > 0
+    for ch in range(2):
+        ref = orc.cwt_amplitude(x[ch].astype(np.float64), fs, f, epoch_bounds=eb, n_threads=8)
+        assert rel_err(got[ch], ref).max() < TOL, ch
+    for k in (3, 7):                                   # no line there: nothing made again
+        np.testing.assert_array_equal(got[:, :, eb[k][0] + 3000:eb[k][1] - 3000], high[:, :, eb[k][0] + 3000:eb[k][1] - 3000])
+    assert not np.array_equal(got, high)
+    blk = p.execute_block(x, 100001, 150002)
+    np.testing.assert_array_equal(blk, got[:, :, 100001:250003])
+    xb = DeviceBuffer(x.nbytes); xb.upload(x)
+    ob = DeviceBuffer(p.info["out_bytes"])
+    times = {}
+    for name, plan in (("high", ph), ("auto", p)):
+        plan.execute_device(xb, ob)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            plan.execute_device(xb, ob)
+        times[name] = (time.perf_counter() - t0) / 3
+    assert times["auto"] < 25 * times["high"], times
+    xb.free(); ob.free(); p.close(); ph.close()
 
 
 def test_public_call_float64_input_with_a_huge_offset():

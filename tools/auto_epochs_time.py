@@ -10,7 +10,14 @@ f = np.geomspace(200.0, 2.0, 100)
 t = np.arange(n) / fs
 rng = np.random.default_rng(3)
 x = np.stack([lfp_channel(n, fs, 20 + c) for c in range(C)]).astype(np.float64)
-x += (100.0 * x.std() * (1.0 + 0.5 * np.sin(2 * np.pi * t / 97.0)) * np.sin(2 * np.pi * 60.0 * t))[None]
+import os
+if os.environ.get("AE_VARY"):       # the line's strength differs from epoch to epoch: 3 .. 300 x the spread (other verdicts per epoch)
+    amp = np.zeros(n)
+    for k in range(n_ep):
+        amp[n * k // n_ep: n * (k + 1) // n_ep] = 3.0 * 100.0 ** (rng.random())
+else:
+    amp = 100.0 * (1.0 + 0.5 * np.sin(2 * np.pi * t / 97.0))
+x += (x.std() * amp * np.sin(2 * np.pi * 60.0 * t))[None]
 x = x.astype(np.float32)
 edges = np.linspace(0, n, n_ep + 1).astype(int)
 eb = [[int(a) + 5, int(b)] for a, b in zip(edges[:-1], edges[1:])]
