@@ -110,6 +110,7 @@ struct gcwt_plan {
   bool use_synthp = false;    // option synthp = 1: q = 2 levels with I <= 256 go to the pipelined kernel (synthp.hip); it
                               // ties with k_synthi on the headline and loses at R = 8 (profiles/r05_synth_study.md): off
   bool use_graphs = true;     // option graphs: small device-resident executes are replayed as a HIP graph
+  bool fullband4 = true;      // option fullband4 = 0: 16 384-point segments by the two-pass kernels (A/B, tests)
   int fullband_group = 0;     // option fullband_group: rows per group of the fused full-band row pass (0: the kernel's default)
   int64_t fullband_cache_cap = 0;   // bytes of full-band responses kept across executes (set at upload: option
                                     // fullband_cache_mb, else a quarter of the memory free then, at most 16 GiB)
@@ -428,6 +429,7 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->kappa_eps = 1e-9f * (float)option_or("auto_kappa_ppb", 160);
   p->oob_tol = 1e-12f * (float)option_or("auto_oob_ppt", 25000);
   p->fullband_group = (int)option_or("fullband_group", 0);
+  p->fullband4 = option_or("fullband4", 1) != 0;
   p->synth_kernel = kMeasureBuild && option_or("synth_kernel", 7) == 8 ? 8 : 7;
   p->drop_stores = kMeasureBuild && option_is_set("synth_drop_stores") ? (int)std::max<long long>(1, option_or("synth_drop_stores", 1)) : 0;
   p->clock_probe = kMeasureBuild && option_is_set("clock_probe");
@@ -1381,6 +1383,14 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         set.z[k] = p->d_z + (int64_t)k * p->z_half;
         const int rc_ = response(member[k], k, &set.h[k]);
         if (rc_) return rc_;
+      }
+      if (P1 == 4 && p->fullband4) {       // time blocks of 16 384 samples: both passes in one kernel, no z
+        const float2* hh[kFullbandSet];
+        int32_t rows_[kFullbandSet];
+        for (int k = 0; k < np; ++k) { hh[k] = set.h[k]; rows_[k] = member[k]; }
+        RUN(ST_FULLBAND, launch_fullband4(mode, p->d_x, hh, rows_, np, dout, P, p->d_bc_tw, p->d_tw256, S, row_len, sout,
+                                          slots, st));
+        continue;
       }
       // inverse: rows over k2 of the products X H with the W_P^(k1 n2) twiddle, then columns over k1 ->
       // natural order; the usual FFT lengths store from the column pass's registers (2.9 GB of traffic per

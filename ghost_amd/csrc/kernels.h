@@ -264,6 +264,11 @@ hipError_t launch_fullband_rows(const float2* x, const FullbandSet& set, int p1,
                                 const float2* twt, const float2* tw256, int n_slots, hipStream_t st,
                                 int group = 0);
 bool fullband_cols_fused(int p1);
+// P = 4 x 4096: both passes fused (kernels.hip: k_fullband4); up to kFullband4Scales scales per launch
+constexpr int kFullband4Scales = 8;
+hipError_t launch_fullband4(int mode, const float2* x, const float2* const* h, const int32_t* scales, int n, float* out,
+                            int64_t x_cstride, const float2* twt, const float2* tw256, int n_scales, int64_t row_len,
+                            const SegOut& seg, int n_slots, hipStream_t st);
 hipError_t launch_fullband_cols(int mode, const float2* z, float* out, int p1, int64_t z_cstride,
                                 const float2* tw4096, const float2* tw256, int scale, int n_scales,
                                 int64_t row_len, const SegOut& seg, int n_slots, hipStream_t st);

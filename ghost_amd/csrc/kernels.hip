@@ -876,6 +876,18 @@ __global__ void __launch_bounds__(256, 2) k_fullband_rows(const cf* __restrict__
   }
 }
 
+// P = 4 x 4096 (time blocks of 16 384 samples: kernels of 1 - 5 K taps under precision = exact, planner.h): both passes
+// in one workgroup.  The four rows k1 of a slot go through k_fullband_rows' arithmetic one after the other -- product
+// with the scale's response, 4096-point inverse transform, W_P^(k1 n2) -- and stay in registers; a DFT4 over k1
+// finishes the column pass for the thread's sixteen n2, and the samples go to the scale's row through the sink below.
+// HBM sees the slot's spectrum (128 KB, again per scale: L2 mostly) and the result: no z buffer, no column pass, no
+// store pass (40 -> 11 bytes per point).  grid (slots, sets of scales)
+struct Fullband4Set {
+  const cf* h[kFullband4Scales];       // responses on the 16 384-point grid, k1-major like one slot of x
+  int32_t scale[kFullband4Scales];     // their output rows
+  int32_t n, pad;
+};
+
 // Pass 2 stores what the column transform leaves in registers: sample n = k ld + column of the slot's
 // segment, cropped to the segment's window, as |.|, |.|^2 or the complex value, into the scale's row.
 struct FullbandSink {
@@ -899,6 +911,112 @@ __device__ __forceinline__ void fullband_put(const FullbandSink& k, int64_t n, c
   if (MODE == GCWT_OUT_AMPLITUDE_F32) k.out[n] = sqrtf(v.x * v.x + v.y * v.y);
   else if (MODE == GCWT_OUT_POWER_F32) k.out[n] = v.x * v.x + v.y * v.y;
   else reinterpret_cast<cf*>(k.out)[n] = v;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) k_fullband4(const cf* __restrict__ in, const Fullband4Set set,
+                                                   float* __restrict__ out, int64_t in_cstride,
+                                                   const cf* __restrict__ twt, const cf* __restrict__ tw256,
+                                                   int n_scales, int64_t row_len, const SegOut seg) {
+  // 512 threads: waves 0 - 3 take rows k1 = 0, 2, waves 4 - 7 rows 1, 3, each half with its own exchange buffer.
+  // With a = z_0 +- z_2 and b = z_1 +- z_3 (W_P^(k1 n2) applied) the DFT4 over k1 is
+  //   y[n2] = a+ + b+,  y[n2 + 2 . 4096] = a+ - b+,  y[n2 + 4096] = a- + i b-,  y[n2 + 3 . 4096] = a- - i b-:
+  // the halves swap a- and b+ through LDS, the first stores n1 = 0, 2, the second n1 = 1, 3.
+  constexpr int64_t kP = (int64_t)4 * kRowLenDev;
+  __shared__ __attribute__((aligned(16))) cf bufs[2][16 * kExColD];
+  __shared__ v2f twl[256];
+  const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, a = tid & 15, t = tid >> 4;
+  cf* const buf = bufs[half];
+  float* const ex_re = reinterpret_cast<float*>(buf) + a * kExColD;
+  float* const ex_im = ex_re + 16 * kExColD;
+  const int slot = blockIdx.x;
+  if (half == 0) {
+    const cf w = tw256[(a * t) & 255];
+    twl[tid] = v2f{w.x, w.y};
+  }
+  const int at = 16 * t + a;
+  v2f* const bufv = reinterpret_cast<v2f*>(buf);
+  const v2f* const tws = reinterpret_cast<const v2f*>(twt) + tid;
+  v2f twa[4], twb[4];                   // the middle twiddles of the 4096-point transform (k_bc_scales)
+#pragma unroll
+  for (int m = 0; m < 4; ++m) twa[m] = tws[256 * (4 * m)];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) twb[n] = reinterpret_cast<const v2f*>(twt)[256 * n + a];
+  // W_P^(k1 n2), n2 = tid + 256 ka: first value and step, for this half's two rows (row 0: one)
+  v2f w0[2], wst[2];
+#pragma unroll
+  for (int rho = 0; rho < 2; ++rho) {
+    const int r = half + 2 * rho;
+    const cf p0 = unit_phase((int64_t)r * tid, kP, 1), p1 = unit_phase((int64_t)r * 256, kP, 1);
+    w0[rho] = v2f{p0.x, p0.y};
+    wst[rho] = v2f{p1.x, p1.y};
+  }
+  const v2f* const xs = reinterpret_cast<const v2f*>(in) + (int64_t)slot * in_cstride + at;
+  v2f* const swap_mine = reinterpret_cast<v2f*>(bufs[half]);          // what this half hands over
+  const v2f* const swap_theirs = reinterpret_cast<const v2f*>(bufs[half ^ 1]);
+  for (int sel = blockIdx.y; sel < set.n; sel += gridDim.y) {
+    const v2f* const hs = reinterpret_cast<const v2f*>(set.h[sel]) + at;
+    v2f keep[16], v[16];
+#pragma nounroll
+    for (int rho = 0; rho < 2; ++rho) {    // (rolled: unrolled, the second row's loads are hoisted over the first's transform)
+      {
+        const int64_t ro = (int64_t)(half + 2 * rho) * kRowLenDev;
+        const v2f* __restrict__ xp = xs + ro;
+        const v2f* __restrict__ hp = hs + ro;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = cmulv(xp[256 * j], hp[256 * j]);
+      }
+      __syncthreads();                    // twiddle table written / the buffers' last readers done
+      idft16v(v);
+#pragma unroll
+      for (int m2 = 0; m2 < 16; ++m2) {
+        const v2f u = cmulv(v[dft16_pos(m2)], twl[t + 16 * m2]);
+        ex_re[t * kExPitch + m2] = u.x;
+        ex_im[t * kExPitch + m2] = u.y;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) v[k1] = v2f{ex_re[k1 * kExPitch + t], ex_im[k1 * kExPitch + t]};
+      idft16v(v);
+      __syncthreads();                    // the element buffer aliases the exchange planes
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        bufv[pad32(16 * (t + 16 * j) + a)] = cmulv(cmulv(v[dft16_pos(j)], twa[j >> 2]), twb[j & 3]);
+      __syncthreads();
+#pragma unroll
+      for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[pad32(16 * tid + aa)];
+      idft16v(v);
+      v2f w = rho ? w0[1] : w0[0];
+      const v2f ws = rho ? wst[1] : wst[0];
+#pragma unroll
+      for (int ka = 0; ka < 16; ++ka) {
+        v2f val = cmulv(v[dft16_pos(ka)], w);
+        w = cmulv(w, ws);
+        if (rho == 0) keep[ka] = val;
+        else { const v2f k0 = keep[ka]; keep[ka] = k0 + val; v[dft16_pos(ka)] = k0 - val; }   // z_r + z_(r+2), z_r - z_(r+2)
+      }
+    }
+    // first half hands a- over, second half b+
+    __syncthreads();                      // every thread is done reading its element buffer
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) swap_mine[256 * ka + tid] = half == 0 ? v[dft16_pos(ka)] : keep[ka];
+    __syncthreads();
+    const FullbandSink sink = fullband_sink(out, slot, set.scale[sel], n_scales, row_len, seg, MODE == GCWT_OUT_COMPLEX_C64 ? 2 : 1);
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) {
+      const v2f o = swap_theirs[256 * ka + tid];
+      const int64_t n2 = tid + 256 * ka;
+      if (half == 0) {                    // a+ and b+
+        const v2f ap = keep[ka];
+        fullband_put<MODE>(sink, n2, make_float2(ap.x + o.x, ap.y + o.y));
+        fullband_put<MODE>(sink, n2 + 2 * kRowLenDev, make_float2(ap.x - o.x, ap.y - o.y));
+      } else {                            // a- and i b-
+        const v2f bm = v[dft16_pos(ka)];
+        fullband_put<MODE>(sink, n2 + kRowLenDev, make_float2(o.x - bm.y, o.y + bm.x));
+        fullband_put<MODE>(sink, n2 + 3 * kRowLenDev, make_float2(o.x + bm.y, o.y - bm.x));
+      }
+    }
+  }
 }
 
 // A tile's 16 columns are 64 bytes of an amplitude row: the tile next to it completes the 128-byte line,
@@ -1892,6 +2010,29 @@ hipError_t launch_fullband_rows(const cf* x, const FullbandSet& set, int p1, int
   if (group < 1 || group > p1 || p1 % group) group = p1 < 32 ? p1 : 32;   // p1 is a power of two
   hipLaunchKernelGGL(k_fullband_rows, dim3((unsigned)(n_slots * p1)), dim3(256), 0, st, x, set, x_cstride, z_cstride,
                      p1 > 1 ? p : 0, twt, tw256, n_slots, group);
+  return hipGetLastError();
+}
+
+hipError_t launch_fullband4(int mode, const cf* x, const cf* const* h, const int32_t* scales, int n, float* out,
+                            int64_t x_cstride, const cf* twt, const cf* tw256, int n_scales, int64_t row_len,
+                            const SegOut& seg, int n_slots, hipStream_t st) {
+  if (n < 1 || n > kFullband4Scales || !twt || !tw256 || n_slots < 1) return hipErrorInvalidValue;
+  Fullband4Set set{};
+  set.n = n;
+  for (int k = 0; k < n; ++k) {
+    if (!h[k]) return hipErrorInvalidValue;
+    set.h[k] = h[k];
+    set.scale[k] = scales[k];
+  }
+  // few slots: the scales of the set go to workgroups of their own
+  const int split = n_slots >= 2048 ? 1 : std::min(n, std::max(1, 2048 / n_slots));
+  const dim3 grid((unsigned)n_slots, (unsigned)split), block(512);
+  if (mode == GCWT_OUT_AMPLITUDE_F32)
+    hipLaunchKernelGGL((k_fullband4<GCWT_OUT_AMPLITUDE_F32>), grid, block, 0, st, x, set, out, x_cstride, twt, tw256, n_scales, row_len, seg);
+  else if (mode == GCWT_OUT_POWER_F32)
+    hipLaunchKernelGGL((k_fullband4<GCWT_OUT_POWER_F32>), grid, block, 0, st, x, set, out, x_cstride, twt, tw256, n_scales, row_len, seg);
+  else
+    hipLaunchKernelGGL((k_fullband4<GCWT_OUT_COMPLEX_C64>), grid, block, 0, st, x, set, out, x_cstride, twt, tw256, n_scales, row_len, seg);
   return hipGetLastError();
 }
 

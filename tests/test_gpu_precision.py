@@ -543,3 +543,28 @@ def test_public_call_float64_input_with_a_huge_offset():
     cwt.transform(x, fs=fs, freq_limits=[3, 300], voices_per_octave=4)
     ref = orc.cwt_amplitude(x, fs, cwt.frequencies, n_threads=8)
     assert rel_err(cwt.amplitude, ref).max() < 0.2 * TOL
+
+
+def test_time_blocks_of_16384_samples_fused_full_band(option):
+    """Kernels of 1 - 7 K taps under precision='exact' with the recording cut into time blocks of 2^14 samples: the
+    block's whole inverse transform -- four 4096-point rows, the W_P twiddle, the DFT4 across them -- and the store run in
+    one kernel (k_fullband4), and give the two-pass kernels' numbers to the bit and the oracle's within the gate;
+    amplitude and complex coefficients (convolution.py:68-87 has one path for every kernel length)."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp_channel
+    fs, n = 1000.0, 90000
+    f = np.geomspace(12.0, 2.0, 7)
+    x = np.stack([lfp_channel(n, fs, 40 + c) for c in range(2)]).astype(np.float32)
+    eb = [[5, 40003], [40100, n]]
+    for out in ("amplitude", "complex"):
+        ref = np.stack([orc.cwt_complex(x[c].astype(np.float64), fs, f, epoch_bounds=eb, n_threads=8) for c in range(2)])
+        ref = np.abs(ref) if out == "amplitude" else ref
+        got = {}
+        for fused in (1, 0):
+            option("fullband4", fused)
+            p = CwtPlan(n, 2, fs, f, precision="exact", output=out, max_fft_log2=14, epoch_bounds=eb)
+            assert p.info["n_fullband"] == f.size
+            got[fused] = p.execute(x)
+            p.close()
+        np.testing.assert_array_equal(got[1], got[0])
+        assert max(rel_err(got[1][c], ref[c]).max() for c in range(2)) < TOL
