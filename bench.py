@@ -600,7 +600,7 @@ def run_rank(args):
             except Exception:
                 pass
             line["other_configs"] = {"config1": config1_leg(fs, dev, lib, check, no_check=args.no_check),
-                                     "config2": config2_leg(fs, freqs, dev, lib, check, no_check=args.no_check),
+                                     "config2": config2_leg(fs, freqs, dev, lib, check, no_check=args.no_check, cooldown=not args.no_cooldown),
                                      "heavy_tailed_wavelet": heavy_tail_leg(N, C, fs, freqs, dev, lib, check,
                                                                             no_check=args.no_check),
                                      "config5": config5_leg(args)}
@@ -725,7 +725,7 @@ def heavy_tail_leg(N, C, fs, freqs, dev, lib, check, no_check=False, steps=5, wa
     return res
 
 
-def config2_leg(fs, freqs, dev, lib, check, no_check=False, steps=20, warmup=3):
+def config2_leg(fs, freqs, dev, lib, check, no_check=False, steps=20, warmup=3, cooldown=True):
     """BASELINE.json config 2: 1 channel x 1e6 samples x 100 scales 200..2 Hz on one GPU.  (a) device-resident
     execute, plan prebuilt (the metric's definition: SURVEY.md 8d); (b) the public call
     ContinuousWaveletTransform.transform() end to end -- host array in, host result out over PCIe, the
@@ -771,7 +771,31 @@ def config2_leg(fs, freqs, dev, lib, check, no_check=False, steps=20, warmup=3):
             worst = max(worst, float(np.abs(row - ref[i]).max() / ref[i].max()))
         res["checked"], res["worst_rel_err"] = bool(worst <= 1e-5), float("%.3g" % worst)
     xb.free(); ob.free(); plan.close()
+    # The link is half as fast for some twenty seconds after the card has run at its power limit (measured: a 400 MB
+    # float32 result 7.6 ms before the headline steps, 13.9 ms right after them, 7.6 ms again after 20 s of idling): the
+    # public call's leg waits for it to come back, up to 30 s, and says what the link gave before and after the wait.
     api = {}
+    import ctypes as C
+    from ghost_amd import hostmem
+    probe_dst = hostmem.empty((64 << 20,), np.float32)
+    probe_src = DeviceBuffer(256 << 20)
+
+    def link_gbps():
+        if probe_dst is None:
+            return None
+        t0 = time.perf_counter()
+        check(lib.gcwt_rows_to_host(probe_src.ptr, 64 << 20, 1, 64 << 20, probe_dst.ctypes.data_as(C.c_void_p), 64 << 20, 16))
+        return round(0.268435456 / (time.perf_counter() - t0), 1)
+    link_gbps()
+    link_before = link_gbps()
+    waited = 0.0
+    link_after = link_before
+    while cooldown and link_after is not None and link_after < 45.0 and waited < 30.0:
+        time.sleep(2.0)
+        waited += 2.0
+        link_after = link_gbps()
+    probe_src.free()
+    del probe_dst
     for name, kw in (("float64", {}), ("float32", {"dtype": np.float32})):
         cwt = ContinuousWaveletTransform()
         ts, t_call, t_slice = [], [], []
@@ -796,8 +820,9 @@ def config2_leg(fs, freqs, dev, lib, check, no_check=False, steps=20, warmup=3):
                      "transform_returns_ms": round(float(np.median(t_call[1:])) * 1e3, 2),
                      "transform_plus_1s_slice_ms": round(float(np.median(t_slice[1:])) * 1e3, 2)}
         del cwt
+    api["link"] = {"gbps_after_the_timed_steps": link_before, "waited_s": waited, "gbps_when_measured": link_after}
     res["transform_end_to_end"] = dict(api, note="host array in, transform() and then the whole `amplitude` on the host (page-locked result from the pool of "
-                                            "ghost_amd.hostmem, float64 sent as float32 and widened by host threads as it lands); transform_returns_ms: the call alone (rows left on the "
+                                            "ghost_amd.hostmem, float64 sent as float32 and widened by host threads as it lands; `link`: what a 256 MB copy gave right after the timed steps and when this leg ran -- the card's link is half as fast for some 20 s after a run at the power limit); transform_returns_ms: the call alone (rows left on the "
                                             "device); transform_plus_1s_slice_ms: transform() + fetch() of 1000 samples of every scale.  PCIe-inclusive: never the headline value")
     return res
 
@@ -888,6 +913,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config-2 and config-5 legs after the timed steps")
+    ap.add_argument("--no-cooldown", action="store_true", help="config-2 public-call leg: do not wait for the link to recover after the timed steps")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the complex-output measurement after the timed steps")
     ap.add_argument("--dry-run", default="", metavar="DIR",
                     help="launcher rehearsal: every rank writes DIR/rank<r>.json and exits (no GPU)")
