@@ -509,6 +509,11 @@ __device__ __forceinline__ cf unit_phase(int64_t num, int64_t den, int sign) {
 }
 
 __device__ __forceinline__ int pad32(int i) { return i + (i >> 5); }
+// element buffer of the 4096-point transforms' last exchange: thread T's sixteen values 18 elements apart -- 36 dwords,
+// = 4 (mod 32), so the 16-byte reads of eight neighbouring lanes cover the 32 banks once (at a pitch of 16 + T / 2
+// pairs of lanes met on the same banks: 17 % of the LDS time of k_bc_scales, profiles/r04_pmc_k_bc_scales.json)
+constexpr int kElemPitch = 18;
+static_assert(256 * kElemPitch <= 16 * kExColD, "the element buffer aliases the exchange planes");
 
 
 // Rows of length Q = 256 q, q = 1 << LQ: FFT256 over the stride-q subsequences,
@@ -861,10 +866,10 @@ __global__ void __launch_bounds__(256, 2) k_fullband_rows(const cf* __restrict__
     __syncthreads();                      // the element buffer aliases the exchange planes
 #pragma unroll
     for (int j = 0; j < 16; ++j)        // W_4096^(+(t + 16 j) a) = twa[j >> 2] twb[j & 3], as in k_bc_scales
-      bufv[pad32(16 * (t + 16 * j) + a)] = cmulv(cmulv(v[dft16_pos(j)], twa[j >> 2]), twb[j & 3]);
+      bufv[kElemPitch * (t + 16 * j) + a] = cmulv(cmulv(v[dft16_pos(j)], twa[j >> 2]), twb[j & 3]);
     __syncthreads();
 #pragma unroll
-    for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[pad32(16 * tid + aa)];
+    for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[kElemPitch * tid + aa];
     idft16v(v);
     v2f w = w0;
 #pragma unroll
@@ -981,10 +986,10 @@ __global__ void __launch_bounds__(512, 2) k_fullband4(const cf* __restrict__ in,
       __syncthreads();                    // the element buffer aliases the exchange planes
 #pragma unroll
       for (int j = 0; j < 16; ++j)
-        bufv[pad32(16 * (t + 16 * j) + a)] = cmulv(cmulv(v[dft16_pos(j)], twa[j >> 2]), twb[j & 3]);
+        bufv[kElemPitch * (t + 16 * j) + a] = cmulv(cmulv(v[dft16_pos(j)], twa[j >> 2]), twb[j & 3]);
       __syncthreads();
 #pragma unroll
-      for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[pad32(16 * tid + aa)];
+      for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[kElemPitch * tid + aa];
       idft16v(v);
       v2f w = rho ? w0[1] : w0[0];
       const v2f ws = rho ? wst[1] : wst[0];
@@ -1167,10 +1172,10 @@ __global__ void __launch_bounds__(256, 2) k_bc_scales(const cf* __restrict__ xb,
     __syncthreads();                      // the element buffer aliases the exchange planes
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      bufv[pad32(16 * (t + 16 * j) + a)] = cmulv(cmulv(v[dft16_pos(j)], twa[j >> 2]), twb[j & 3]);
+      bufv[kElemPitch * (t + 16 * j) + a] = cmulv(cmulv(v[dft16_pos(j)], twa[j >> 2]), twb[j & 3]);
     __syncthreads();
 #pragma unroll
-    for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[pad32(16 * tid + aa)];
+    for (int aa = 0; aa < 16; ++aa) v[aa] = bufv[kElemPitch * tid + aa];
     idft16v(v);
     float* const o = o0 + (int64_t)rows[s] * row_len * kElem;
 #pragma unroll

@@ -6,7 +6,7 @@ from _opts import apply_env_options; apply_env_options()
 from ghost_amd.synthetic import lfp
 fs=1000.; N=1000000; S=100; C=int(os.environ.get("QB_C","128")); reps=int(os.environ.get("QB_REPS","10"))
 f=np.geomspace(200,2,S)
-plan=CwtPlan(N,C,fs,f,output=os.environ.get("QB_OUT","amplitude"))
+plan=CwtPlan(N,C,fs,f,output=os.environ.get("QB_OUT","amplitude"),precision=os.environ.get("QB_PRECISION","auto"))
 plan.set_profiling(True)
 x=lfp(4,N); x=np.tile(x,(C//4+1,1))[:C]
 xb=DeviceBuffer(x.nbytes); xb.upload(x)
