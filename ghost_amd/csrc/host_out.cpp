@@ -3,11 +3,14 @@
 
 #include <immintrin.h>
 #include <pthread.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cctype>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -33,6 +36,15 @@ class Workers {
       else delete fresh;
     }
     return *w;
+  }
+  // The workers run beside the device: the staging buffers and page-locked destinations live on the device's NUMA node
+  // (the runtime places them there), and threads on the other socket widen at half the rate (measured: 800 MB in
+  // 7 against 17 ms).  Best effort: within the process's own affinity, nothing if the node cannot be told.
+  void bind(const cpu_set_t& cpus) {
+    std::lock_guard<std::mutex> one(job_mu_);
+    cpus_ = cpus;
+    bound_ = true;
+    for (std::thread& t : threads_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(cpus_), &cpus_);
   }
   // body(a, b) over [0, n) in contiguous pieces, the caller's thread taking one of them
   void run(size_t n, size_t n_thr, const std::function<void(size_t, size_t)>& body) {
@@ -64,7 +76,7 @@ class Workers {
   void grow(size_t n) {
     while (threads_.size() < n) {
       threads_.emplace_back([this] { loop(); });
-      threads_.back().detach();
+      if (bound_) (void)pthread_setaffinity_np(threads_.back().native_handle(), sizeof(cpus_), &cpus_);
     }
   }
   void loop() {
@@ -90,11 +102,44 @@ class Workers {
   }
   std::mutex job_mu_, mu_;
   std::condition_variable cv_, done_;
-  std::vector<std::thread> threads_;
+  std::vector<std::thread> threads_;        // never joined: the object is never destroyed
+  cpu_set_t cpus_;
+  bool bound_ = false;
   const std::function<void(size_t, size_t)>* body_ = nullptr;
   size_t n_ = 0, per_ = 0, next_ = 0, last_ = 0, pending_ = 0;
   uint64_t epoch_ = 0;
 };
+
+// CPUs on the current device's NUMA node (sysfs: local_cpulist of its PCI function), cut to the process's affinity
+void bind_workers_beside_device() {
+  static int bound_device = -2;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev == bound_device) return;
+  bound_device = dev;
+  char bdf[64] = {0}, path[160];
+  if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), dev) != hipSuccess) { (void)hipGetLastError(); return; }
+  for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char line[4096] = {0};
+  const bool ok = fgets(line, sizeof(line), f) != nullptr;
+  fclose(f);
+  if (!ok) return;
+  cpu_set_t node, mine, both;
+  CPU_ZERO(&node);
+  for (char* tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    int a = 0, b = 0;
+    const int n = sscanf(tok, "%d-%d", &a, &b);
+    if (n < 1) continue;
+    if (n == 1) b = a;
+    for (int c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET(c, &node);
+  }
+  if (sched_getaffinity(0, sizeof(mine), &mine) != 0) return;
+  CPU_AND(&both, &node, &mine);
+  if (CPU_COUNT(&both) == 0 || CPU_EQUAL(&both, &mine)) return;     // nothing to choose
+  Workers::get().bind(both);
+}
 
 size_t worker_count(size_t bytes) {
   if (bytes < (size_t(1) << 20)) return 1;
@@ -139,6 +184,7 @@ hipError_t HostOut::drain(const float* d_src, size_t src_pitch_floats, size_t n_
                           size_t row_floats, void* dst, bool widen, hipStream_t stream, size_t dst_pitch) {
   if (n_rows == 0 || row_floats == 0) return hipStreamSynchronize(stream);
   if (dst_pitch == 0) dst_pitch = row_floats;
+  bind_workers_beside_device();
   hipError_t e;
   for (int i = 0; i < kDepth; ++i) {
     if (!ring_[i] && (e = hipHostMalloc((void**)&ring_[i], kChunkBytes, hipHostMallocDefault)) != hipSuccess)
