@@ -775,8 +775,10 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       // Blocks per workgroup: a workgroup's prologue (its blocks' spectra, 16 threads each) takes
       // about as long whatever their number, and a block of a low decimation is little work:
       // two blocks per workgroup up to R = 32, one from R = 64 up (measured per level,
-      // profiles/r03_synth_study.md; the 16 columns of a pass are blocks x scales x phases).
-      int lgnb = lp.decimation <= 32 ? 1 : 0;
+      // profiles/r03_synth_study.md; the 16 columns of a pass are blocks x scales x phases) -- with two phases per scale;
+      // with four (R >= 32 since round 5) two blocks leave two scales per pass and one block is the better cut (R = 32:
+      // 1.56 against 1.63 - 1.66 ms)
+      int lgnb = lp.decimation <= 32 && lp.interp_q <= 2 ? 1 : 0;
       if (p->interp_lgnb >= 0) lgnb = std::min(p->interp_lgnb, 2);
       while (lgnb > 0 && (lp.interp_q << lgnb) > kInterpMaxPhases) --lgnb;
       // what k_synthi's indexing assumes (synthi.hip); the planner guarantees it
