@@ -112,10 +112,10 @@ class Workers {
 
 // CPUs on the current device's NUMA node (sysfs: local_cpulist of its PCI function), cut to the process's affinity
 void bind_workers_beside_device() {
-  static int bound_device = -2;
+  static std::atomic<int> bound_device{-2};       // (drains of different plans may run on different threads)
   int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev == bound_device) return;
-  bound_device = dev;
+  if (hipGetDevice(&dev) != hipSuccess || dev == bound_device.load()) return;
+  bound_device.store(dev);
   char bdf[64] = {0}, path[160];
   if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), dev) != hipSuccess) { (void)hipGetLastError(); return; }
   for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
