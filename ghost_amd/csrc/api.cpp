@@ -185,6 +185,7 @@ struct gcwt_plan {
   // forward row pass; d_pred: per scale, the largest predicted loss over the slots of an execute.
   bool detect = false;               // the plan predicts (float64 forward transform, no long mode, some spectral scale)
   float* d_hist = nullptr;
+  float* d_bands = nullptr;          // [slots][kSpecBands]: the rows of d_hist added up (detect.hip: k_band_sums)
   float* d_pred = nullptr;
   hipStream_t det_stream = nullptr;  // the predictions are made beside the level passes and the synthesis, not behind them
   int32_t* d_scale_level = nullptr;
@@ -205,6 +206,7 @@ struct gcwt_plan {
   // scales made again by the exact paths: a sub-plan with precision = exact over ALL the scales, for every channel [0] or
   // for one [1], made on first need; a run of it is masked to the scales wanted and writes straight into this plan's rows
   gcwt_plan* sub_plan[2] = {nullptr, nullptr};
+  bool is_sub_plan = false;          // this plan IS such a sub-plan (its response cache takes half the share)
   // a masked run (this plan IS such a sub-plan): run_mask[scale] != 0 -> make the row; nothing else is touched
   const unsigned char* run_mask = nullptr;
   unsigned char* d_run_mask = nullptr;
@@ -247,7 +249,7 @@ void free_dev(gcwt_plan* p) {
   fr(p->d_in);
   if (p->d_out) { (void)hipFree(p->d_out); p->d_out = nullptr; }
   if (p->h_pred) { (void)hipHostFree(p->h_pred); p->h_pred = nullptr; }
-  fr(p->d_hist); fr(p->d_pred); fr(p->d_scale_level); fr(p->d_scale_length); fr(p->d_run_mask);
+  fr(p->d_hist); fr(p->d_bands); fr(p->d_pred); fr(p->d_scale_level); fr(p->d_scale_length); fr(p->d_run_mask);
   for (gcwt_plan*& sub : p->sub_plan)
     if (sub) { gcwt_plan_destroy(sub); sub = nullptr; }
   for (auto& kv : p->hfull_cache) (void)hipFree(kv.second);
@@ -349,7 +351,16 @@ int gcwt_device_pci_bus_id(int device, char* buf, size_t buflen) {
   return GCWT_OK;
 }
 
-int gcwt_set_device(int device) { HIP_TRY(hipSetDevice(device)); return GCWT_OK; }
+int gcwt_set_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    return set_err(GCWT_ERR_NO_DEVICE, "no HIP device: libghostcwt needs an AMD GPU (gfx950); there is no CPU path");
+  }
+  if (device < 0 || device >= n) return set_err(GCWT_ERR_NO_DEVICE, "no such device (gcwt_device_count tells how many there are)");
+  HIP_TRY(hipSetDevice(device));
+  return GCWT_OK;
+}
 int gcwt_current_device(int* device) {
   if (!device) return set_err(GCWT_ERR_INVALID, "NULL argument");
   HIP_TRY(hipGetDevice(device));
@@ -487,12 +498,18 @@ int gcwt_plan_get_info(const gcwt_plan* plan, gcwt_plan_info* info) {
     if (hp.high_precision && !hp.exact_only) {             // the detector's band sums and predictions (precision auto / high)
       int64_t max_rows = 1;
       for (const EpochPlan& ep : hp.epochs) max_rows = std::max<int64_t>(max_rows, ep.p1);
-      extra += 4 * (slots * max_rows * kSpecBands + (int64_t)hp.prm.n_freqs * (int64_t)hp.epochs.size());
+      extra += 4 * (slots * (max_rows * kRowBands + kSpecBands) + (int64_t)hp.prm.n_freqs * (int64_t)hp.epochs.size());
     }
     if (hp.n_fullband > 0)
       extra += std::min<int64_t>(plan->uploaded ? plan->fullband_cache_cap : kFullbandCacheBytes,
                                  8 * (int64_t)hp.n_fullband * hp.max_p * (int64_t)hp.epochs.size());
     info->workspace_bytes = hp.workspace_bytes + extra;
+    // precision = auto: the exact sub-plans a recording with in-band interference made this plan create (at most two,
+    // kept for later executes) are device memory of this plan too
+    for (const gcwt_plan* sub : plan->sub_plan) {
+      gcwt_plan_info si{};
+      if (sub && gcwt_plan_get_info(sub, &si) == GCWT_OK) info->workspace_bytes += si.workspace_bytes;
+    }
   }
   info->out_bytes = (int64_t)hp.out_elem_bytes * hp.prm.n_channels * hp.prm.n_freqs * hp.prm.n_samples;
   return GCWT_OK;
@@ -549,9 +566,18 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
   const int64_t C = hp.prm.n_channels;
   const int S = hp.prm.n_freqs, B = hp.block;
   int rc;
-  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-  for (auto& q : p->aux) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&p->det_stream, hipStreamNonBlocking));
+  // option cu_count (measurements: profiles/r06_bound.md): the plan's streams may use that many of the CUs only.  The
+  // mask's bits are dealt round-robin over the XCDs by the driver, so its first n bits are n / 8 CUs of each.
+  auto make_stream = [&](hipStream_t* q) -> hipError_t {
+    const int n_cu = (int)option_or("cu_count", 0);
+    if (n_cu <= 0) return hipStreamCreateWithFlags(q, hipStreamNonBlocking);
+    uint32_t mask[16] = {};
+    for (int i = 0; i < n_cu && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
+    return hipExtStreamCreateWithCUMask(q, 16, mask);
+  };
+  HIP_TRY(make_stream(&p->stream));
+  for (auto& q : p->aux) HIP_TRY(make_stream(&q));
+  HIP_TRY(make_stream(&p->det_stream));
   auto bail = [&](int code) { free_dev(p); return code; };
   bool he_sync_tables = false;
 
@@ -909,7 +935,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       int64_t max_rows = 1;                              // rows of the forward row pass: run_pipeline's rows_a
       for (const EpochPlan& ep : hp.epochs)
         max_rows = std::max<int64_t>(max_rows, ep.p1);
-      if ((rc = dev_alloc(&p->d_hist, (size_t)(slots * max_rows * kSpecBands)))) return bail(rc);
+      if ((rc = dev_alloc(&p->d_hist, (size_t)(slots * max_rows * kRowBands)))) return bail(rc);
+      if ((rc = dev_alloc(&p->d_bands, (size_t)(slots * kSpecBands)))) return bail(rc);
       if ((rc = dev_alloc(&p->d_pred, (size_t)S * (size_t)C * hp.epochs.size()))) return bail(rc);
       if ((rc = upload_vec(&p->d_scale_level, scale_level, p->stream))) return bail(rc);
       std::vector<int32_t> scale_length((size_t)S);
@@ -957,6 +984,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     p->fullband_cache_cap = std::min<int64_t>(kFullbandCacheBytes, (int64_t)(free_b / 4));
+    if (p->is_sub_plan) p->fullband_cache_cap /= 2;      // two of them may live inside one parent
     if (option_is_set("fullband_cache_mb")) p->fullband_cache_cap = std::max<long long>(0, option_or("fullband_cache_mb", 0)) << 20;
   }
   p->uploaded = true;
@@ -1071,27 +1099,22 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         RUN(ST_FWD, launch_fwd64_cols(dx, p->d_y, P1, N, p->y_stride, P, p->d_tw64, p->d_sums, inv_n, sin, nb,
                                       rows_a, st, A, a));
         RUN(ST_FWD, launch_fwd64_rows(p->d_y, p->d_x, rows_a, p->y_stride, P, p->d_tw64, slots,
-                                      hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0, st, a, A, Pt));
+                                      hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0, st, a, A, Pt,
+                                      p->detect ? p->d_hist : nullptr, P1));
       }
-      // precision = auto / high: the spectrum's band energies, then -- on a stream of its own, beside the level passes
-      // and the synthesis -- what the float32 stages will cost each scale (detect.hip); joined at the end of the batch
+      // precision = auto / high: the row pass left the band energies of every row of the spectrum (fwd64.hip:
+      // row_band_sums); on a stream of its own, beside the level passes and the synthesis, they are added up and turned
+      // into what the float32 stages will cost each scale (detect.hip); joined at the end of the batch
       if (p->detect) {
-        // (a small batch does not fill the chip: there the band pass goes to the detector's stream as well and the
-        // chain of dependent kernels is as long as without the detector; a large one competes for bandwidth wherever
-        // it runs, and beside the level passes it cost them more than it took: profiles/r05_auto_precision.md 3)
-        const bool beside = (int64_t)slots * P <= ((int64_t)1 << 24);
-        if (!beside) RUN(ST_FWD, launch_spectrum_bands(p->d_x, P, P1, p->d_hist, slots, st));
         hipEvent_t bands_done;
         int rc_ = get_event(p, &bands_done);
         if (rc_) return rc_;
         he = hipEventRecord(bands_done, st);
         if (he == hipSuccess) he = hipStreamWaitEvent(p->det_stream, bands_done, 0);
         if (he != hipSuccess) return hip_err(he, "detector fork");
-        if (beside) {
-          he = launch_spectrum_bands(p->d_x, P, P1, p->d_hist, slots, p->det_stream);
-          if (he != hipSuccess) return hip_err(he, "launch_spectrum_bands");
-        }
-        he = launch_precision_predict(p->d_hist, P1, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[ep.batch_first].pred_levels, S,
+        he = launch_band_sums(p->d_hist, P1, p->d_bands, slots, p->det_stream);
+        if (he != hipSuccess) return hip_err(he, "launch_band_sums");
+        he = launch_precision_predict(p->d_bands, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[ep.batch_first].pred_levels, S,
                                       (int)hp.levels.size(), (double)Pt, p->kappa_eps, p->oob_tol, p->d_pred, nullptr, nullptr, slots, psegs,
                                       p->det_stream);
         if (he != hipSuccess) return hip_err(he, "launch_precision_predict");
@@ -1526,6 +1549,7 @@ static int reroute_scales(gcwt_plan* p, const float* dx, float* dout, int64_t ou
       gcwt_plan_destroy(sub); sub = nullptr;
       return set_err(GCWT_ERR_INVALID, "internal: the exact sub-plan keeps a decimated scale");
     }
+    sub->is_sub_plan = true;
     if ((rc = gcwt_plan_upload(sub))) { gcwt_plan_destroy(sub); sub = nullptr; return rc; }
     if (hipMalloc((void**)&sub->d_run_mask, (size_t)S) != hipSuccess) {
       (void)hipGetLastError();
@@ -1674,7 +1698,17 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
     for (float v : p->last_pred) p->last_worst = std::max(p->last_worst, v);
     p->last_rerouted = 0;
     if (hp.auto_precision) {
-      for (size_t e = 0; e < n_seg;) {
+      // A scale that cannot be made again -- no device memory for the exact sub-plan or its workspace on a small or busy
+      // GPU, a layout the exact paths do not take -- keeps the fast path's row: what precision = high returns, complete
+      // and finite.  The execute succeeds, the report says so (a negative count) and gcwt_last_error why.
+      bool gave_up = false;
+      auto soft = [&](int code) {
+        if (code != GCWT_ERR_NOMEM && code != GCWT_ERR_UNSUPPORTED) return false;
+        (void)hipGetLastError();
+        gave_up = true;
+        return true;
+      };
+      for (size_t e = 0; e < n_seg && !gave_up;) {
         size_t e1 = e + 1;
         if (vd[e].scales.empty()) { e = e1; continue; }
         int64_t a = std::max(hp.epochs[e].core0, r0), b = std::min(hp.epochs[e].core1, r1);
@@ -1685,17 +1719,19 @@ static int execute_range(gcwt_plan* p, const void* x, void* out, int64_t r0, int
         if (b > a) {
           if (vd[e].channels.empty()) {
             rc = reroute_scales(p, dx, dout, r0, a, b, row_len, vd[e].scales, -1);
-            if (rc) return rc;
+            if (rc && !soft(rc)) return rc;
           } else {
             for (int32_t c : vd[e].channels) {
               rc = reroute_scales(p, dx, dout, r0, a, b, row_len, vd[e].scales, c);
-              if (rc) return rc;
+              if (rc && !soft(rc)) return rc;
+              if (gave_up) break;
             }
           }
         }
         e = e1;
       }
       for (char c : any) p->last_rerouted += c;
+      if (gave_up) p->last_rerouted = -p->last_rerouted;
     }
   }
   if (!(flags & GCWT_OUT_ON_DEVICE)) {
@@ -1809,24 +1845,28 @@ int gcwt_plan_precision_report(const gcwt_plan* p, float* predicted, float* wors
 
 // test hook: the two terms of the prediction (rounding of the level's stages; what the level leaves out) of workspace
 // slot 0 of the last batch the last execute ran, S floats each, and the level energies (n_levels floats, may be NULL)
-int gcwt_debug_precision_terms(gcwt_plan* p, float* rounding, float* left_out, float* level_energy) {
+int gcwt_debug_precision_terms(gcwt_plan* p, float* rounding, float* left_out, float* level_energy, float* band_energy) {
   if (!p || !rounding || !left_out) return set_err(GCWT_ERR_INVALID, "NULL argument");
   if (!p->detect || p->last_batch_slots <= 0) return set_err(GCWT_ERR_INVALID, "no execute with the detector on yet");
   const int S = p->hp.prm.n_freqs, L = (int)p->hp.levels.size();
-  float *d_sc = nullptr, *d_lv = nullptr, *d_pr = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_sc, sizeof(float) * 2 * (size_t)S * p->last_batch_slots));
-  HIP_TRY(hipMalloc((void**)&d_lv, sizeof(float) * (size_t)L * p->last_batch_slots));
-  HIP_TRY(hipMalloc((void**)&d_pr, sizeof(float) * (size_t)S));
-  HIP_TRY(hipMemsetAsync(d_pr, 0, sizeof(float) * (size_t)S, p->stream));
-  PredSegs dbg_segs{};                       // (every slot to row 0 of the scratch predictions)
+  // scratch predictions: the kernel writes pred[(segment, channel, scale)] -- every slot's segment is 0 here, so C rows of S
+  struct Scratch {
+    float* p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+  } sc, lv, pr;
+  const size_t Cn = (size_t)p->hp.prm.n_channels;
+  HIP_TRY(hipMalloc((void**)&sc.p, sizeof(float) * 2 * (size_t)S * p->last_batch_slots));
+  HIP_TRY(hipMalloc((void**)&lv.p, sizeof(float) * (size_t)L * p->last_batch_slots));
+  HIP_TRY(hipMalloc((void**)&pr.p, sizeof(float) * (size_t)S * Cn));
+  PredSegs dbg_segs{};
   dbg_segs.n_channels = p->hp.prm.n_channels;
-  hipError_t he = launch_precision_predict(p->d_hist, p->last_rows, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[p->last_batch].pred_levels, S, L,
-                                           p->last_pt, p->kappa_eps, p->oob_tol, d_pr, d_lv, d_sc, p->last_batch_slots, dbg_segs, p->stream);
-  if (he == hipSuccess) he = hipMemcpyAsync(rounding, d_sc, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, p->stream);
-  if (he == hipSuccess) he = hipMemcpyAsync(left_out, d_sc + S, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, p->stream);
-  if (he == hipSuccess && level_energy) he = hipMemcpyAsync(level_energy, d_lv, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, p->stream);
+  hipError_t he = launch_precision_predict(p->d_bands, p->d_gain, p->d_scale_level, p->d_scale_length, p->ep_dev[p->last_batch].pred_levels, S, L,
+                                           p->last_pt, p->kappa_eps, p->oob_tol, pr.p, lv.p, sc.p, p->last_batch_slots, dbg_segs, p->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(rounding, sc.p, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, p->stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(left_out, sc.p + S, sizeof(float) * (size_t)S, hipMemcpyDeviceToHost, p->stream);
+  if (he == hipSuccess && level_energy) he = hipMemcpyAsync(level_energy, lv.p, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, p->stream);
+  if (he == hipSuccess && band_energy) he = hipMemcpyAsync(band_energy, p->d_bands, sizeof(float) * (size_t)kSpecBands, hipMemcpyDeviceToHost, p->stream);
   if (he == hipSuccess) he = hipStreamSynchronize(p->stream);
-  (void)hipFree(d_sc); (void)hipFree(d_lv); (void)hipFree(d_pr);
   if (he != hipSuccess) return hip_err(he, "precision terms");
   return GCWT_OK;
 }

@@ -1,5 +1,5 @@
 // detect.hip -- precision = auto: predict, per scale, what the float32 stages of the decimated path cost it, from
-// the band energies of the float64 spectrum (fwd64.hip: k_fwd64_rows, hist).  The reference computes in float64
+// the band energies of the float64 spectrum (summed where it is made: fwd64.hip, k_fwd64_rows -> row_band_sums).  The reference computes in float64
 // (transforms.py:142-143, convolution.py:68-77) and does not care how far a band lies below the rest of the
 // recording; the float32 level transform and block spectra do: their rounding is white at ~2^-24 of everything
 // the level's x_R contains, so a scale whose own output is D times weaker than its level's content loses
@@ -37,36 +37,27 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 }  // namespace
 
-// Band energies of the spectrum (kernels.h: spec_band): one workgroup per (row k1, slot) reads the row's 2048 bins
-// k1 + p1 k2, k2 < 2048 -- the positive half; consecutive k2 are p1 bins apart, so a thread's eight consecutive k2
-// lie in one band as a rule -- and leaves the row's kSpecBands sums: 0.54 GB read per headline step.
-__global__ void __launch_bounds__(256) k_spectrum_bands(const float2* __restrict__ x, int64_t x_cstride, int p1,
-                                                        float* __restrict__ hist) {
-  __shared__ float hl[kSpecBands];
-  const int tid = threadIdx.x, row = blockIdx.x;
-  for (int i = tid; i < kSpecBands; i += 256) hl[i] = 0.f;
-  const float4* src = reinterpret_cast<const float4*>(x + (int64_t)blockIdx.y * x_cstride + (int64_t)row * kRowLenDev) + 4 * tid;
-  const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];     // bins k2 = 8 tid .. 8 tid + 7
-  __syncthreads();
-  const float e[8] = {q0.x * q0.x + q0.y * q0.y, q0.z * q0.z + q0.w * q0.w, q1.x * q1.x + q1.y * q1.y, q1.z * q1.z + q1.w * q1.w,
-                      q2.x * q2.x + q2.y * q2.y, q2.z * q2.z + q2.w * q2.w, q3.x * q3.x + q3.y * q3.y, q3.z * q3.z + q3.w * q3.w};
-  const int64_t k0 = (int64_t)row + (int64_t)p1 * (8 * tid);
-  const int ba = k0 > 0 ? spec_band((float)k0) : -1, bz = spec_band((float)(k0 + 7 * (int64_t)p1));
-  if (ba == bz) {
-    atomicAdd(hl + ba, ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7])));
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int64_t k = k0 + (int64_t)p1 * j;
-      if (k > 0) atomicAdd(hl + spec_band((float)k), e[j]);
-    }
-  }
-  __syncthreads();
-  float* const hg = hist + ((int64_t)blockIdx.y * gridDim.x + row) * kSpecBands;
-  for (int i = tid; i < kSpecBands; i += 256) hg[i] = hl[i];
+// The rows' band sums (kernels.h: kRowBands; written by the forward row pass, fwd64.hip: row_band_sums) added up into
+// the slot's kSpecBands band energies: one thread per band, rows in row order -- the same bits every run.
+__global__ void __launch_bounds__(kSpecBands) k_band_sums(const float* __restrict__ hist, int p1, int lg_p1,
+                                                          float* __restrict__ bands) {
+  const int b = threadIdx.x;
+  const float* const hs = hist + (int64_t)blockIdx.x * p1 * kRowBands;
+  float acc = 0.f;
+  // bins k1 + p1 k2, k2 >= 16: band(k) = band(k2) + 16 log2 p1; the rows keep band(k2) = 64 .. 175 at entries 16 .. 127
+  const int entry = b - 16 * lg_p1 - 64 + 16;
+  if (entry >= 16 && entry < kRowBands)
+    for (int r = 0; r < p1; ++r) acc += hs[(int64_t)r * kRowBands + entry];
+  // k2 < 16: kept bin by bin (entries 0 .. 15); this band's bins below 16 p1, in order (bin 0 belongs to no band)
+  float lo, hi;
+  band_edges(b, &lo, &hi);
+  const int k_lo = max(1, (int)ceilf(lo)), k_hi = min((int)ceilf(hi), 16 * p1);
+  for (int k = k_lo; k < k_hi; ++k)
+    if (spec_band((float)k) == b) acc += hs[(int64_t)(k & (p1 - 1)) * kRowBands + (k >> lg_p1)];
+  bands[(int64_t)blockIdx.x * kSpecBands + b] = acc;
 }
 
-__global__ void __launch_bounds__(256) k_precision_predict(const float* __restrict__ hist, int n_rows, const float* __restrict__ gain,
+__global__ void __launch_bounds__(256) k_precision_predict(const float* __restrict__ bands, const float* __restrict__ gain,
                                                            const int32_t* __restrict__ scale_level,
                                                            const int32_t* __restrict__ scale_length,
                                                            const PredLevel* __restrict__ levels, int n_scales,
@@ -80,12 +71,7 @@ __global__ void __launch_bounds__(256) k_precision_predict(const float* __restri
   __shared__ int band_of[256];
   __shared__ float red[4];
   const int tid = threadIdx.x, slot = blockIdx.x;
-  for (int i = tid; i < kSpecBands; i += 256) {                  // the rows' band sums, added in row order
-    const float* hr = hist + (int64_t)slot * n_rows * kSpecBands + i;
-    float acc = 0.f;
-    for (int r = 0; r < n_rows; ++r) acc += hr[(int64_t)r * kSpecBands];
-    h[i] = acc;
-  }
+  for (int i = tid; i < kSpecBands; i += 256) h[i] = bands[(int64_t)slot * kSpecBands + i];
   __syncthreads();
   {
     const int l = blockIdx.y;                                    // one workgroup per (slot, level)
@@ -165,18 +151,21 @@ __global__ void __launch_bounds__(256) k_precision_predict(const float* __restri
   }
 }
 
-hipError_t launch_spectrum_bands(const float2* x, int64_t x_cstride, int p1, float* hist, int n_slots, hipStream_t st) {
+hipError_t launch_band_sums(const float* hist, int p1, float* bands, int n_slots, hipStream_t st) {
   if (n_slots <= 0 || p1 <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_spectrum_bands, dim3((unsigned)p1, (unsigned)n_slots), dim3(256), 0, st, x, x_cstride, p1, hist);
+  int lg = 0;
+  while ((1 << lg) < p1) ++lg;
+  if ((1 << lg) != p1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_band_sums, dim3((unsigned)n_slots), dim3(kSpecBands), 0, st, hist, p1, lg, bands);
   return hipGetLastError();
 }
 
-hipError_t launch_precision_predict(const float* hist, int n_rows, const float* gain, const int32_t* scale_level,
+hipError_t launch_precision_predict(const float* bands, const float* gain, const int32_t* scale_level,
                                     const int32_t* scale_length, const PredLevel* levels, int n_scales, int n_levels, double p_true,
                                     float kappa_eps, float oob_tol, float* pred, float* dbg_level, float* dbg_scale,
                                     int n_slots, const PredSegs& segs, hipStream_t st) {
   if (n_slots <= 0 || n_scales <= 0 || n_levels <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_precision_predict, dim3(n_slots, n_levels), dim3(256), 0, st, hist, n_rows, gain, scale_level, scale_length, levels, n_scales,
+  hipLaunchKernelGGL(k_precision_predict, dim3(n_slots, n_levels), dim3(256), 0, st, bands, gain, scale_level, scale_length, levels, n_scales,
                      n_levels, (float)p_true, kappa_eps, oob_tol, pred, dbg_level, dbg_scale, segs);
   return hipGetLastError();
 }

@@ -366,12 +366,32 @@ __global__ void __launch_bounds__(256) k_fwd64_cols_small(const float* __restric
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int dpad(int i) { return i + (i >> 4); }
 
+// precision = auto (detect.hip): the band energies of the spectrum are summed where it is made.  A wave of the row
+// pass holds 64 consecutive k2 of one row k1 (bins k1 + p1 k2), ascending or -- the reflected half -- descending, and
+// from k2 = 16 on the band of a bin is the band of its k2 (sixteen per octave: kernels.h, spec_band; p1 is a power of
+// two), 2^(e - 4) consecutive k2 of octave e: aligned groups of 1 .. 64 lanes, summed by a butterfly in a fixed order
+// and stored once by the group's first k2 -- no atomics, no staging, the same bits every run.  k2 < 16 (where the
+// band depends on k1 too) are kept bin by bin.  Row layout (kernels.h: kRowBands): [0, 16) those bins, [16, 128) the
+// bands of k2 = 16 .. 2047.  Everything but the values is uniform over the wave's 64-aligned run of k2.
+__device__ __forceinline__ void row_band_sums(float e, int k2, float* __restrict__ hrow) {
+  const int depth = k2 < 32 ? 0 : 27 - __clz(k2);                                  // log2 of the group: octave - 4
+  const int top = __builtin_amdgcn_readfirstlane(k2 | 63);
+  const int d_max = top < 32 ? 0 : 27 - __clz(top);
+  for (int s = 0; s < d_max; ++s) {
+    const float o = __shfl_xor(e, 1 << s, 64);
+    if (s < depth) e += o;
+  }
+  if ((k2 & ((1 << depth) - 1)) == 0)
+    hrow[k2 < 16 ? k2 : 16 + (int)(__float_as_uint((float)k2) >> 19) - (127 * 16 + 64)] = e;
+}
+
 // comb_n > 1 (long mode): this is subsequence comb_a of comb_n; every output bin k is multiplied by W_pt^(a k),
 // pt = 2^lg_pt the true FFT length, and added to what the earlier subsequences left (a = 0 stores).
 __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, float2* __restrict__ out,
                                                     int64_t in_cstride, int64_t out_cstride,
                                                     const cd* __restrict__ tw_hi, int out_len, int mirror,
-                                                    int comb_a, int comb_n, int lg_pt) {
+                                                    int comb_a, int comb_n, int lg_pt, float* __restrict__ hist,
+                                                    int hist_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* const ex_re = reinterpret_cast<double*>(smem);
   double* const ex_im = ex_re + 16 * kDCol;
@@ -416,6 +436,13 @@ __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, f
       continue;
     }
     const float2 val = make_float2((float)u[ka].x, (float)u[ka].y);
+    if (hist) {                          // (kernel-uniform) |X|^2 of the rounded bin into its row's band sums
+      float* const hslot = hist + (int64_t)blockIdx.y * hist_rows * kRowBands;
+      const float e = val.x * val.x + val.y * val.y;
+      if (ka < 8) row_band_sums(e, idx, hslot + (int64_t)row * kRowBands);
+      else if (mirror > 0 && row > 0 && 2 * row < mirror)               // workgroup-uniform
+        row_band_sums(e, kRowLenDev - 1 - idx, hslot + (int64_t)(mirror - row) * kRowBands);
+    }
     if (mirror == 0) {
       if (256 * ka < out_len) o[(int64_t)row * kRowLenDev + idx] = val;
     } else if (idx < kRowLenDev / 2) {
@@ -575,12 +602,14 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
 
 hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
                              const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st,
-                             int comb_a, int comb_n, int64_t p_true) {
+                             int comb_a, int comb_n, int64_t p_true, float* hist, int hist_rows) {
   if (comb_n > 1 && (mirror == 0 || comb_a < 0 || comb_a >= comb_n || ilog2_64(p_true) > 24)) return hipErrorInvalidValue;
+  // band sums: every row k1 of the spectrum's positive half once -- from its own workgroup or, reflected, from its twin's
+  if (hist && (comb_n > 1 || out_len < kRowLenDev / 2 || hist_rows != (mirror > 0 ? mirror : n_rows))) return hipErrorInvalidValue;
   hipError_t e = allow_lds(k_fwd64_rows, kFwd64Lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fwd64_rows, dim3(n_rows, n_slots), dim3(256), kFwd64Lds, st, y, x, y_cstride, x_cstride,
-                     tables, out_len, mirror, comb_a, comb_n, comb_n > 1 ? ilog2_64(p_true) : 0);
+                     tables, out_len, mirror, comb_a, comb_n, comb_n > 1 ? ilog2_64(p_true) : 0, hist, hist_rows);
   return hipGetLastError();
 }
 

@@ -309,7 +309,7 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
 // comb_n > 1 (long mode): subsequence comb_a of comb_n, accumulated into x with the twiddle W_p_true^(a k)
 hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
                              const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st,
-                             int comb_a = 0, int comb_n = 1, int64_t p_true = 0);
+                             int comb_a = 0, int comb_n = 1, int64_t p_true = 0, float* hist = nullptr, int hist_rows = 0);
 
 // precision = auto (detect.hip): what the float32 stages of the decimated path will cost each scale, predicted from
 // the float64 spectrum while it is made.  The positive half of the spectrum is summed into bands, sixteen per octave:
@@ -336,10 +336,14 @@ struct PredLevel {
 // ~2^-24 of the level's content, against the scale's own output -- and oob_tol sqrt(E_out / E_s), E_out what the
 // level's x_R leaves out (the reference's kernel answers to it through its side lobes; the decimated path does
 // not).  scale_level[s] < 0: not on the decimated path.  dbg_scale: [slots][2][S], the two terms.
-// hist: [slots][p1][kSpecBands], the energy |X|^2 of bins 0 < k < P / 2 of the k1-major spectrum x ([slot][p1 rows][4096],
-// bin k1 + p1 k2 at (k1, k2)) summed into bands per (slot, row); plain stores, no reset needed
-hipError_t launch_spectrum_bands(const float2* x, int64_t x_cstride, int p1, float* hist, int n_slots, hipStream_t st);
-hipError_t launch_precision_predict(const float* hist, int n_rows, const float* gain, const int32_t* scale_level,
+// hist: [slots][p1][kRowBands], the energy |X|^2 of the bins 0 <= k < P / 2 of the k1-major spectrum ([slot][p1 rows][4096],
+// bin k1 + p1 k2 at (k1, k2)) per (slot, row k1): entries [0, 16) the bins k2 < 16 one by one, [16, 128) the bands of
+// k2 = 16 .. 2047 (band of k = band of k2 + 16 log2 p1 there) -- written by the forward row pass itself (fwd64.hip:
+// row_band_sums; plain stores, every entry every time).  launch_band_sums adds the rows up, in row order, into
+// bands: [slots][kSpecBands] (bin 0 left out).
+constexpr int kRowBands = 128;
+hipError_t launch_band_sums(const float* hist, int p1, float* bands, int n_slots, hipStream_t st);
+hipError_t launch_precision_predict(const float* bands, const float* gain, const int32_t* scale_level,
                                     const int32_t* scale_length, const PredLevel* levels, int n_scales, int n_levels, double p_true,
                                     float kappa_eps, float oob_tol, float* pred, float* dbg_level, float* dbg_scale,
                                     int n_slots, const PredSegs& segs, hipStream_t st);

@@ -519,9 +519,9 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   if (prm.n_channels <= 0) return fail(GCWT_ERR_INVALID, "n_channels must be positive");
   if (prm.n_channels > 65535) return fail(GCWT_ERR_UNSUPPORTED, "n_channels > 65535 per plan");
   if (prm.n_freqs <= 0 || !prm.freqs_hz) return fail(GCWT_ERR_INVALID, "no analysis frequencies");
-  if (!(prm.fs > 0)) return fail(GCWT_ERR_INVALID, "Sampling rate must be positive");
-  if (!(prm.gamma > 0)) return fail(GCWT_ERR_INVALID, "gamma must be positive");
-  if (!(prm.beta > 0)) return fail(GCWT_ERR_INVALID, "beta must be positive");
+  if (!(prm.fs > 0) || !std::isfinite(prm.fs)) return fail(GCWT_ERR_INVALID, "Sampling rate must be positive and finite");
+  if (!(prm.gamma > 0) || !std::isfinite(prm.gamma)) return fail(GCWT_ERR_INVALID, "gamma must be positive and finite");
+  if (!(prm.beta > 0) || !std::isfinite(prm.beta)) return fail(GCWT_ERR_INVALID, "beta must be positive and finite");
   if (prm.wavelet_flags < 0 || (prm.wavelet_flags & ~(0xff | GCWT_WAVELET_ENERGY)) || (prm.wavelet_flags & 0xff) > 32)
     return fail(GCWT_ERR_INVALID, "bad wavelet_flags (order 0..32, GCWT_WAVELET_ENERGY)");
   if (prm.out_mode < 0 || prm.out_mode > 2) return fail(GCWT_ERR_INVALID, "bad out_mode");
@@ -564,6 +564,15 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
     if (s < 0 || t > prm.n_samples || t <= s)
       return fail(GCWT_ERR_INVALID, "epoch bounds outside the data or empty");
   }
+  if (n_ep > 1) {
+    // epochs are disjoint runs of samples (utils.py:3-42 cuts the recording where its clock jumps): two that share a
+    // sample would both write it
+    std::vector<std::pair<int64_t, int64_t>> runs;
+    for (int e = 0; e < n_ep; ++e) runs.push_back({hp->bounds[2 * e], hp->bounds[2 * e + 1]});
+    std::sort(runs.begin(), runs.end());
+    for (int e = 1; e < n_ep; ++e)
+      if (runs[e].first < runs[e - 1].second) return fail(GCWT_ERR_INVALID, "epoch bounds overlap");
+  }
   {
     // how full the 4096-sample blocks of the block convolution would be: a block costs the same however little
     // of an epoch it holds (plan_blockconv weighs that against the time domain)
@@ -596,7 +605,10 @@ int build_host_plan(const gcwt_params& prm, HostPlan* hp, std::string* err) {
   for (int i = 0; i < prm.n_freqs; ++i) {
     ScalePlan& sp = hp->scales[i];
     sp.freq_hz = hp->freqs[i];
-    if (!(sp.freq_hz > 0)) return fail(GCWT_ERR_INVALID, "analysis frequencies must be positive");
+    // (the reference clamps its grid to the wavelet's range, transforms.py:412-431 -- at most 0.39 fs for the default
+    // wavelet; beyond Nyquist a sampled kernel means nothing, and inf / nan would plan a one-tap "kernel")
+    if (!(sp.freq_hz > 0) || !std::isfinite(sp.freq_hz)) return fail(GCWT_ERR_INVALID, "analysis frequencies must be positive and finite");
+    if (sp.freq_hz > 0.5 * prm.fs) return fail(GCWT_ERR_INVALID, "analysis frequency above the Nyquist frequency fs / 2");
     sp.omega = sp.freq_hz / (prm.fs / 2.0) * M_PI;                    // transforms.py:408-410
     sp.length = (int64_t)std::ceil(hp->w0 / sp.omega * hp->base_length);  // morse.py:118-122
     if (sp.length < 1) sp.length = 1;

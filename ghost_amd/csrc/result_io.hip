@@ -35,17 +35,19 @@ __global__ void __launch_bounds__(256) k_widen_rows(const float* __restrict__ sr
   }
 }
 
+// one per device: a process that drives several (ghost_amd/multi.py: one host thread per device slot) drains them side
+// by side, each over its own link; two drains from the same device take turns
 struct ResultIo {
   std::mutex mu;
   hipStream_t stream = nullptr;
   double* d_stage = nullptr;            // widened chunk on the device
   size_t stage_elems = 0;
   HostOut ring;                         // destinations that are not page-locked
-  int device = -1;
 };
-ResultIo& io() {
-  static ResultIo s;
-  return s;
+constexpr int kMaxDevices = 64;
+ResultIo& io(int device) {
+  static ResultIo* const s = new ResultIo[kMaxDevices];      // never destroyed: nothing of HIP runs at process exit
+  return s[device];
 }
 constexpr size_t kStageElems = (size_t)16 << 20;   // 128 MB of doubles
 
@@ -54,18 +56,13 @@ constexpr size_t kStageElems = (size_t)16 << 20;   // 128 MB of doubles
 hipError_t rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, int64_t row_elems, void* dst,
                         int64_t dst_pitch, bool widen, bool pinned) {
   if (n_rows <= 0 || row_elems <= 0) return hipSuccess;
-  ResultIo& s = io();
-  std::lock_guard<std::mutex> lock(s.mu);
   hipPointerAttribute_t attr;
   hipError_t e = hipPointerGetAttributes(&attr, d_src);
   if (e != hipSuccess) return e;
-  if ((e = hipSetDevice(attr.device)) != hipSuccess) return e;
-  if (s.device != attr.device) {        // (a process that moves to another device: the stream and the staging buffer follow)
-    if (s.stream) { (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
-    if (s.d_stage) { (void)hipFree(s.d_stage); s.d_stage = nullptr; s.stage_elems = 0; }
-    s.ring.release();
-    s.device = attr.device;
-  }
+  if (attr.device < 0 || attr.device >= kMaxDevices) return hipErrorInvalidDevice;
+  if ((e = hipSetDevice(attr.device)) != hipSuccess) return e;      // (the calling thread's device, from here on)
+  ResultIo& s = io(attr.device);
+  std::lock_guard<std::mutex> lock(s.mu);
   if (!s.stream && (e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return e;
   if (!pinned) {
     if (dst_pitch != row_elems) return hipErrorInvalidValue;   // the staging ring scatters into dense rows

@@ -175,8 +175,9 @@ class CwtPlan:
         if not 0 <= int(order) <= 32:
             raise ValueError("order must be between 0 and 32")
         p.wavelet_flags = int(order) | (_lib.WAVELET_ENERGY if normalization == "energy" else 0)
-        # 'high' (default): float64 forward transform and per-level low cut, the reference's dynamic
-        # range (it computes in float64: transforms.py:142-143); 'fast': float32 throughout
+        # 'auto' (default): float64 forward transform and per-level low cut, the reference's dynamic range (it
+        # computes in float64: transforms.py:142-143), with the scales at risk recomputed exactly; 'high': the same
+        # without the recomputation; 'fast': float32 throughout; 'exact': no decimated path
         if precision not in (None, "default", "auto", "fast", "high", "exact"):
             raise ValueError("precision must be 'auto', 'fast', 'high' or 'exact'")
         p.precision = {None: 0, "default": 0, "auto": 4, "fast": 1, "high": 2, "exact": 3}[precision]
@@ -243,12 +244,15 @@ class CwtPlan:
 
     def debug_precision_terms(self):
         """The two terms of the last execute's prediction (slot 0 of its last batch): float32 rounding of the level's
-        stages, and what the level's slice of the spectrum leaves out; plus the energy each level's x_R held."""
+        stages, and what the level's slice of the spectrum leaves out; plus the energy each level's x_R held and the
+        spectrum's band energies (sixteen bands per octave of the bin index) all of it is predicted from."""
         a, b = np.zeros(self.n_freqs, np.float32), np.zeros(self.n_freqs, np.float32)
         lv = np.zeros(max(1, self.info["n_levels"]), np.float32)
+        bands = np.zeros(384, np.float32)
         f32p = C.POINTER(C.c_float)
-        check(lib.gcwt_debug_precision_terms(self._handle, a.ctypes.data_as(f32p), b.ctypes.data_as(f32p), lv.ctypes.data_as(f32p)))
-        return {"rounding": a, "left_out": b, "level_energy": lv}
+        check(lib.gcwt_debug_precision_terms(self._handle, a.ctypes.data_as(f32p), b.ctypes.data_as(f32p), lv.ctypes.data_as(f32p),
+                                             bands.ctypes.data_as(f32p)))
+        return {"rounding": a, "left_out": b, "level_energy": lv, "band_energy": bands}
 
     def timings(self):
         t = _lib.Timings()

@@ -63,14 +63,17 @@ class ContinuousWaveletTransform(WaveletTransform):
         Parameters are those of ghost/wave/transforms.py:59-107: ``timestamps``,
         ``fs``, ``freq_limits``, ``freqs``, ``voices_per_octave``, ``parallel``
         (validated, then ignored: the GPU does all scales at once), ``verbose``.
-        Beyond the reference: ``multichannel``, ``output`` ('amplitude', 'power', 'complex'), ``dtype``,
+        Beyond the reference: ``multichannel``, ``devices`` (with ``multichannel=True``: the GPUs the channels are
+        sharded over, contiguous blocks, one plan and one host thread each -- ghost_amd/multi.py; the results stay on
+        their devices and ``amplitude`` / ``fetch()`` stitch them), ``output`` ('amplitude', 'power', 'complex'), ``dtype``,
         ``lazy`` (default True: the result stays on the device when transform() returns and crosses PCIe on first
         access to ``amplitude`` / ``power`` / ``coefficients`` -- or piecewise through ``fetch()`` --; False: it is on
         the host when transform() returns, as in the reference),
-        ``device`` and ``precision`` ('high', the default: the forward FFT in float64 like the reference's
-        arithmetic, transforms.py:142-143; 'fast': float32 throughout; 'exact': every scale by FFT convolution
-        with its literal kernel, 3 - 5 x slower, for recordings with interference far above the signal inside the
-        analysed band).
+        ``device`` and ``precision`` ('auto', the default: the forward FFT in float64 like the reference's
+        arithmetic, transforms.py:142-143, and the scales a mains line or the like inside their decimation band
+        would cost more than 1.5e-6 of their peak are recomputed by exact FFT convolution, logged; 'high': the same
+        without the recomputation, it only warns; 'fast': float32 throughout; 'exact': every scale by FFT
+        convolution with its literal kernel, 3 - 9 x slower).
         """
         if multichannel is None:
             multichannel = False
@@ -95,7 +98,7 @@ class ContinuousWaveletTransform(WaveletTransform):
 
     def _run(self, data, *, squeeze, timestamps=None, fs=None, freq_limits=None, freqs=None,
              voices_per_octave=None, parallel=None, verbose=None, output=None, dtype=None,
-             device=None, precision=None, lazy=None, **kwargs):
+             device=None, devices=None, precision=None, lazy=None, **kwargs):
         self.fs = fs                        # validates (transforms.py:109)
         self._time = timestamps
 
@@ -122,6 +125,16 @@ class ContinuousWaveletTransform(WaveletTransform):
             raise ValueError("'output' must be 'amplitude', 'power' or 'complex'")
         if dtype is None:
             dtype = np.float64
+        if devices is not None:
+            # several GPUs of one node: contiguous channel blocks, one plan and one host thread per entry
+            # (ghost_amd/multi.py); an entry may repeat (two slots on one device)
+            if device is not None:
+                raise ValueError("'device' and 'devices' cannot both be used")
+            devices = [int(d) for d in np.atleast_1d(devices)]
+            if not devices or min(devices) < 0:
+                raise ValueError("'devices' must be a non-empty list of device indices")
+            if len(devices) == 1:
+                device, devices = devices[0], None
         if device is None:
             device = -1
         if lazy is None:
@@ -169,6 +182,7 @@ class ContinuousWaveletTransform(WaveletTransform):
         self._wavelet.fs = self._fs                            # transforms.py:179
 
         from ..engine import CwtPlan   # needs the built library; no CPU fallback
+        from .. import _lib
         if precision not in (None, "auto", "high", "fast", "exact"):
             raise ValueError("'precision' must be 'auto' (default: 'high', with the scales a strong in-band "
                              "interferer would cost their low bits made again by the exact paths), 'high' (the "
@@ -176,13 +190,22 @@ class ContinuousWaveletTransform(WaveletTransform):
                              "throughout) or 'exact' (no decimated path: every scale's float32 stages see only what "
                              "its own filter lets through)")
         key = (n_samples, n_channels, float(self._fs), f.tobytes(), float(self._wavelet.gamma),
-               float(self._wavelet.beta), epoch_bounds.tobytes(), output, int(device), precision)
+               float(self._wavelet.beta), epoch_bounds.tobytes(), output, int(device), precision,
+               None if devices is None else tuple(devices))
         if self._plan is None or self._plan_key != key:
             if self._plan is not None:
                 self._plan.close()
-            self._plan = CwtPlan(n_samples, n_channels, self._fs, f, gamma=self._wavelet.gamma,
-                                 beta=self._wavelet.beta, epoch_bounds=epoch_bounds,
-                                 output=output, device=device, precision=precision)
+                self._plan = None
+            if devices is not None and n_channels > 1:
+                from ..multi import ShardedPlan
+                self._plan = ShardedPlan(n_samples, n_channels, self._fs, f, devices, gamma=self._wavelet.gamma,
+                                         beta=self._wavelet.beta, epoch_bounds=epoch_bounds,
+                                         output=output, precision=precision)
+            else:
+                self._plan = CwtPlan(n_samples, n_channels, self._fs, f, gamma=self._wavelet.gamma,
+                                     beta=self._wavelet.beta, epoch_bounds=epoch_bounds,
+                                     output=output, device=device if devices is None else devices[0],
+                                     precision=precision)
             self._plan_key = key
         self._plan.set_profiling(bool(verbose))
         start_time = time.time()
@@ -190,6 +213,8 @@ class ContinuousWaveletTransform(WaveletTransform):
         # (transforms.py:203-204, 496-527) is brought over by the first access to the attribute: into page-locked
         # memory at the link's rate; float64 (the reference's dtype) crosses as float32 and is widened as it lands.
         self._amplitude = self._power = self._coefficients = None
+        # (the device buffer of the previous call is reused: until this execute has succeeded nothing describes it)
+        self._pending = None
         self._device_result = self._plan.execute_resident(x, self._device_result)
         self._pending = (output, np.dtype(dtype), squeeze)
         # the detector's verdict (precision 'auto' / 'high': DESIGN.md 3): scales whose decimation level holds far more
@@ -198,7 +223,12 @@ class ContinuousWaveletTransform(WaveletTransform):
         self.precision_report = None
         if precision in (None, "auto", "high"):
             rep = self.precision_report = self._plan.precision_report()
-            if rep["rerouted"]:
+            if rep["rerouted"] < 0:
+                logging.warning("{} of {} scales are predicted to lose up to {:.1e} of their peak to the float32 stages and "
+                                "could not all be recomputed exactly (no device memory for the exact paths: {}); they hold "
+                                "what precision='high' returns".format(-rep["rerouted"], f.size, rep["worst"],
+                                                                        _lib.lib.gcwt_last_error().decode("utf-8", "replace")))
+            elif rep["rerouted"]:
                 logging.warning("{} of {} scales were recomputed by exact FFT convolution: the recording holds up to {:.0f} x "
                                 "more in their decimation bands than in the scales themselves (predicted float32 loss {:.1e} "
                                 "of a scale's peak; precision='high' skips this, 'exact' does it for every scale)"

@@ -222,8 +222,10 @@ int gcwt_plan_set_profiling(gcwt_plan* plan, int enabled);
 /* After an execute of a plan with precision DEFAULT / AUTO / HIGH: predicted[s] (S floats, may be NULL) is the
  * predicted loss of scale s to the float32 stages of its decimation level, relative to its own output (0 for
  * scales on the exact paths), *worst the largest of them, *n_rerouted how many scales that execute made again by
- * the exact paths (AUTO; 0 for HIGH).  The reference needs no such thing: it is float64 end to end
- * (transforms.py:142-143). */
+ * the exact paths (AUTO; 0 for HIGH).  Negative: that many scales were over the threshold and some of them could NOT
+ * be made again -- no device memory for the exact sub-plan (gcwt_last_error tells) -- so their rows are the fast
+ * path's, what HIGH returns; the execute itself succeeded.  The reference needs no such thing: it is float64 end
+ * to end (transforms.py:142-143). */
 int gcwt_plan_precision_report(const gcwt_plan* plan, float* predicted, float* worst, int32_t* n_rerouted);
 /* Row pitch, in samples, of DEVICE output buffers (0 = dense rows of N, or of the block
  * length).  Rows whose byte offset is not a multiple of 128 make every store straddle

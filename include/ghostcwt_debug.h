@@ -41,9 +41,12 @@ int gcwt_debug_scale_theta_lo(const gcwt_plan* plan, double* theta_lo);
  * instantiated, 0 = none (yet), -1 = capture failed once and the plan runs eagerly. */
 int gcwt_debug_graph_state(const gcwt_plan* plan);
 /* precision = auto / high: the two terms of the last execute's prediction for workspace slot 0 of its last batch
- * (S floats each: float32 rounding of the level's stages; what the level's slice of the spectrum leaves out) and
- * the energy each level's x_R held (one float per level; may be NULL). */
-int gcwt_debug_precision_terms(gcwt_plan* plan, float* rounding, float* left_out, float* level_energy);
+ * (S floats each: float32 rounding of the level's stages; what the level's slice of the spectrum leaves out), the
+ * energy each level's x_R held (one float per level; may be NULL) and the band energies they come from (384 floats,
+ * may be NULL: sum of |X[k]|^2 over the bins 0 < k < P / 2 of band (bits of (float) k >> 19) - 127 * 16, sixteen
+ * bands per octave -- summed by the forward row pass, csrc/fwd64.hip: row_band_sums). */
+int gcwt_debug_precision_terms(gcwt_plan* plan, float* rounding, float* left_out, float* level_energy,
+                               float* band_energy);
 /* Block convolution (GCWT_SCALE_BLOCKCONV): the scales in order of kernel length (`order`: n_blockconv entries, at
  * most max_order are written) and the groups of consecutive entries that share the spectra of their blocks (at
  * most max_groups are written): blocks of `hop` output samples from the 4096 recording samples that start `back`

@@ -1342,3 +1342,48 @@ def test_time_domain_kernel_every_alignment_and_edge(option):
             for start, length in [(1, 2047), (2049, 2050), (2502, 3698), (3, 1)]:
                 blk = p.execute_block(x, start, length)
                 np.testing.assert_array_equal(blk, got[:, :, start:start + length])
+
+
+def test_devices_list_shards_the_channels_over_device_slots(golden):
+    """``transform(multichannel=True, devices=[...])``: contiguous channel blocks, one plan and one host thread per
+    entry (ghost_amd/multi.py; SURVEY 8(e): channels are independent, transforms.py:57-58; config 4's split).  An entry
+    may repeat, so a one-GPU box runs two and three slots on its one device: the rows must be the bits one plan over
+    all the channels makes, whole (``amplitude``) and piecewise (``fetch`` across a shard boundary), and the goldens
+    of the reference hold for them."""
+    from ghost_amd.wave import ContinuousWaveletTransform
+    from ghost_amd.multi import ShardedResult
+    from ghost_amd.synthetic import lfp
+    g = golden("g8_multichannel.npz")
+    kw = dict(fs=1000.0, freq_limits=[20, 250], voices_per_octave=4, multichannel=True, dtype=np.float32)
+    one = ContinuousWaveletTransform(); one.transform(g["x"], **kw)
+    two = ContinuousWaveletTransform(); two.transform(g["x"], devices=[0, 0], **kw)
+    assert isinstance(two.device_result, ShardedResult) and [p[:2] for p in two.device_result.parts] == [(0, 2), (2, 3)]
+    np.testing.assert_allclose(two.frequencies, g["frequencies"], rtol=1e-14)
+    assert two.amplitude.shape == g["amplitude"].shape
+    np.testing.assert_array_equal(two.amplitude, one.amplitude)
+    for c in range(3):
+        assert rel_err(two.amplitude[c], g["amplitude"][c]).max() < TOL
+    with pytest.raises(ValueError):
+        two.transform(g["x"], devices=[0, 0], device=0, **kw)
+    with pytest.raises(ValueError):
+        two.transform(g["x"], devices=[], **kw)
+    # 128 channels (the headline's count) in two and three slots, float64 power, a second call on the same object
+    x = np.tile(lfp(8, 100000), (16, 1)) * np.linspace(0.5, 2.0, 128, dtype=np.float32)[:, None]
+    kw = dict(fs=1000.0, freq_limits=[2, 200], voices_per_octave=4, multichannel=True, output="power")
+    one = ContinuousWaveletTransform(); one.transform(x, **kw)
+    ref = one.power
+    for devs, blocks in (([0, 0], [(0, 64), (64, 128)]), ([0, 0, 0], [(0, 43), (43, 86), (86, 128)])):
+        many = ContinuousWaveletTransform()
+        for rep in range(2):
+            many.transform(x if rep == 0 else x[::-1].copy(), devices=devs, **kw)
+        many.transform(x, devices=devs, **kw)
+        assert [p[:2] for p in many.device_result.parts] == blocks
+        assert many.device_result.shape == (128, len(many.frequencies), 100000)
+        piece = many.fetch(scales=slice(3, 9), start=777, stop=5003)           # across every shard boundary
+        np.testing.assert_array_equal(piece, ref[:, 3:9, 777:5003])
+        assert many.power.dtype == np.float64
+        np.testing.assert_array_equal(many.power, ref)
+        rep = many.precision_report
+        assert rep["rerouted"] == 0 and len(rep["per_device"]) == len(devs)
+        many.release_device()
+        assert many.device_result is None

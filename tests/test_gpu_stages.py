@@ -91,3 +91,42 @@ def test_config1_complex_vs_golden(golden):
     err = rel_err(out[0][:, g["cols"]], g["complex_cols"])
     print("config1 complex rel err per scale:", err)
     assert err.max() < 1e-5
+
+
+@pytest.mark.parametrize("n, f_hi, f_lo, gamma_beta", [(3000, 200.0, 20.0, (3, 20)), (16384, 200.0, 5.0, (3, 20)),
+                                                       (300000, 200.0, 2.0, (3, 20)), (1000000, 200.0, 2.0, (3, 20)),
+                                                       (2000000, 200.0, 1.0, (3, 20)), (1000000, 100.0, 0.1, (3, 4))])
+def test_band_energies_of_the_detector_are_those_of_the_spectrum(n, f_hi, f_lo, gamma_beta):
+    """precision = 'auto' predicts from the spectrum's band energies, sixteen bands per octave of the bin index
+    (kernels.h: spec_band).  They are summed inside the forward row pass (fwd64.hip: row_band_sums -- wave butterflies
+    over aligned runs of k2, the reflected rows from their twins) and added up row by row (detect.hip: k_band_sums):
+    here against |FFT|^2 of the same recording, for FFT lengths 2^12 .. 2^21 -- one row, radix-2 columns, two real
+    columns per transform, subsequences -- and for a plan with a full-band scale beside the decimated ones
+    (Morse(3, 4) down to 0.1 Hz), which makes every row of the spectrum itself instead of reflecting half of them.
+    The recording carries a mains line 40 x its spread: one bin that must land in its band and nowhere else."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp
+    fs = 1000.0
+    x = lfp(1, n)[0].astype(np.float64)
+    x += 40.0 * x.std() * np.sin(2 * np.pi * 60.0 * np.arange(n) / fs)
+    x = x.astype(np.float32)
+    f = np.geomspace(f_hi, f_lo, 24)
+    plan = CwtPlan(n, 1, fs, f, gamma=gamma_beta[0], beta=gamma_beta[1], precision="auto")
+    if gamma_beta != (3, 20):
+        assert set(plan.scale_info()["method"].tolist()) >= {0, 2}           # decimated and full-band scales
+    plan.execute(x[None, :])
+    got = plan.debug_precision_terms()["band_energy"].astype(np.float64)
+    P = plan.info["fft_length"]
+    xc = x.astype(np.float64) - x.astype(np.float64).mean()
+    E = np.abs(fft(xc, n=P)[1:P // 2]) ** 2
+    band = (np.arange(1, P // 2, dtype=np.float32).view(np.uint32) >> 19).astype(np.int64) - 127 * 16
+    ref = np.bincount(band, weights=E, minlength=384)[:384]
+    assert got.shape == (384,)
+    assert np.all(got[ref == 0] == 0)
+    assert np.abs(got - ref).max() < 1e-5 * ref.max()
+    big = ref > 1e-6 * ref.max()
+    assert np.abs(got[big] / ref[big] - 1).max() < 2e-5, np.abs(got[big] / ref[big] - 1).max()
+    # twice the same bits: fixed order of every sum
+    plan.execute(x[None, :])
+    again = plan.debug_precision_terms()["band_energy"]
+    assert np.array_equal(again.view(np.uint32), got.astype(np.float32).view(np.uint32))

@@ -259,14 +259,24 @@ def test_operator_entry_points_validate_then_need_a_device():
 
 
 def test_planner_rejects_bad_requests():
+    inf, nan = float("inf"), float("nan")
     for kw in (dict(n_samples=0), dict(fs=-1.0), dict(freqs=[-5.0]), dict(gamma=0.0),
-               dict(bounds=[[0, 20000]]), dict(bounds=[[5, 5]])):
+               dict(bounds=[[0, 20000]]), dict(bounds=[[5, 5]]),
+               # not a frequency: inf and 1e300 used to plan a one-tap "kernel", nan a length of INT64_MIN
+               dict(freqs=[inf]), dict(freqs=[10.0, nan]), dict(freqs=[1e300]), dict(freqs=[500.1]),
+               dict(fs=inf), dict(fs=nan), dict(gamma=inf), dict(gamma=nan),
+               # epochs that share samples: both would write them
+               dict(bounds=[[0, 6000], [5999, 10000]]), dict(bounds=[[4000, 10000], [0, 4001]]),
+               dict(bounds=[[0, 100], [0, 100]])):
         args = dict(n_samples=10000, fs=1000.0, freqs=[10.0], gamma=3.0, bounds=None)
         args.update(kw)
         with pytest.raises(GhostCwtError) as e:
             CwtPlan(args["n_samples"], 1, args["fs"], args["freqs"], gamma=args["gamma"],
                     epoch_bounds=args["bounds"])
         assert e.value.code == _lib.ERR_INVALID
+    # touching epochs in any order, and the Nyquist frequency itself, are requests
+    CwtPlan(10000, 1, 1000.0, [10.0], epoch_bounds=[[6000, 10000], [0, 6000]])
+    CwtPlan(10000, 1, 1000.0, [500.0])
     # a 3.2 M-tap kernel: refused until round 4, FFTs of 2^23 points (long mode) since
     assert CwtPlan(1 << 20, 1, 30000.0, [0.13]).segments()[0][2] == 1 << 23
     with pytest.raises(GhostCwtError) as e:
@@ -730,3 +740,35 @@ def test_pinned_result_pool_falls_back_without_a_device():
     assert not hostmem.is_pinned(np.zeros(3))
     assert hostmem.empty((0, 5), np.float32) is None
     hostmem.trim()
+
+
+def test_devices_list_makes_one_plan_per_slot_and_needs_a_device():
+    """``devices=[...]`` (ghost_amd/multi.py): the channel blocks are ``dist.shard_channels``' (contiguous, sizes differ
+    by one at most), a slot never stays empty, planning is host work -- and executing without a GPU fails as loudly as
+    one plan does (no CPU path)."""
+    from ghost_amd.multi import ShardedPlan
+    from ghost_amd.wave import ContinuousWaveletTransform
+    f = np.geomspace(200.0, 5.0, 12)
+    sp = ShardedPlan(20000, 10, 1000.0, f, [0, 1, 2, 3], output="power")
+    assert sp.blocks == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [p.n_channels for p in sp.plans] == [3, 3, 2, 2] and sp.out_shape == (10, 12, 20000)
+    assert sp.info["workspace_bytes"] == sum(p.info["workspace_bytes"] for p in sp.plans)
+    sp.close()
+    sp = ShardedPlan(20000, 2, 1000.0, f, [0, 1, 2, 3])
+    assert sp.devices == [0, 1] and sp.blocks == [(0, 1), (1, 2)]
+    x = np.zeros((2, 20000), np.float32)
+    if not _lib_has_device():
+        with pytest.raises(GhostCwtError) as e:
+            sp.execute_resident(x)
+        assert e.value.code == _lib.ERR_NO_DEVICE
+    sp.close()
+    cwt = ContinuousWaveletTransform()
+    for bad in (dict(devices=[]), dict(devices=[-1, 0]), dict(devices=[0, 1], device=0)):
+        with pytest.raises(ValueError):
+            cwt.transform(x, fs=1000.0, multichannel=True, **bad)
+
+
+def _lib_has_device():
+    import ctypes
+    n = ctypes.c_int(0)
+    return _lib.lib.gcwt_device_count(ctypes.byref(n)) == 0 and n.value > 0
