@@ -70,6 +70,8 @@ struct EpochDev {
   int n_items7 = 0;
   Synth7Item* items7w = nullptr;     // ... its wide-halo instantiation (shifted-band levels with halo > 48)
   int n_items7w = 0;
+  Synth7Item* items7n = nullptr;     // ... its 16-column instantiation (R = 2: gcwt_plan::synth7_narrow_r)
+  int n_items7n = 0;
   SynthiItem* items_i = nullptr;     // interpolating kernel (synthi.hip)
   SynthiLevel* levels_i = nullptr;
   int n_items_i = 0;
@@ -92,6 +94,11 @@ struct gcwt_plan {
   bool uploaded = false;
   bool profiling = false;
   int synth_cols = 32;        // columns per workgroup of k_synth7 (GHOSTCWT_SYNTH_COLS=16|32)
+  int synth7_narrow_r = 2;    // option synth7_narrow_r: levels of decimation <= this take the 16-column instantiation whatever
+                              // synth_cols says (0: none).  R = 2 has seven scales on the headline grid, so a workgroup's prologue
+                              // (its blocks' samples, their transforms) is a quarter of its life; 256-thread workgroups are three
+                              // to a CU instead of two and hide it better: 1.17 against 1.26 ms for the level, while R = 4 and 8
+                              // (fifteen scales) lose 8 % that way (profiles/r06_bound.md 5)
   bool fuse_blocks = true;    // k_synth7 makes its own block spectra from x_R (GHOSTCWT_FUSE_BLOCKS=0: separate pass)
   int synth_kernel = 7;       // 7: k_synth7; 8 (measure build only): producer/consumer waves (synth8.hip,
                               // measured slower: DESIGN.md 5) -- GHOSTCWT_SYNTH_KERNEL
@@ -256,7 +263,7 @@ void free_dev(gcwt_plan* p) {
   p->hfull_cache.clear();
   p->hfull_cache_bytes = 0;
   p->host_out.release();
-  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.items7w); fr(e.levels7); fr(e.items_i); fr(e.levels_i); fr(e.items_p[0]); fr(e.items_p[1]); fr(e.levels_p); fr(e.pred_levels); }
+  for (auto& e : p->ep_dev) { fr(e.items); fr(e.levels); fr(e.items7); fr(e.items7w); fr(e.items7n); fr(e.levels7); fr(e.items_i); fr(e.levels_i); fr(e.items_p[0]); fr(e.items_p[1]); fr(e.levels_p); fr(e.pred_levels); }
   p->ep_dev.clear();
   if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
   for (auto e : p->ev_pool) (void)hipEventDestroy(e);
@@ -424,6 +431,7 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   // options (options.h): read once, here; an execute never looks at them or at the environment
   p->use_synth16 = option_or("synth16", 0) == 1;
   p->synth_cols = option_or("synth_cols", 32) == 16 ? 16 : 32;
+  p->synth7_narrow_r = (int)option_or("synth7_narrow_r", 2);
   p->fuse_blocks = option_or("fuse_blocks", 1) != 0;
   p->prune_inputs = option_or("prune_inputs", 1) != 0;
   p->fast_fft = option_or("slow_fft", 0) == 0;
@@ -743,7 +751,7 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
                ep.lv[l].xb_offset, hp.levels[l].twiddle_offset};
     if ((rc = upload_vec(&p->ep_dev[e].items, items, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels, lv, p->stream))) return bail(rc);
-    std::vector<Synth7Item> items7, items7w;
+    std::vector<Synth7Item> items7, items7w, items7n;
     std::vector<Synth7Level> lv7(hp.levels.size());
     for (size_t l = 0; l < lv7.size(); ++l) {
       const LevelPlan& lp = hp.levels[l];
@@ -752,11 +760,13 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
       lv7[l] = {lp.decimation, lg, lp.hop, lp.halo, ep.lv[l].nblk, (int32_t)lp.scales.size(),
                 scale_off[l], ep.lv[l].blk_lo, n_plain[l], (int32_t)(l * 256), lp.band_shift, 0, ep.lv[l].xb_offset,
                 lp.twiddle_offset, ep.lv[l].xr_offset, ep.lv[l].m - 1};
-      const int bpb = std::max(1, p->synth_cols / lp.decimation);
-      const int n_rtiles = std::max(1, lp.decimation / p->synth_cols);
+      const bool narrow = lp.halo <= 48 && lp.decimation <= p->synth7_narrow_r && p->synth_cols == 32;
+      const int cols = narrow ? 16 : p->synth_cols;
+      const int bpb = std::max(1, cols / lp.decimation);
+      const int n_rtiles = std::max(1, lp.decimation / cols);
       if (level_kernel(p, lp) != LK_SYNTH7) continue;
       for (int b0 = 0; b0 < ep.lv[l].nblk; b0 += bpb)
-        for (int rt = 0; rt < n_rtiles; ++rt) (lp.halo > 48 ? items7w : items7).push_back({(int32_t)l, b0, rt, 0});
+        for (int rt = 0; rt < n_rtiles; ++rt) (lp.halo > 48 ? items7w : narrow ? items7n : items7).push_back({(int32_t)l, b0, rt, 0});
     }
     // order of the k_synth7 items (option synth7_order, A/B runs): 0 as listed (levels in plan order, R = 2 first),
     // 1 reversed, 2 the levels' items dealt in turn
@@ -778,6 +788,8 @@ static int gcwt_plan_upload_impl(gcwt_plan* p) {
     }
     p->ep_dev[e].n_items7 = (int)items7.size();
     p->ep_dev[e].n_items7w = (int)items7w.size();
+    p->ep_dev[e].n_items7n = (int)items7n.size();
+    if ((rc = upload_vec(&p->ep_dev[e].items7n, items7n, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].items7, items7, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].items7w, items7w, p->stream))) return bail(rc);
     if ((rc = upload_vec(&p->ep_dev[e].levels7, lv7, p->stream))) return bail(rc);
@@ -1237,7 +1249,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     // fills the other's tail.  Both only read what the level passes left and write disjoint rows.
     hipStream_t si = st;
     if (dev.n_items_i > 0) {
-      const bool beside = p->synth_streams && (dev.n_items7 > 0 || dev.n_items7w > 0 || dev.n_items > 0);
+      const bool beside = p->synth_streams && (dev.n_items7 > 0 || dev.n_items7w > 0 || dev.n_items7n > 0 || dev.n_items > 0);
       if (beside) {
         hipEvent_t levels_done;
         int rc_ = get_event(p, &levels_done);
@@ -1315,15 +1327,17 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       a.seg = sout;
       RUN(ST_SYNTH, launch_synth(mode, a, dev.n_items, slots, st));
     }
-    for (int wide = 0; wide < 2; ++wide) {
-      const int n7 = wide ? dev.n_items7w : dev.n_items7;
+    for (int variant = 0; variant < 3; ++variant) {          // 16 columns (R = 2) first, then the 32-column lists
+      const int wide = variant == 2;
+      const int cols7 = variant == 0 ? 16 : p->synth_cols;
+      const int n7 = variant == 0 ? dev.n_items7n : wide ? dev.n_items7w : dev.n_items7;
       if (n7 == 0) continue;
       Synth7Args a7{};
       a7.xb = p->d_xb;
       a7.bank = p->d_bank;
       a7.tw256 = p->d_tw256;
       a7.level_tw = p->d_level_tw;
-      a7.items = wide ? dev.items7w : dev.items7;
+      a7.items = variant == 0 ? dev.items7n : wide ? dev.items7w : dev.items7;
       a7.levels = dev.levels7;
       a7.scale_list = p->d_scale_list;
       a7.gain = p->d_gain;
@@ -1342,11 +1356,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
         a7.xb_scale = (float)(1.0 / ((double)hp.block * (double)Pt));
       }
 #ifdef GCWT_MEASURE
-      if (p->synth_kernel == 8 && !wide)
+      if (p->synth_kernel == 8 && variant == 1)
         RUN(ST_SYNTH, launch_synth8(mode, p->synth_cols, a7, n7, slots, st));
       else
 #endif
-        RUN(ST_SYNTH, launch_synth7(mode, p->synth_cols, wide != 0, a7, n7, slots, st));
+        RUN(ST_SYNTH, launch_synth7(mode, cols7, wide != 0, a7, n7, slots, st));
     }
     if (si != st) {                        // join: the batch is done when both kernels are
       hipEvent_t interp_done;

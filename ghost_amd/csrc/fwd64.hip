@@ -372,17 +372,69 @@ __device__ __forceinline__ int dpad(int i) { return i + (i >> 4); }
 // two), 2^(e - 4) consecutive k2 of octave e: aligned groups of 1 .. 64 lanes, summed by a butterfly in a fixed order
 // and stored once by the group's first k2 -- no atomics, no staging, the same bits every run.  k2 < 16 (where the
 // band depends on k1 too) are kept bin by bin.  Row layout (kernels.h: kRowBands): [0, 16) those bins, [16, 128) the
-// bands of k2 = 16 .. 2047.  Everything but the values is uniform over the wave's 64-aligned run of k2.
+// bands of k2 = 16 .. 2047.  The butterfly is vector ALU only (DPP within rows of 16 lanes, v_permlane16_swap /
+// v_permlane32_swap across them): through ds_bpermute (__shfl_xor) the 82 exchanges per thread doubled the kernel's
+// LDS instructions and cost more than the separate pass over the spectrum they replace (0.15 against 0.12 ms).
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// own value + the value of the lane 16 (32) away: v_permlane16_swap (v_permlane32_swap) exchanges the odd rows (upper
+// half) of one register with the even rows (lower half) of another, so two copies of e come back as {own, partner} in
+// some order.  Through the builtin hipcc 7.2 takes the two results of a swap of equal operands for one value (it emits
+// e' + e'), hence the instruction itself.
+__device__ __forceinline__ float swap_sum16(float e) {
+  float a = e, b = e;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // (two wait states after the VALU that wrote them)
+  return a + b;
+}
+__device__ __forceinline__ float swap_sum32(float e) {
+  float a = e, b = e;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__host__ __device__ constexpr int band_group_log2(int k2) {      // log2 of the run of k2 that shares k2's band
+  int e = 0;
+  while ((2 << e) <= k2) ++e;                                     // floor(log2 k2), k2 >= 1
+  return k2 < 32 ? 0 : e - 4;
+}
+// D_MAX: the wave's largest group (log2), known at compile time except for k2 < 256 (D_MAX = -1: from the wave's top k2)
+template <int D_MAX>
 __device__ __forceinline__ void row_band_sums(float e, int k2, float* __restrict__ hrow) {
-  const int depth = k2 < 32 ? 0 : 27 - __clz(k2);                                  // log2 of the group: octave - 4
-  const int top = __builtin_amdgcn_readfirstlane(k2 | 63);
-  const int d_max = top < 32 ? 0 : 27 - __clz(top);
-  for (int s = 0; s < d_max; ++s) {
-    const float o = __shfl_xor(e, 1 << s, 64);
-    if (s < depth) e += o;
+  const int depth = k2 < 32 ? 0 : 27 - __clz(k2);
+  int d_max = D_MAX;
+  if (D_MAX < 0) {
+    const int top = __builtin_amdgcn_readfirstlane(k2 | 63);
+    d_max = top < 32 ? 0 : min(3, 27 - __clz(top));     // (k2 < 256: groups of eight at most)
+  }
+  if (d_max >= 1) {                                    // (the one step a wave's lanes may differ in: k2 < 32 keep their own)
+    const float o = dpp_get<0xB1>(e);                  // quad_perm [1, 0, 3, 2]: lane ^ 1
+    e = depth >= 1 ? e + o : e;
+  }
+  if (d_max >= 2) e += dpp_get<0x4E>(e);               // quad_perm [2, 3, 0, 1]: lane ^ 2
+  if (d_max >= 3) e += dpp_get<0x141>(e);              // row_half_mirror: the other quad of the eight (quads are uniform by now)
+  if (d_max >= 4) e += dpp_get<0x140>(e);              // row_mirror: the other eight of the row
+  if (d_max >= 5) {                                    // the neighbouring row of 16
+    e = swap_sum16(e);
+  }
+  if (d_max >= 6) {                                    // the other half of the wave
+    e = swap_sum32(e);
   }
   if ((k2 & ((1 << depth) - 1)) == 0)
     hrow[k2 < 16 ? k2 : 16 + (int)(__float_as_uint((float)k2) >> 19) - (127 * 16 + 64)] = e;
+}
+
+__device__ __forceinline__ void constexpr_band_sums(int ka, float e, int idx, int row, int mirror, float* __restrict__ hslot) {
+  // ka -> the wave's largest group at compile time: 256 .. 511 -> 16 lanes, 512 .. 1023 -> 32, from 1024 on the whole wave
+  const bool up = ka >= 8;
+  if (up && !(mirror > 0 && row > 0 && 2 * row < mirror)) return;                  // workgroup-uniform
+  const int kq = up ? 15 - ka : ka;                                                 // which 256 of the destination row
+  const int k2 = up ? kRowLenDev - 1 - idx : idx;
+  float* const hrow = hslot + (int64_t)(up ? mirror - row : row) * kRowBands;
+  if (kq == 0) row_band_sums<-1>(e, k2, hrow);
+  else if (kq == 1) row_band_sums<4>(e, k2, hrow);
+  else if (kq <= 3) row_band_sums<5>(e, k2, hrow);
+  else row_band_sums<6>(e, k2, hrow);
 }
 
 // comb_n > 1 (long mode): this is subsequence comb_a of comb_n; every output bin k is multiplied by W_pt^(a k),
@@ -439,9 +491,8 @@ __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, f
     if (hist) {                          // (kernel-uniform) |X|^2 of the rounded bin into its row's band sums
       float* const hslot = hist + (int64_t)blockIdx.y * hist_rows * kRowBands;
       const float e = val.x * val.x + val.y * val.y;
-      if (ka < 8) row_band_sums(e, idx, hslot + (int64_t)row * kRowBands);
-      else if (mirror > 0 && row > 0 && 2 * row < mirror)               // workgroup-uniform
-        row_band_sums(e, kRowLenDev - 1 - idx, hslot + (int64_t)(mirror - row) * kRowBands);
+      // (ka is a constant of the unrolled loop: k2 = kb + 256 ka, reflected k2 = 255 - kb + 256 (15 - ka))
+      constexpr_band_sums(ka, e, idx, row, mirror, hslot);
     }
     if (mirror == 0) {
       if (256 * ka < out_len) o[(int64_t)row * kRowLenDev + idx] = val;

@@ -17,7 +17,7 @@ namespace {
 const char* const kSelect[] = {"synth16", "synth_cols", "fuse_blocks", "slow_fft", "level_streams", "interp_grid",
                                "synth_streams", "interp_lgnb", "merge_levels", "split_levels", "interp",
                                "batch_bytes", "stage_floats", "fullband_group", "blockconv",
-                               "direct_max_len", "graphs", "plan_threads", "synthp", "synthp_lgnb", "synthp_help", "fullband_cache_mb", "auto_threshold_ppb", "auto_kappa_ppb", "auto_oob_ppt", "synth7_order", "host_widen", "host_threads", "fullband4", "cu_count"};
+                               "direct_max_len", "graphs", "plan_threads", "synthp", "synthp_lgnb", "synthp_help", "fullband_cache_mb", "auto_threshold_ppb", "auto_kappa_ppb", "auto_oob_ppt", "synth7_order", "host_widen", "host_threads", "fullband4", "cu_count", "synth7_narrow_r"};
 // accuracy-changing or measurement hooks: libghostcwt_measure.so only
 const char* const kMeasureOnly[] = {"halo_margin", "interp_q", "interp_taps", "interp_min_r", "prune_inputs", "clock_phases",
                                     "synth_kernel", "synth_drop_stores", "clock_probe", "synthi_pad_kb"};

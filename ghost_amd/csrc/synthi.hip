@@ -28,6 +28,8 @@
 // workgroups repeat pass A and share B); items are listed largest first.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "interp.h"
 #include "kernels.h"
 #include "options.h"
@@ -339,15 +341,19 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
         // (only those with a sample inside this launch's window: task wt covers s_blk + 256 wt .. + 255)
         const int wt_a = max(it.wt_lo, s_blk >= 0 ? 0 : (-s_blk) >> 8);
         const int wt_b = (int)min((int64_t)it.wt_hi, max((int64_t)0, (w_len - s_blk + 255) >> 8));
-        for (int wt = wt_a + ((wt0 - wt_a) & (kWavesI - 1)); wt < wt_b; wt += kWavesI) {
+        // A wave-task is WHOLE when its 256 samples lie inside the block's kept run and inside the window: true for
+        // all but the first and last one or two of a slot, so the run of whole tasks [f_lo, f_hi) is cut out once per
+        // slot and walked by a loop that tests nothing: one scalar add for the store's offset, one vector add for the
+        // z window's address, the FIR, |.|, one store (round 5's loop spent 30 scalar instructions per task on the
+        // three tests and the tap-count branch: SQ_INSTS_SALU 0.69 of SQ_INSTS_VALU).
+        const int f_lo = max(wt_a, s_blk >= 0 ? 0 : (255 - s_blk) >> 8);
+        const int f_hi = (int)min((int64_t)min(wt_b, tps >> 6), max((int64_t)0, (w_len - s_blk) >> 8));
+        auto edge_task = [&](int wt) {
           const int k = wt * 64 + lane;
-          const int s_first = s_blk + 256 * wt;               // window-relative sample of the wave-task's first
-          const bool whole = wt * 64 + 64 <= tps && s_first >= 0 && (int64_t)s_first + 256 <= w_len;
-          if (whole || k < tps) {
+          if (k < tps) {
             const v2f* const zp = zs + (k >> lgi4);
-            // tap by tap: two (re, im) accumulator pairs live
             v2f are[2], aim[2];
-            if (six) fir_taps<1, kT - 1>(zp, cf, are, aim);   // level-uniform: the rows' middle six taps
+            if (six) fir_taps<1, kT - 1>(zp, cf, are, aim);
             else fir_taps<0, kT>(zp, cf, are, aim);
             float res[4];
 #pragma unroll
@@ -356,24 +362,46 @@ __global__ void __launch_bounds__(kThreadsI, kColsI == 32 ? 4 : 3) k_synthi(cons
               res[2 * pr] = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2v.x) : p2v.x;
               res[2 * pr + 1] = MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2v.y) : p2v.y;
             }
+            // the window's edge (or the block's last samples) runs through this wave-task: one sample at a time,
+            // each under its own test (four plain stores in a row may be merged into one 16-byte store by the
+            // compiler, whose single range check would drop samples inside the window: synthp.hip)
             const int s0 = s_blk + 4 * k;                     // window-relative sample of res[0]
-            if (whole) {                                      // wave-uniform: no lane looks at its own range
-              typedef unsigned v4u __attribute__((ext_vector_type(4)));
-              const v4u pk = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
-                              __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
-              __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (unsigned)s0 * 4u, 0, GCWT_STORE_AUX);
-            } else {
-              // the window's edge (or the block's last samples) runs through this wave-task: one sample at
-              // a time, each under its own test (four plain stores in a row may be merged into one 16-byte store
-              // by the compiler, whose single range check would drop samples inside the window: synthp.hip)
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if ((unsigned)(s0 + i) < (unsigned)w_len)
-                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rsrc,
-                                                        (unsigned)(s0 + i) * 4u, 0, GCWT_STORE_AUX);
-            }
+            for (int i = 0; i < 4; ++i)
+              if ((unsigned)(s0 + i) < (unsigned)w_len)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rsrc,
+                                                      (unsigned)(s0 + i) * 4u, 0, GCWT_STORE_AUX);
           }
+        };
+        int wt = wt_a + ((wt0 - wt_a) & (kWavesI - 1));
+        for (; wt < min(f_lo, wt_b); wt += kWavesI) edge_task(wt);
+        if (wt < f_hi) {
+          // z window of lane-task k = 64 wt + lane: element k >> lgi4, and a wave's tasks are kWavesI apart, so the
+          // window moves by (64 kWavesI) >> lgi4 elements per task whatever the lane (I / 4 <= 256: static_assert above)
+          const v2f* zp = zs + ((wt * 64 + lane) >> lgi4);
+          const int z_step = (64 * kWavesI) >> lgi4;
+          unsigned soff = (unsigned)(s_blk + 256 * wt) * 4u;             // scalar: byte offset of the task's first sample
+          const unsigned voff = (unsigned)lane * 16u;
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          auto whole_task = [&](auto taps) {
+            v2f are[2], aim[2];
+            if constexpr (decltype(taps)::value == 6) fir_taps<1, kT - 1>(zp, cf, are, aim);
+            else fir_taps<0, kT>(zp, cf, are, aim);
+            v4u pk;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const v2f p2v = pk_fma(aim[pr], aim[pr], pk_mul(are[pr], are[pr]));
+              pk[2 * pr] = __builtin_bit_cast(unsigned, MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2v.x) : p2v.x);
+              pk[2 * pr + 1] = __builtin_bit_cast(unsigned, MODE == GCWT_OUT_AMPLITUDE_F32 ? __builtin_amdgcn_sqrtf(p2v.y) : p2v.y);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, voff, soff, GCWT_STORE_AUX);
+            zp += z_step;
+            soff += 1024u * kWavesI;
+          };
+          if (six) for (; wt < f_hi; wt += kWavesI) whole_task(std::integral_constant<int, 6>());
+          else for (; wt < f_hi; wt += kWavesI) whole_task(std::integral_constant<int, 8>());
         }
+        for (; wt < wt_b; wt += kWavesI) edge_task(wt);
       }
     }
     __syncthreads();                        // z is read out before the next pass's exchange overwrites it

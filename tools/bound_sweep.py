@@ -6,7 +6,9 @@ per launch, package W, sclk, mclk, fclk (sysfs, sampled while the kernel runs ba
   energy-bound        -> the time stays about flat while CUs drop and the clock rises towards 2.4 GHz;
   issue/latency-bound -> the time goes as 1 / CUs at once, at an unchanged or higher clock and lower power.
 Groups: k_synthi (R >= 16, 63 scales), k_synth7 (R = 2, 4, 8; 37 scales) and each level alone (BS_LEVELS=1).
-Prints a markdown table; tools/cu_mask_probe.hip gives the same sweep for a pure store kernel and a pure FMA kernel."""
+Prints a markdown table; tools/cu_mask_probe.hip gives the same sweep for a pure store kernel and a pure FMA kernel.
+With the measure build (GHOSTCWT_LIB=ghost_amd/libghostcwt_measure.so BS_PROBE=1) the k_synth7 rows also carry the clock
+the workgroups themselves saw (s_memtime over s_memrealtime, gcwt_debug_clock) next to the sysfs reading."""
 import glob
 import os
 import sys
@@ -89,8 +91,16 @@ groups = [("k_synthi (R >= 16)", f_all[dec >= 16]), ("k_synth7 (R = 2, 4, 8)", f
 if os.environ.get("BS_LEVELS", "0") == "1":
     groups += [("R = %d" % R, f_all[dec == R]) for R in sorted(set(dec.tolist()))]
 
-print("| kernels | scales | CUs | ms | TB/s of rows | ms x CUs / 256 | W | sclk GHz | mclk MHz | fclk MHz |")
-print("|---|---|---|---|---|---|---|---|---|---|")
+probe = os.environ.get("BS_PROBE", "0") == "1"
+if probe:
+    import ctypes
+    from ghost_amd._lib import lib, check
+    set_option("clock_probe", 1)
+only = os.environ.get("BS_ONLY")            # substring of the group names to keep ("synth7", "R = 2", ...)
+if only:
+    groups = [g for g in groups if only in g[0]]
+print("| kernels | scales | CUs | ms | TB/s of rows | ms x CUs / 256 | W | sclk GHz | mclk MHz | fclk MHz | in-kernel GHz |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
 for name, f in groups:
     for n_cu in counts:
         set_option("cu_count", 0 if n_cu >= 256 else n_cu)
@@ -106,7 +116,12 @@ for name, f in groups:
                 pw.append(smp.read())
         t = float(np.median(ts[len(ts) // 3:]))
         m = np.nanmean(np.array(pw), axis=0) if pw else [float("nan")] * 4
-        print("| %s | %d | %d | %.3f | %.2f | %.3f | %.0f | %.2f | %.0f | %.0f |" % (
-            name, len(f), n_cu, t, C * N * len(f) * 4 / t / 1e9, t * n_cu / 256.0, m[0], m[1], m[2], m[3]), flush=True)
+        ghz = float("nan")
+        if probe and plan.info["n_interp"] == 0:
+            g, w = ctypes.c_double(), ctypes.c_double()
+            check(lib.gcwt_debug_clock(plan._handle, ctypes.byref(g), ctypes.byref(w)))
+            ghz = g.value
+        print("| %s | %d | %d | %.3f | %.2f | %.3f | %.0f | %.2f | %.0f | %.0f | %.3f |" % (
+            name, len(f), n_cu, t, C * N * len(f) * 4 / t / 1e9, t * n_cu / 256.0, m[0], m[1], m[2], m[3], ghz), flush=True)
         plan.close(); ob.free()
 set_option("cu_count", 0)
