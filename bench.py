@@ -529,14 +529,18 @@ def run_rank(args):
             cap = ref.get("power_cap_w")
             if sustained:
                 rl["power_w_sustained"], rl["sclk_ghz_sustained"] = sustained["power_w"], sustained["sclk_ghz"]
-            near_cap = cap is not None and ref["power_w_max"] >= 0.9 * cap
-            at_store = bool(ceilings) and achieved >= 0.9 * ceilings["store_pattern_ceiling"]
-            rl["limited_by"] = ("hbm stores (within 10 % of this box's store-pattern ceiling)" if at_store else
-                                "package power (peak %.0f W of the %.0f W cap, mean sclk %.2f GHz)"
-                                % (ref["power_w_max"], cap, ref["sclk_ghz"] or 0.0) if near_cap else
-                                "instruction issue / latency (neither the power cap nor the store ceiling is reached)")
+            # What was measured beside the kernels, not a verdict: the package's peak and mean power against its cap,
+            # the clock the card reported, and how close the launch came to this box's own store-pattern ceiling.  What
+            # these mean for the synthesis is profiles/r06_bound.md's CU-mask sweep (a fixed number of CU-cycles run at
+            # the clock the cap allows; the R = 64 / 128 levels at the store path's rate).
+            rl["limits_measured"] = {
+                "power_w_max": ref["power_w_max"], "power_w_mean": ref["power_w"], "power_cap_w": cap,
+                "power_frac_of_cap": round(ref["power_w_max"] / cap, 3) if cap else None,
+                "sclk_ghz_mean": ref["sclk_ghz"], "sclk_ghz_max": 2.4,
+                "frac_of_store_pattern_ceiling": round(achieved / ceilings["store_pattern_ceiling"], 4) if ceilings else None,
+                "study": "profiles/r06_bound.md"}
         else:
-            rl["power_w"] = rl["sclk_ghz"] = rl["limited_by"] = None   # no readable hwmon: not asserted
+            rl["power_w"] = rl["sclk_ghz"] = rl["limits_measured"] = None   # no readable hwmon
         if not cfg5:
             # SURVEY.md 8d's secondary ceiling, fp32 vector flops.  `reference_method_*`: what the
             # reference's method implies -- one real P-point FFT per channel, one P-point inverse

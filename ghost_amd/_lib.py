@@ -108,6 +108,7 @@ def _load():
         "gcwt_debug_level_low_cut": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
         "gcwt_debug_scale_theta_lo": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "gcwt_debug_graph_state": (C.c_int, [vp]),
+        "gcwt_debug_mean_folded": (C.c_int, [vp]),
         "gcwt_debug_precision_terms": (C.c_int, [vp, f32p, f32p, f32p, f32p]),
         "gcwt_debug_blockconv_groups": (C.c_int, [vp] + [C.POINTER(C.c_int32)] * 5 + [C.c_int, C.c_int]),
         "gcwt_debug_batch_of": (C.c_int, [vp, C.c_int, i32p, i32p]),

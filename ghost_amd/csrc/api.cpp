@@ -127,6 +127,8 @@ struct gcwt_plan {
   int synthp_lgnb = -1;       // option synthp_lgnb: blocks per k_synthp workgroup forced (A/B runs)
   int interp_lgnb = -1;       // option interp_lgnb: blocks per k_synthi workgroup forced (A/B runs)
   int interp_grid = -1;       // GHOSTCWT_INTERP_GRID=0|1: k_synthi's grid order forced (default: by the number of channel slots)
+  bool last_fold = false;     // the last run took the channel sums inside the forward column pass
+  bool fold_mean = true;      // option fold_mean = 0: the channel sums by a pass of their own over x even where the forward column pass could take them (run_pipeline)
   bool synth_streams = false; // GHOSTCWT_SYNTH_STREAMS=1: the interpolating kernel runs beside k_synth7 on aux[0] (its store-bound
                               // workgroups share the CUs with the arithmetic-bound ones: measured equal on the headline,
                               // profiles/r03_synth_study.md); default: one after the other, so that per-kernel times add up
@@ -438,8 +440,9 @@ static int gcwt_plan_create_impl(gcwt_plan** out, const gcwt_params* params) {
   p->level_streams = option_or("level_streams", 1) != 0;
   if (option_is_set("interp_grid")) p->interp_grid = option_or("interp_grid", 0) != 0;
   p->synth_streams = option_or("synth_streams", 0) != 0;
+  p->fold_mean = option_or("fold_mean", 1) != 0;
   p->interp_lgnb = (int)option_or("interp_lgnb", -1);
-  p->use_synthp = option_or("synthp", 0) != 0;
+  p->use_synthp = kMeasureBuild && option_or("synthp", 0) != 0;   // (the kernel exists in the measure build only)
   p->synthp_lgnb = (int)option_or("synthp_lgnb", -1);
   p->synthp_help = (int)option_or("synthp_help", -1);
   p->use_graphs = option_or("graphs", 1) != 0;
@@ -1026,7 +1029,18 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
     if (rc_) return rc_;                            \
   } while (0)
 
-  if (!reuse_means) RUN(ST_MEAN, launch_channel_sum(dx, N, C, p->d_sums, st));
+  // The channel means (transforms.py:142-143).  When the plan is one segment that is the whole recording (no epochs cut
+  // out, no time blocks with faded edges, FFT of 2^20 points) and every scale reads the spectrum, the forward column
+  // pass sums the samples it reads anyway and the row pass takes the mean's transform out of its input (fwd64.hip):
+  // the recording is read once.  A block request of such a plan runs the same forward side, so it gives the same bits.
+  bool fold = false;
+  if (p->fold_mean && p->d_y && hp.epochs.size() == 1 && hp.n_direct == 0 && hp.n_blockconv == 0) {
+    const EpochPlan& m = hp.epochs[0];
+    fold = m.start == 0 && m.ne == N && m.lead == 0 && m.ramp_lo == 0 && m.ramp_hi == 0 && m.long_a == 1 && m.p1 == 256 &&
+           std::max(1, m.batch_count) == 1;
+  }
+  p->last_fold = fold;
+  if (!reuse_means && !fold) RUN(ST_MEAN, launch_channel_sum(dx, N, C, p->d_sums, st));
   if (p->detect) {
     he = hipMemsetAsync(p->d_pred, 0, sizeof(float) * (size_t)S * (size_t)C * hp.epochs.size(), st);
     if (he != hipSuccess) return hip_err(he, "predictions reset");
@@ -1109,10 +1123,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       // precision = high: both passes in float64, the spectrum rounded to float32 per bin (fwd64.hip)
       for (int a = 0; a < A; ++a) {
         RUN(ST_FWD, launch_fwd64_cols(dx, p->d_y, P1, N, p->y_stride, P, p->d_tw64, p->d_sums, inv_n, sin, nb,
-                                      rows_a, st, A, a));
+                                      rows_a, st, A, a, fold));
+        if (fold) RUN(ST_MEAN, launch_channel_sum_final(p->d_sums, C, kFoldParts, st));
         RUN(ST_FWD, launch_fwd64_rows(p->d_y, p->d_x, rows_a, p->y_stride, P, p->d_tw64, slots,
                                       hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0, st, a, A, Pt,
-                                      p->detect ? p->d_hist : nullptr, P1));
+                                      p->detect ? p->d_hist : nullptr, P1, fold ? p->d_sums : nullptr, inv_n, ep.ne, P1));
       }
       // precision = auto / high: the row pass left the band energies of every row of the spectrum (fwd64.hip:
       // row_band_sums); on a stream of its own, beside the level passes and the synthesis, they are added up and turned
@@ -1309,7 +1324,11 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       ap.flags = 0;
       ap.seg = sout;
       p->cur = si;
+#ifdef GCWT_MEASURE
       RUN(ST_INTERP, launch_synthp(mode, ap, dev.n_items_p[k], slots, k == 1, si));
+#else
+      return set_err(GCWT_ERR_INVALID, "internal: a level planned for the measure build's pipelined kernel");
+#endif
       p->cur = nullptr;
     }
     if (dev.n_items > 0) {
@@ -1958,6 +1977,11 @@ int gcwt_debug_scale_theta_lo(const gcwt_plan* p, double* theta_lo) {
   if (!p || !theta_lo) return set_err(GCWT_ERR_INVALID, "NULL argument");
   for (size_t i = 0; i < p->hp.scales.size(); ++i) theta_lo[i] = p->hp.scales[i].theta_lo;
   return GCWT_OK;
+}
+
+int gcwt_debug_mean_folded(const gcwt_plan* p) {
+  if (!p) return set_err(GCWT_ERR_INVALID, "NULL plan");
+  return p->last_fold ? 1 : 0;
 }
 
 int gcwt_debug_graph_state(const gcwt_plan* p) {

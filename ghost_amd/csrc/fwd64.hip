@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
                                                              int lg_p, const cd* __restrict__ tw_hi,
                                                              const cd* __restrict__ tw_lo,
                                                              const double* __restrict__ sums, double inv_n,
-                                                             const SegIn segs, int rows_out) {
+                                                             const SegIn segs, int rows_out, double* __restrict__ fold_parts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* const ex_re = reinterpret_cast<double*>(smem);
   double* const ex_im = ex_re + 16 * kDCol;
@@ -166,7 +166,10 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
   const int n_valid = (int)segs.n_valid[g], n_lead = (int)segs.n_lead[g];
   const SegRamp ramp = seg_ramp(segs, g);
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
-  const double mean = sums[ch] * inv_n;      // transforms.py:142-143: float64 copy minus the global mean
+  // transforms.py:142-143: float64 copy minus the global mean -- or, fold_parts (kernel-uniform; kernels.h:
+  // launch_fwd64_cols): the samples as they are, their sum left for the row pass to take the mean's transform out
+  const double mean = fold_parts ? 0.0 : sums[ch] * inv_n;
+  double acc = 0.0;
   const int s = tid & 15, t = tid >> 4;
   d_fill_twl(twl, tw_hi, tid);
   const int top = n_valid > 0 ? n_valid - 1 : 0;
@@ -192,6 +195,7 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
                           n + 1 >= n_lead && n + 1 < n_valid ? (double)rb[j] - mean : 0.0);
       if (__any(seg_in_ramp(ramp, n) || seg_in_ramp(ramp, n + 1)))      // wave-uniform: the ramps are rare
         v[j] = make_double2(v[j].x * seg_weight(ramp, n), v[j].y * seg_weight(ramp, n + 1));
+      acc += v[j].x + v[j].y;
     }
     if (it + 1 < n_tiles) fetch(col0 + 32);          // in flight during this tile's transform
     d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
@@ -216,6 +220,15 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
       w = dmul(w, st);
     }
     __syncthreads();                                 // the tile is read before the next exchange overwrites it
+  }
+  if (fold_parts) {
+    // the workgroup's share of the channel's sum, in a fixed order: lanes by butterfly, the four waves in turn
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((tid & 63) == 0) ex_re[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0)
+      fold_parts[(int64_t)segs.n_channels + (int64_t)ch * kSumParts + blockIdx.x] = (ex_re[0] + ex_re[1]) + (ex_re[2] + ex_re[3]);
   }
 }
 
@@ -443,7 +456,8 @@ __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, f
                                                     int64_t in_cstride, int64_t out_cstride,
                                                     const cd* __restrict__ tw_hi, int out_len, int mirror,
                                                     int comb_a, int comb_n, int lg_pt, float* __restrict__ hist,
-                                                    int hist_rows) {
+                                                    int hist_rows, const double* __restrict__ fold_sums, double inv_n,
+                                                    int n_valid, int lg_p, int lg_p1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* const ex_re = reinterpret_cast<double*>(smem);
   double* const ex_im = ex_re + 16 * kDCol;
@@ -456,6 +470,35 @@ __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, f
   cd v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = x[16 * (t + 16 * j) + a];
+  if (fold_sums) {                       // kernel-uniform
+    // The column pass transformed x, not x - mean (kernels.h: launch_fwd64_cols, fold_mean).  The mean's share of
+    // Y[k1][n2] is mean W_P^(-n2 k1) G_c(k1), G_c(k1) = sum_{n1 < c} W_P1^(-n1 k1) a geometric sum over the c samples
+    // column n2 holds (c = ceil(N / 4096) for the first columns, one less for the rest): taken out here, in float64,
+    // before the row's transform -- transforms.py:142-143's x - mean(x) without a pass of its own over x.
+    const cd* const tw_lo = tw_hi + 4096;
+    const double mean = fold_sums[blockIdx.y] * inv_n;
+    const int c_hi = (n_valid + kRowLenDev - 1) / kRowLenDev, n_split = n_valid - (c_hi - 1) * kRowLenDev;
+    cd g_hi = make_double2((double)c_hi, 0.0), g_lo = make_double2((double)(c_hi - 1), 0.0);
+    if (row > 0) {
+      const cd w1 = d_phase(tw_hi, tw_lo, row, lg_p1);
+      const cd den = make_double2(1.0 - w1.x, -w1.y);
+      const double r2 = 1.0 / (den.x * den.x + den.y * den.y);
+      const cd inv = make_double2(den.x * r2, -den.y * r2);
+      const cd wh = d_phase(tw_hi, tw_lo, (int64_t)row * c_hi, lg_p1), wl = d_phase(tw_hi, tw_lo, (int64_t)row * (c_hi - 1), lg_p1);
+      g_hi = dmul(make_double2(1.0 - wh.x, -wh.y), inv);
+      g_lo = dmul(make_double2(1.0 - wl.x, -wl.y), inv);
+    }
+    g_hi = make_double2(g_hi.x * mean, g_hi.y * mean);
+    g_lo = make_double2(g_lo.x * mean, g_lo.y * mean);
+    cd w = d_phase(tw_hi, tw_lo, (int64_t)row * (a + 16 * t), lg_p);
+    const cd step = d_phase(tw_hi, tw_lo, (int64_t)row * 256, lg_p);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int n2 = a + 16 * t + 256 * j;
+      v[j] = dsub(v[j], dmul(n2 < n_split ? g_hi : g_lo, w));
+      w = dmul(w, step);
+    }
+  }
   __syncthreads();
   d_fft256(v, twl + t, ex_re + a * kDCol, ex_im + a * kDCol, t);
   __syncthreads();                       // the element buffer aliases the exchange planes
@@ -619,7 +662,7 @@ void fwd64_fill_tables(double2* host) {
 hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cstride, int64_t y_cstride,
                              int64_t p, const double2* tables, const double* sums, double inv_n,
                              const SegIn& segs, int n_segments, int rows_out, hipStream_t st, int in_stride,
-                             int in_offset) {
+                             int in_offset, bool fold_mean) {
   const int slots = segs.n_channels * n_segments, ld = kRowLenDev, lg_p = ilog2_64(p);
   const cd* tw_hi = tables;
   const cd* tw_lo = tables + 4096;
@@ -628,10 +671,14 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
   if (in_stride < 1 || in_offset < 0 || in_offset >= in_stride || (in_stride > 1 && p1 != 512 && p1 != 1024))
     return hipErrorInvalidValue;                     // strided input: the 2^21 / 2^22-point kernels only (long mode)
   hipError_t e;
+  static_assert((kRowLenDev / 32 + kColsTiles - 1) / kColsTiles == kFoldParts && kFoldParts <= kSumParts, "partial sums of the folded mean");
+  if (fold_mean && (p1 != 256 || n_segments != 1 || in_stride != 1 || segs.n_lead[0] != 0 || segs.ramp_lo[0] != 0 ||
+                    segs.ramp_hi[0] != 0 || segs.x_off[0] != 0)) return hipErrorInvalidValue;
   if (p1 == 256) {
     if ((e = allow_lds(k_fwd64_cols256_real2, kFwd64Lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_fwd64_cols256_real2, dim3((ld / 32 + kColsTiles - 1) / kColsTiles, slots), dim3(256), kFwd64Lds, st, in, y, ld,
-                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out);
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out,
+                       fold_mean ? const_cast<double*>(sums) : nullptr);
   } else if (p1 == 512) {
     if ((e = allow_lds(k_fwd64_colsq_real2<1>, kFwd64Lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_fwd64_colsq_real2<1>, dim3(ld / 16, slots), dim3(256), kFwd64Lds, st, in, y, ld,
@@ -653,14 +700,17 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
 
 hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
                              const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st,
-                             int comb_a, int comb_n, int64_t p_true, float* hist, int hist_rows) {
+                             int comb_a, int comb_n, int64_t p_true, float* hist, int hist_rows,
+                             const double* fold_sums, double inv_n, int64_t n_valid, int p1) {
+  if (fold_sums && (comb_n > 1 || p1 < 2 || (p1 & (p1 - 1)) || n_valid < 1 || n_valid > (int64_t)p1 * kRowLenDev)) return hipErrorInvalidValue;
   if (comb_n > 1 && (mirror == 0 || comb_a < 0 || comb_a >= comb_n || ilog2_64(p_true) > 24)) return hipErrorInvalidValue;
   // band sums: every row k1 of the spectrum's positive half once -- from its own workgroup or, reflected, from its twin's
   if (hist && (comb_n > 1 || out_len < kRowLenDev / 2 || hist_rows != (mirror > 0 ? mirror : n_rows))) return hipErrorInvalidValue;
   hipError_t e = allow_lds(k_fwd64_rows, kFwd64Lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fwd64_rows, dim3(n_rows, n_slots), dim3(256), kFwd64Lds, st, y, x, y_cstride, x_cstride,
-                     tables, out_len, mirror, comb_a, comb_n, comb_n > 1 ? ilog2_64(p_true) : 0, hist, hist_rows);
+                     tables, out_len, mirror, comb_a, comb_n, comb_n > 1 ? ilog2_64(p_true) : 0, hist, hist_rows,
+                     fold_sums, inv_n, (int)n_valid, fold_sums ? ilog2_64((int64_t)p1 * kRowLenDev) : 0, fold_sums ? ilog2_64(p1) : 0);
   return hipGetLastError();
 }
 

@@ -305,11 +305,18 @@ void fwd64_fill_tables(double2* host);
 hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cstride, int64_t y_cstride,
                              int64_t p, const double2* tables, const double* sums, double inv_n,
                              const SegIn& segs, int n_segments, int rows_out, hipStream_t st, int in_stride = 1,
-                             int in_offset = 0);
+                             int in_offset = 0, bool fold_mean = false);
+// fold_mean (one segment that IS the recording, p1 = 256, no faded edges: api.cpp decides): the column pass transforms
+// the samples as they are, leaves its workgroups' partial sums behind sums[C ..] (k_channel_sum's layout; added up by
+// launch_channel_sum_final), and the row pass takes the mean's own transform out of Y as it reads it (fold_sums): the
+// recording is read once for the forward side, not twice (transforms.py:142-143: x - mean(x)).
+hipError_t launch_channel_sum_final(double* sums, int n_channels, int parts, hipStream_t st);
+constexpr int kFoldParts = 32;     // workgroups of k_fwd64_cols256_real2 per channel
 // comb_n > 1 (long mode): subsequence comb_a of comb_n, accumulated into x with the twiddle W_p_true^(a k)
 hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
                              const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st,
-                             int comb_a = 0, int comb_n = 1, int64_t p_true = 0, float* hist = nullptr, int hist_rows = 0);
+                             int comb_a = 0, int comb_n = 1, int64_t p_true = 0, float* hist = nullptr, int hist_rows = 0,
+                             const double* fold_sums = nullptr, double inv_n = 0.0, int64_t n_valid = 0, int p1 = 0);
 
 // precision = auto (detect.hip): what the float32 stages of the decimated path will cost each scale, predicted from
 // the float64 spectrum while it is made.  The positive half of the spectrum is summed into bands, sixteen per octave:

@@ -1824,6 +1824,13 @@ hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double*
   return hipSuccess;
 }
 
+hipError_t launch_channel_sum_final(double* sums, int n_channels, int parts, hipStream_t st) {
+  if (parts < 1 || parts > kSumParts) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_channel_sum_final, dim3((n_channels + 63) / 64), dim3(64), 0, st, sums, n_channels, parts);
+  GCWT_LAUNCH_CHECK();
+  return hipSuccess;
+}
+
 hipError_t launch_shift_gather(const cf* x, cf* xs, int p1, int q, int u2, int64_t x_row, int64_t x_cstride,
                                int64_t xs_cstride, int n_channels, hipStream_t st) {
   hipLaunchKernelGGL(k_shift_gather, dim3((q + 255) / 256, p1, n_channels), dim3(256), 0, st, x, xs, p1, q, u2,

@@ -215,14 +215,64 @@ hipError_t dft_f64(const double* x, int64_t n, int is_complex, int inverse, doub
   return hipMemcpy(out, c, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost);
 }
 
+// Results beyond one 2^24-point transform: overlap-add over chunks of the signal, the kernel's spectrum made once --
+// what convolution.py:70-77 does on the host (chunks of chunk_size samples, each chunk's full result added where it
+// belongs).  A chunk's transform is 2^22 points (four times the kernel for longer kernels, 2^24 at most), its
+// Lc - m + 1 signal samples give Lc result samples of which the part inside [first, first + count) is added into out
+// on the host, in chunk order: every sum has the same order every run.
+static hipError_t fastconv_f64_chunked(const double* signal, int64_t n, int signal_is_complex, const double* kernel, int64_t m,
+                                       int kernel_is_complex, int64_t first, int64_t count, double* out, const cd* tw) {
+  if (m > ((int64_t)1 << 23)) return hipErrorInvalidValue;
+  const int lg = std::min(24, std::max(22, ilog2(4 * m)));
+  const int64_t L = (int64_t)1 << lg, B = L - m + 1;           // B >= m: a result sample has two chunks' parts at most
+  const int sw = signal_is_complex ? 2 : 1, kw = kernel_is_complex ? 2 : 1;
+  hipError_t e;
+  Scratch s, s2;
+  if ((e = s.alloc(0, sizeof(double) * (size_t)std::max(B * sw, m * kw))) != hipSuccess || (e = s.alloc(1, sizeof(cd) * (size_t)L)) != hipSuccess ||
+      (e = s.alloc(2, sizeof(cd) * (size_t)L)) != hipSuccess || (e = s.alloc(3, sizeof(cd) * (size_t)L)) != hipSuccess ||
+      (e = s2.alloc(0, sizeof(cd) * (size_t)L)) != hipSuccess)
+    return e;
+  double* d_in = (double*)s.p[0];
+  cd *a = (cd*)s.p[1], *b = (cd*)s.p[2], *c = (cd*)s.p[3], *d = (cd*)s2.p[0];
+  cd* fk = nullptr;
+  if ((e = hipMemcpy(d_in, kernel, sizeof(double) * (size_t)(m * kw), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_load64, grid1(L), dim3(256), 0, nullptr, d_in, kernel_is_complex, c, m, L);
+  if ((e = fft64(c, d, lg, -1, tw, nullptr, &fk)) != hipSuccess) return e;
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+  std::vector<double> part((size_t)2 * (size_t)L);
+  std::memset(out, 0, sizeof(double) * 2 * (size_t)count);
+  for (int64_t s0 = 0; s0 < n; s0 += B) {
+    const int64_t nb = std::min(B, n - s0), len = nb + m - 1;            // the chunk's result: [s0, s0 + len) of the full one
+    const int64_t lo = std::max(s0, first), hi = std::min(s0 + len, first + count);
+    if (hi <= lo) continue;
+    if ((e = hipMemcpy(d_in, signal + s0 * sw, sizeof(double) * (size_t)(nb * sw), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    cd *fa = nullptr, *fc = nullptr;
+    hipLaunchKernelGGL(k_load64, grid1(L), dim3(256), 0, nullptr, d_in, signal_is_complex, a, nb, L);
+    if ((e = fft64(a, b, lg, -1, tw, nullptr, &fa)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mul64, grid1(L), dim3(256), 0, nullptr, fa, fk, L, 1.0 / (double)L);
+    if ((e = fft64(fa, fa == a ? b : a, lg, +1, tw, nullptr, &fc)) != hipSuccess) return e;
+    double* d_out = (double*)(fc == a ? b : a);
+    hipLaunchKernelGGL(k_store64, grid1(hi - lo), dim3(256), 0, nullptr, fc, d_out, lo - s0, hi - lo, 1.0);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    if ((e = hipMemcpy(part.data(), d_out, sizeof(double) * 2 * (size_t)(hi - lo), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    double* dst = out + 2 * (lo - first);
+    for (int64_t i = 0; i < 2 * (hi - lo); ++i) dst[i] += part[(size_t)i];
+  }
+  return hipSuccess;
+}
+
 // Linear convolution of signal (n) and kernel (m), both real or complex float64 on the host; samples
-// [first, first + count) of the full result to out ((re, im) pairs).  One FFT of 2^k >= n + m - 1 points (<= 2^24).
+// [first, first + count) of the full result to out ((re, im) pairs).  One FFT of 2^k >= n + m - 1 points up to 2^24;
+// longer results by overlap-add (above).
 hipError_t fastconv_f64(const double* signal, int64_t n, int signal_is_complex, const double* kernel, int64_t m,
                         int kernel_is_complex, int64_t first, int64_t count, double* out) {
   std::lock_guard<std::mutex> lock(dev64().mu);
   cd* tw = nullptr;
   hipError_t e = tables(&tw);
   if (e != hipSuccess) return e;
+  if (n + m - 1 > ((int64_t)1 << 24))
+    return fastconv_f64_chunked(signal, n, signal_is_complex, kernel, m, kernel_is_complex, first, count, out, tw);
   const int lg = ilog2(n + m - 1);
   if (lg > 24) return hipErrorInvalidValue;
   const int64_t L = (int64_t)1 << lg;

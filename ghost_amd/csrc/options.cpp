@@ -17,10 +17,12 @@ namespace {
 const char* const kSelect[] = {"synth16", "synth_cols", "fuse_blocks", "slow_fft", "level_streams", "interp_grid",
                                "synth_streams", "interp_lgnb", "merge_levels", "split_levels", "interp",
                                "batch_bytes", "stage_floats", "fullband_group", "blockconv",
-                               "direct_max_len", "graphs", "plan_threads", "synthp", "synthp_lgnb", "synthp_help", "fullband_cache_mb", "auto_threshold_ppb", "auto_kappa_ppb", "auto_oob_ppt", "synth7_order", "host_widen", "host_threads", "fullband4", "cu_count", "synth7_narrow_r"};
+                               "direct_max_len", "graphs", "plan_threads", "fullband_cache_mb", "auto_threshold_ppb", "auto_kappa_ppb", "auto_oob_ppt", "synth7_order", "host_widen", "host_threads", "fullband4", "cu_count", "synth7_narrow_r", "fold_mean"};
 // accuracy-changing or measurement hooks: libghostcwt_measure.so only
 const char* const kMeasureOnly[] = {"halo_margin", "interp_q", "interp_taps", "interp_min_r", "prune_inputs", "clock_phases",
-                                    "synth_kernel", "synth_drop_stores", "clock_probe", "synthi_pad_kb"};
+                                    "synth_kernel", "synth_drop_stores", "clock_probe", "synthi_pad_kb",
+                                    // measured-slower kernels: k_synthp (synthp.hip; ties with k_synthi at a lower clock: profiles/r05_synth_study.md)
+                                    "synthp", "synthp_lgnb", "synthp_help"};
 // the two budgets the product library also takes from the environment
 const char* const kEnvBudgets[] = {"batch_bytes", "stage_floats"};
 

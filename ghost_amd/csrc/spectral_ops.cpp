@@ -204,7 +204,9 @@ int gcwt_fastconv_f64(const double* signal, int64_t n, int signal_is_complex, co
   return guarded([&] {
     if (!signal || !kernel || !out || n < 1 || m < 1 || mode < 0 || mode > 2) return fail(GCWT_ERR_INVALID, "bad arguments");
     if (mode == 2 && n < m) return fail(GCWT_ERR_INVALID, "'valid' needs a signal at least as long as the kernel");
-    if (n + m - 1 > ((int64_t)1 << 24)) return fail(GCWT_ERR_UNSUPPORTED, "float64 convolutions up to 2^24 samples of result (the float32 operator chunks: gcwt_conv_plan_*)");
+    // (results beyond one 2^24-point transform are made by overlap-add over chunks of the signal, as convolution.py:70-77
+    // does; the kernel's own transform bounds its length)
+    if (n + m - 1 > ((int64_t)1 << 24) && m > ((int64_t)1 << 23)) return fail(GCWT_ERR_UNSUPPORTED, "float64 convolutions with kernels up to 2^23 taps");
     if (device >= 0 && hipSetDevice(device) != hipSuccess) return fail(GCWT_ERR_NO_DEVICE, "cannot select the device");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) { (void)hipGetLastError(); return fail(GCWT_ERR_NO_DEVICE, "no HIP device"); }

@@ -356,6 +356,10 @@ class CwtPlan:
                         "nblk": nb.value, "m": m.value, "band_shift": sh.value, "low_cut": cut.value})
         return res
 
+    def debug_mean_folded(self):
+        """True when the last run summed the channels inside the forward column pass (include/ghostcwt_debug.h)."""
+        return bool(lib.gcwt_debug_mean_folded(self._handle))
+
     def debug_graph_state(self):
         """1: executes replay a HIP graph, 0: not (yet), -1: capture failed, eager from then on."""
         return int(lib.gcwt_debug_graph_state(self._handle))

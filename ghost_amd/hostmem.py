@@ -7,6 +7,7 @@ engines write them directly, and a block goes back to a small pool when the last
 dropped, so that the next result of that size reuses memory that is already mapped.  ``limit_bytes`` bounds
 what the pool keeps (and the size of a single pinned request); beyond it callers fall back to pageable arrays.
 """
+import collections
 import ctypes as C
 import os
 import threading
@@ -22,6 +23,10 @@ _GRANULE = 2 << 20
 _lock = threading.Lock()
 _free = []                     # [(nbytes, ptr)]
 _kept = 0
+# Blocks whose last view died, waiting to be sorted into the pool.  __del__ may run inside ANY allocation of the thread
+# that holds _lock (the cyclic collector is triggered by allocations), so it must not take that lock: deque.append is
+# atomic, and _take / trim drain the deque under the lock.
+_returned = collections.deque()
 
 
 class _Block:
@@ -32,21 +37,36 @@ class _Block:
         self.ptr, self.nbytes = ptr, nbytes
 
     def __del__(self):
-        global _kept
         try:
-            with _lock:
-                if _kept + self.nbytes <= limit_bytes:
-                    _free.append((self.nbytes, self.ptr))
-                    _kept += self.nbytes
-                    return
-            lib.gcwt_host_free(C.c_void_p(self.ptr))
+            _returned.append((self.nbytes, self.ptr))      # lock-free: see _returned
         except Exception:                      # interpreter shutdown: the process's memory goes with it
             pass
+
+
+def _drain():
+    """Sorts the returned blocks into the pool up to ``limit_bytes``; the rest is handed back to free.  _lock held."""
+    global _kept
+    over = []
+    while True:
+        try:
+            n, ptr = _returned.popleft()
+        except IndexError:
+            break
+        if _kept + n <= limit_bytes:
+            _free.append((n, ptr))
+            _kept += n
+        else:
+            over.append(ptr)
+    return over
 
 
 def _take(nbytes):
     global _kept
     need = -(-nbytes // _GRANULE) * _GRANULE
+    with _lock:
+        over = _drain()
+    for ptr in over:
+        lib.gcwt_host_free(C.c_void_p(ptr))
     with _lock:
         best = None
         for i, (n, _) in enumerate(_free):
@@ -132,7 +152,8 @@ def trim():
     """Frees what the pool holds (blocks still viewed by live arrays are not touched)."""
     global _kept
     with _lock:
+        over = _drain()
         blocks, _free[:] = list(_free), []
         _kept = 0
-    for _, ptr in blocks:
+    for ptr in over + [ptr for _, ptr in blocks]:
         lib.gcwt_host_free(C.c_void_p(ptr))

@@ -166,7 +166,7 @@ def fastconv_hip(signal, kernel, *, mode=None, fft_length=None, device=-1, preci
     """Linear convolution of a real 1-D ``signal`` with a real or complex 1-D ``kernel``.
     ``mode``: 'full', 'same' (default, centred as convolution.py:85) or 'valid';
     ``fft_length`` as in the reference (a power of two here).  precision='high': float64 arithmetic and a float64 /
-    complex128 result, what the reference returns (one FFT of the whole result, up to 2**24 samples)."""
+    complex128 result, what the reference returns (one FFT of the whole result up to 2**24 samples, overlap-add over chunks of the signal beyond, as convolution.py:70-77)."""
     signal = np.asarray(signal)
     kernel = np.asarray(kernel)
     if signal.ndim != 1:

@@ -320,7 +320,8 @@ int gcwt_analytic_signal(const float* signal, int64_t n, int64_t fft_length, flo
  * element, down to a result's zero crossings.  Host memory in and out; out: (re, im) pairs of doubles.
  * gcwt_dft_f64: any n <= 2^23 (powers of two directly, other lengths by the chirp-z identity, phases reduced in
  * integers).  gcwt_fastconv_f64: signal and kernel real or complex; mode 0 'full', 1 'same' (centred as
- * convolution.py:85), 2 'valid'; n + m - 1 <= 2^24.  The analytic signal is two gcwt_dft_f64 calls around the
+ * convolution.py:85), 2 'valid'; results beyond 2^24 samples are made by overlap-add over chunks of the signal like
+ * convolution.py:70-77's (kernels up to 2^23 taps then).  The analytic signal is two gcwt_dft_f64 calls around the
  * one-sided mask (ghost_amd.sigtools.analytic_signal_hip(precision='high')). */
 int gcwt_dft_f64(const double* x, int64_t n, int is_complex, int inverse, double* out, int device);
 int gcwt_fastconv_f64(const double* signal, int64_t n, int signal_is_complex, const double* kernel, int64_t m,

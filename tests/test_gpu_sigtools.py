@@ -82,6 +82,17 @@ def test_reference_operator_names_run_on_the_device():
     assert np.allclose(chirpz_idft_hip(z, precision="high"), np.fft.ifft(z), rtol=1e-10, atol=1e-13)
     with pytest.raises(ValueError):
         fastconv_hip(xs, psi, precision="exact")
+    # a recording longer than one 2^24-point transform holds (9.3 minutes at 30 kHz): overlap-add over chunks of the
+    # signal, the kernel's spectrum made once, as convolution.py:70-77 does -- every mode, real and complex kernels
+    from scipy.signal import fftconvolve
+    xl = rng.standard_normal((1 << 24) + 300001)
+    for kern in (psi, y):
+        for mode in ("same", "full", "valid"):
+            ref = fftconvolve(xl, kern, mode=mode)
+            got = fastconv_scipy(xl, kern, mode=mode)
+            assert got.shape == ref.shape and got.dtype == ref.dtype
+            assert np.allclose(got, ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max()), (mode, kern.dtype)
+            del ref, got
 
 
 def test_fastconv_freq_domain():

@@ -130,3 +130,46 @@ def test_band_energies_of_the_detector_are_those_of_the_spectrum(n, f_hi, f_lo, 
     plan.execute(x[None, :])
     again = plan.debug_precision_terms()["band_energy"]
     assert np.array_equal(again.view(np.uint32), got.astype(np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("n, offset", [(1000000, 0.0), (700001, 1000.0), (4096 * 200, -37.5), (524288 + 5000, 1.0e4)])
+def test_channel_means_taken_inside_the_forward_passes(option, n, offset):
+    """transforms.py:142-143 subtracts the recording's mean before anything else.  For a plan that is one segment of
+    the whole recording (FFT of 2^20 points, every scale spectral) the forward column pass sums the samples it reads
+    and the row pass takes the mean's transform out of its input in float64 (fwd64.hip; option fold_mean = 0: a pass
+    of its own over x first): per bin the spectrum is that of x - mean to float32 rounding, with an offset of ten
+    thousand times the signal's spread as without one (float64: the offset costs 1e-16 of itself), the rows are the
+    oracle's, and a block request gives the bits of the whole transform."""
+    from ghost_amd.engine import CwtPlan
+    from ghost_amd.synthetic import lfp
+    fs = 1000.0
+    x = (lfp(3, n).astype(np.float64) + offset).astype(np.float32)
+    x[1] *= 0.25
+    x[2] = x[2] - offset                                       # one channel without the offset
+    f = np.geomspace(200.0, 2.0, 24)
+    plan = CwtPlan(n, 3, fs, f, output="complex")
+    assert np.all(plan.scale_info()["method"] == 0) and plan.info["fft_length"] == 1 << 20
+    got = plan.execute(x)
+    assert plan.debug_mean_folded()
+    P, p1 = plan.info["fft_length"], plan.info["fft_length"] // 4096
+    for c in range(3):
+        xc = x[c].astype(np.float64) - x[c].astype(np.float64).mean()
+        ref = fft(xc, n=P).reshape(4096, p1).T[:, :2048]
+        spec = plan.debug_fetch(0, channel=c).astype(np.complex128).reshape(p1, 4096)[:, :2048]
+        # per bin: float32 rounding of the bin itself plus 1e-9 of the spectrum's largest (float64 arithmetic on a
+        # recording whose offset is up to 1e4 of its spread)
+        assert np.all(np.abs(spec - ref) <= 1.5e-7 * np.abs(ref) + 1e-9 * np.abs(ref).max()), c
+    blk = plan.execute_block(x, 123457, 50001)
+    np.testing.assert_array_equal(blk, got[:, :, 123457:123457 + 50001])
+    ref = orc.cwt_complex(x[1].astype(np.float64), fs, f, n_threads=8)
+    assert rel_err(got[1], ref).max() < 1e-5
+    option("fold_mean", 0)
+    plain = CwtPlan(n, 3, fs, f, output="complex")
+    old = plain.execute(x)
+    assert not plain.debug_mean_folded()
+    assert rel_err(got.reshape(-1, n), old.reshape(-1, n)).max() < 2e-6
+    # epochs cut out of the recording: the sums by their own pass, as before
+    option("fold_mean", None)
+    cut = CwtPlan(n, 3, fs, f, epoch_bounds=[[0, n // 2], [n // 2 + 7, n]])
+    cut.execute(x)
+    assert not cut.debug_mean_folded()
