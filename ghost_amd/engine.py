@@ -236,11 +236,14 @@ class CwtPlan:
         """After an execute with precision 'auto' (the default) or 'high': {"predicted": per scale, the loss to the
         float32 stages of its decimation level predicted from the recording's spectrum (relative to the scale's own
         output; 0 for scales on the exact paths), "worst", "rerouted": how many scales the last execute made again by
-        the exact paths}."""
+        the exact paths, "watched": False where the detector does not look -- plans whose segments take FFTs of 2^23 /
+        2^24 points (kernels of millions of taps: DESIGN.md 8), every scale of which is then 'high''s}."""
         pred = np.zeros(self.n_freqs, np.float32)
         worst, n = C.c_float(0), C.c_int32(0)
         check(lib.gcwt_plan_precision_report(self._handle, pred.ctypes.data_as(C.POINTER(C.c_float)), C.byref(worst), C.byref(n)))
-        return {"predicted": pred, "worst": float(worst.value), "rerouted": int(n.value)}
+        if getattr(self, "_watched", None) is None:
+            self._watched = all(p <= (1 << 22) for _, _, p in self.segments())
+        return {"predicted": pred, "worst": float(worst.value), "rerouted": int(n.value), "watched": self._watched}
 
     def debug_precision_terms(self):
         """The two terms of the last execute's prediction (slot 0 of its last batch): float32 rounding of the level's

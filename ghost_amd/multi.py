@@ -151,7 +151,8 @@ class ShardedPlan:
         n = [r["rerouted"] for r in reps]
         # (a slot that could not reroute reports a negative count: the worst news wins)
         return {"predicted": pred, "worst": float(max(r["worst"] for r in reps)),
-                "rerouted": min(n) if min(n) < 0 else max(n), "per_device": reps}
+                "rerouted": min(n) if min(n) < 0 else max(n), "watched": all(r["watched"] for r in reps),
+                "per_device": reps}
 
     def timings(self):
         ts = [p.timings() for p in self.plans]

@@ -223,6 +223,12 @@ class ContinuousWaveletTransform(WaveletTransform):
         self.precision_report = None
         if precision in (None, "auto", "high"):
             rep = self.precision_report = self._plan.precision_report()
+            if not rep["watched"] and precision != "high":
+                # kernels of millions of taps: FFTs of 2^23 / 2^24 points, combined from interleaved transforms -- the
+                # detector's band sums are not made there: said once per call, never silently
+                logging.warning("precision='auto' does not watch transforms of more than 2^22 points (kernels of millions "
+                                "of taps): every scale holds what precision='high' returns; precision='exact' for "
+                                "recordings with interference far above the signal inside the analysed band")
             if rep["rerouted"] < 0:
                 logging.warning("{} of {} scales are predicted to lose up to {:.1e} of their peak to the float32 stages and "
                                 "could not all be recomputed exactly (no device memory for the exact paths: {}); they hold "

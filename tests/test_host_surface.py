@@ -772,3 +772,20 @@ def _lib_has_device():
     import ctypes
     n = ctypes.c_int(0)
     return _lib.lib.gcwt_device_count(ctypes.byref(n)) == 0 and n.value > 0
+
+
+def test_precision_report_says_where_the_detector_does_not_look():
+    """precision='auto' watches the decimated path's float32 stages through band sums made in the forward row pass;
+    plans whose segments take FFTs of 2^23 / 2^24 points (kernels of millions of taps, combined from interleaved
+    transforms) make none: the report says so ("watched": False) and the public call logs it, instead of a silence
+    that reads as "nothing was at risk" (the reference is float64 end to end: transforms.py:142-143)."""
+    long_plan = CwtPlan(1 << 20, 1, 30000.0, [0.13])
+    assert long_plan.segments()[0][2] == 1 << 23
+    assert long_plan.precision_report()["watched"] is False
+    plain = CwtPlan(1 << 20, 1, 1000.0, [10.0, 5.0])
+    rep = plain.precision_report()
+    assert rep["watched"] is True and rep["rerouted"] == 0
+    from ghost_amd.multi import ShardedPlan
+    sp = ShardedPlan(1 << 20, 2, 30000.0, [0.13], [0, 0])
+    assert sp.precision_report()["watched"] is False
+    sp.close()
