@@ -496,8 +496,9 @@ def run_rank(args):
                        "scales": {"spectral": info["n_spectral"], "direct": info["n_direct"],
                                   "fullband": info["n_fullband"]}},
             "roofline": {"bound": "hbm",
-                         "kernel": "synthesis: k_synthi (%d interpolated scales, R >= 16) + k_synth7 (%d scales), "
-                                   "one launch each per step, back to back" % (info["n_interp"], info["n_spectral"] - info["n_interp"])
+                         "kernel": "synthesis: k_synthi (%d interpolated scales, R >= 16) + k_synth7 (%d scales: R = 4, 8 in "
+                                   "its 32-column instantiation, R = 2 in the 16-column one), launched once each per step, "
+                                   "back to back" % (info["n_interp"], info["n_spectral"] - info["n_interp"])
                                    if info["n_interp"] else "k_synth7",
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -2,7 +2,7 @@
 tracked-numbers block -- from the round's tracked evidence under profiles/, so that the text and the files cannot drift
 (tests/test_docs.py checks the block).  Usage: python tools/design_numbers.py [r04]"""
 import json, os, re, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 j = json.loads(open(os.path.join(root, "profiles", rnd + "_bench.json")).read().strip().splitlines()[-1])
 j5 = json.loads(open(os.path.join(root, "profiles", rnd + "_bench_config5.json")).read().strip().splitlines()[-1])
@@ -13,7 +13,10 @@ stats = {}
 import csv
 for row in csv.DictReader(open(os.path.join(root, "profiles", rnd + "_kernel_stats.csv"))):
     stats[row["Name"].split("(")[0].replace("void ", "")] = (int(row["Calls"]), float(row["AverageNs"]) / 1e6)
-ki, k7 = stats["gcwt::k_synthi<0>"], stats["gcwt::k_synth7<0, 32, false>"]
+# k_synth7: its 32-column launch (R = 4, 8) and, since round 6, the 16-column one (R = 2): one launch each per step
+ki = stats["gcwt::k_synthi<0>"]
+k7_parts = [v for k, v in stats.items() if k.startswith("gcwt::k_synth7<0,")]
+k7 = (k7_parts[0][0], sum(v[1] for v in k7_parts))
 gen = {}
 te = c2["transform_end_to_end"]
 cb = j["cpu_baseline"]
@@ -62,7 +65,7 @@ rows = [(b, "value", "%.2f" % j["value"]), (b, "ms_per_step", "%.4f" % j["ms_per
 # README.md: the measured paragraph, from the same files
 oc = j["other_configs"]
 readme_text = (
-    "Measured (round 5, one MI355X, `profiles/%s_bench.json`; the boxes of the pool differ by a few per cent): headline\n"
+    "Measured (round %s, one MI355X," % rnd[1:].lstrip("0") + " `profiles/%s_bench.json`; the boxes of the pool differ by a few per cent): headline\n"
     "128 ch x 1e6 samples x 100 scales, amplitude, device-resident %.0f Msamples/s (%.2f ms per step; the synthesis\n"
     "kernels at %.3f of the 8 TB/s HBM peak on algorithmic bytes, PMC traffic %.2f x those bytes), checked against the\n"
     "oracle in the same run; complex output %.0f Msamples/s; config 5 (48 ch x 18e6 samples @ 30 kHz x 200 scales,\n"
