@@ -452,6 +452,10 @@ __device__ __forceinline__ void constexpr_band_sums(int ka, float e, int idx, in
 
 // comb_n > 1 (long mode): this is subsequence comb_a of comb_n; every output bin k is multiplied by W_pt^(a k),
 // pt = 2^lg_pt the true FFT length, and added to what the earlier subsequences left (a = 0 stores).
+// HIST / FOLD: instantiations with and without the band sums and the mean's removal (as run-time switches inside one
+// kernel they cost the plain row pass 25 registers and 0.06 ms: the sixteen stores of the epilogue ended up in sixteen
+// basic blocks)
+template <bool HIST, bool FOLD>
 __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, float2* __restrict__ out,
                                                     int64_t in_cstride, int64_t out_cstride,
                                                     const cd* __restrict__ tw_hi, int out_len, int mirror,
@@ -470,7 +474,7 @@ __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, f
   cd v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = x[16 * (t + 16 * j) + a];
-  if (fold_sums) {                       // kernel-uniform
+  if (FOLD) {
     // The column pass transformed x, not x - mean (kernels.h: launch_fwd64_cols, fold_mean).  The mean's share of
     // Y[k1][n2] is mean W_P^(-n2 k1) G_c(k1), G_c(k1) = sum_{n1 < c} W_P1^(-n1 k1) a geometric sum over the c samples
     // column n2 holds (c = ceil(N / 4096) for the first columns, one less for the rest): taken out here, in float64,
@@ -531,7 +535,7 @@ __global__ void __launch_bounds__(256) k_fwd64_rows(const cd* __restrict__ in, f
       continue;
     }
     const float2 val = make_float2((float)u[ka].x, (float)u[ka].y);
-    if (hist) {                          // (kernel-uniform) |X|^2 of the rounded bin into its row's band sums
+    if (HIST) {                          // |X|^2 of the rounded bin into its row's band sums
       float* const hslot = hist + (int64_t)blockIdx.y * hist_rows * kRowBands;
       const float e = val.x * val.x + val.y * val.y;
       // (ka is a constant of the unrolled loop: k2 = kb + 256 ka, reflected k2 = 255 - kb + 256 (15 - ka))
@@ -706,11 +710,20 @@ hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_
   if (comb_n > 1 && (mirror == 0 || comb_a < 0 || comb_a >= comb_n || ilog2_64(p_true) > 24)) return hipErrorInvalidValue;
   // band sums: every row k1 of the spectrum's positive half once -- from its own workgroup or, reflected, from its twin's
   if (hist && (comb_n > 1 || out_len < kRowLenDev / 2 || hist_rows != (mirror > 0 ? mirror : n_rows))) return hipErrorInvalidValue;
-  hipError_t e = allow_lds(k_fwd64_rows, kFwd64Lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_fwd64_rows, dim3(n_rows, n_slots), dim3(256), kFwd64Lds, st, y, x, y_cstride, x_cstride,
-                     tables, out_len, mirror, comb_a, comb_n, comb_n > 1 ? ilog2_64(p_true) : 0, hist, hist_rows,
-                     fold_sums, inv_n, (int)n_valid, fold_sums ? ilog2_64((int64_t)p1 * kRowLenDev) : 0, fold_sums ? ilog2_64(p1) : 0);
+  hipError_t e = hipSuccess;
+#define GCWT_ROWS(H, F)                                                                                                  \
+  do {                                                                                                                   \
+    if ((e = allow_lds(k_fwd64_rows<H, F>, kFwd64Lds)) != hipSuccess) return e;                                          \
+    hipLaunchKernelGGL((k_fwd64_rows<H, F>), dim3(n_rows, n_slots), dim3(256), kFwd64Lds, st, y, x, y_cstride, x_cstride, \
+                       tables, out_len, mirror, comb_a, comb_n, comb_n > 1 ? ilog2_64(p_true) : 0, hist, hist_rows,      \
+                       fold_sums, inv_n, (int)n_valid, fold_sums ? ilog2_64((int64_t)p1 * kRowLenDev) : 0,                \
+                       fold_sums ? ilog2_64(p1) : 0);                                                                    \
+  } while (0)
+  if (hist && fold_sums) GCWT_ROWS(true, true);
+  else if (hist) GCWT_ROWS(true, false);
+  else if (fold_sums) GCWT_ROWS(false, true);
+  else GCWT_ROWS(false, false);
+#undef GCWT_ROWS
   return hipGetLastError();
 }
 
