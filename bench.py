@@ -356,7 +356,11 @@ def run_rank(args):
     check(lib.gcwt_device_synchronize())
     plan_ms = (time.perf_counter() - t_plan) * 1e3   # reported apart from the timed steps
     bank_via = comm.broadcast_bank(plan, root=0)
-    plan.set_profiling(True)
+    # The timed steps carry HIP events around the synthesis kernels only (level 2: `roofline` comes from them, measured
+    # live on the kernels' own stream).  Events around EVERY stage cost the step they measure 0.19 ms of 13.5
+    # (tools/step_gap.py: 25 spans, each an event record between two dependent launches), so the stage breakdown
+    # (`stages_ms`) is taken from further steps after the timed region, outside it.
+    plan.set_profiling(2)
     info = plan.info
 
     # what this box's HBM delivers (measured once, before anything is timed)
@@ -451,6 +455,13 @@ def run_rank(args):
         sustained = s2.stop()
         if sustained:
             sustained["steps"], sustained["seconds"] = n_s, round(time.perf_counter() - t_s, 2)
+    # the stage breakdown: the same step again with every stage between events, after and outside the timed region
+    stage_stats, n_stage_steps = {}, min(args.steps, 10)
+    plan.set_profiling(True)
+    for i in range(n_stage_steps + 1):
+        step(stage_stats if i > 0 else {})               # (the first one after the switch is not counted)
+    check(lib.gcwt_device_synchronize())
+    plan.set_profiling(2)
     per_rank = comm.allgather(own / args.steps * 1e3)
     devices = comm.allgather(dev)
     numas = comm.allgather(-1 if numa is None else numa)
@@ -505,7 +516,12 @@ def run_rank(args):
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": round(k_ms, 4), "launches_per_step": launches // args.steps,
                          "algorithmic_bytes": int(alg_launch), **ceilings},
-            "stages_ms": {k: round(float(v) / args.steps, 4) for k, v in stats.items() if k.endswith("_ms")},
+            # every stage between HIP events, over `stages_steps` further steps after the timed region (their events
+            # slow a step by ~0.19 ms: `total_ms` here is longer than `ms_per_step`); the timed steps themselves
+            # bracket the synthesis kernels only (`roofline.kernel_ms`)
+            "stages_ms": {k: round(float(v) / n_stage_steps, 4) for k, v in stage_stats.items() if k.endswith("_ms")},
+            "stages_steps": n_stage_steps,
+            "timed_region_events": "synthesis kernels only (gcwt_plan_set_profiling level 2)",
             "whole_job_frac_of_hbm_peak": round(alg_step * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
         }
         rl = line["roofline"]

@@ -92,7 +92,7 @@ enum Stage { ST_MEAN = 0, ST_FWD, ST_DECIM, ST_BLOCK, ST_SYNTH, ST_DIRECT, ST_FU
 struct gcwt_plan {
   HostPlan hp;
   bool uploaded = false;
-  bool profiling = false;
+  int profiling = 0;          // gcwt_plan_set_profiling: 0 off, 1 every stage between events, 2 the synthesis kernels only
   int synth_cols = 32;        // columns per workgroup of k_synth7 (GHOSTCWT_SYNTH_COLS=16|32)
   int synth7_narrow_r = 2;    // option synth7_narrow_r: levels of decimation <= this take the 16-column instantiation whatever
                               // synth_cols says (0: none).  R = 2 has seven scales on the headline grid, so a workgroup's prologue
@@ -310,13 +310,16 @@ struct SpanGuard {
   int stage;
   hipEvent_t a = nullptr;
   int rc = GCWT_OK;
+  bool on = false;
   SpanGuard(gcwt_plan* p_, int st) : p(p_), stage(st) {
-    if (!p->profiling) return;
+    // (level 2: the events around the other stages cost the step they measure 0.19 ms of 13.5 -- tools/step_gap.py)
+    on = p->profiling == 1 || (p->profiling == 2 && (st == ST_SYNTH || st == ST_INTERP));
+    if (!on) return;
     rc = get_event(p, &a);
     if (rc == GCWT_OK && hipEventRecord(a, p->cur ? p->cur : p->stream) != hipSuccess) rc = GCWT_ERR_HIP;
   }
   int end() {
-    if (!p->profiling || rc) return rc;
+    if (!on || rc) return rc;
     hipEvent_t b;
     rc = get_event(p, &b);
     if (rc) return rc;
@@ -555,7 +558,7 @@ int gcwt_plan_scale_support(const gcwt_plan* plan, double* theta_hi, double* sup
 
 int gcwt_plan_set_profiling(gcwt_plan* plan, int enabled) {
   if (!plan) return set_err(GCWT_ERR_INVALID, "NULL plan");
-  plan->profiling = enabled != 0;
+  plan->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
   return GCWT_OK;
 }
 

@@ -225,7 +225,8 @@ class CwtPlan:
         check(lib.gcwt_plan_upload(self._handle))
 
     def set_profiling(self, on=True):
-        check(lib.gcwt_plan_set_profiling(self._handle, 1 if on else 0))
+        """True / 1: every stage between HIP events; 2: the synthesis kernels only (include/ghostcwt.h); False: none."""
+        check(lib.gcwt_plan_set_profiling(self._handle, 2 if on == 2 and on is not True else (1 if on else 0)))
 
     def set_row_pitch(self, pitch_samples):
         """Row pitch (samples) of device output buffers; 0 = dense.  Use a multiple of 32

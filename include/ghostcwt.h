@@ -218,6 +218,10 @@ int gcwt_plan_scale_info(const gcwt_plan* plan, int32_t* method, int32_t* decima
  * spectrum samples of morseutils.py:130-131 the kernel is built from. */
 int gcwt_plan_scale_support(const gcwt_plan* plan, double* theta_hi, double* support,
                             int32_t* n_bins);
+/* Stage timings (gcwt_get_timings; the reference's `verbose` print, transforms.py:226-229).  enabled = 1: every stage of
+ * an execute lies between two HIP events on its stream; 2: only the synthesis kernels do (synth_ms, interp_ms and
+ * synth_launches are filled, total_ms is their span, the other stages read 0) -- the events themselves cost a step of the
+ * headline shape 0.19 ms of 13.5, so a loop that is itself being timed asks for level 2; 0: none. */
 int gcwt_plan_set_profiling(gcwt_plan* plan, int enabled);
 /* After an execute of a plan with precision DEFAULT / AUTO / HIGH: predicted[s] (S floats, may be NULL) is the
  * predicted loss of scale s to the float32 stages of its decimation level, relative to its own output (0 for
