@@ -1033,13 +1033,13 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
   } while (0)
 
   // The channel means (transforms.py:142-143).  When the plan is one segment that is the whole recording (no epochs cut
-  // out, no time blocks with faded edges, FFT of 2^20 points) and every scale reads the spectrum, the forward column
+  // out, no time blocks with faded edges, no interleaved transforms) and every scale reads the spectrum, the forward column
   // pass sums the samples it reads anyway and the row pass takes the mean's transform out of its input (fwd64.hip):
   // the recording is read once.  A block request of such a plan runs the same forward side, so it gives the same bits.
   bool fold = false;
   if (p->fold_mean && p->d_y && hp.epochs.size() == 1 && hp.n_direct == 0 && hp.n_blockconv == 0) {
     const EpochPlan& m = hp.epochs[0];
-    fold = m.start == 0 && m.ne == N && m.lead == 0 && m.ramp_lo == 0 && m.ramp_hi == 0 && m.long_a == 1 && m.p1 == 256 &&
+    fold = m.start == 0 && m.ne == N && m.lead == 0 && m.ramp_lo == 0 && m.ramp_hi == 0 && m.long_a == 1 &&
            std::max(1, m.batch_count) == 1;
   }
   p->last_fold = fold;
@@ -1127,7 +1127,7 @@ static int run_pipeline(gcwt_plan* p, const float* dx, float* dout, int64_t r0, 
       for (int a = 0; a < A; ++a) {
         RUN(ST_FWD, launch_fwd64_cols(dx, p->d_y, P1, N, p->y_stride, P, p->d_tw64, p->d_sums, inv_n, sin, nb,
                                       rows_a, st, A, a, fold));
-        if (fold) RUN(ST_MEAN, launch_channel_sum_final(p->d_sums, C, kFoldParts, st));
+        if (fold) RUN(ST_MEAN, launch_channel_sum_final(p->d_sums, C, fold_parts(P1), st));
         RUN(ST_FWD, launch_fwd64_rows(p->d_y, p->d_x, rows_a, p->y_stride, P, p->d_tw64, slots,
                                       hp.n_fullband > 0 ? kRowLen : kRowLen / 2, hermitian ? P1 : 0, st, a, A, Pt,
                                       p->detect ? p->d_hist : nullptr, P1, fold ? p->d_sums : nullptr, inv_n, ep.ne, P1));

@@ -145,6 +145,18 @@ __device__ __forceinline__ void d_fill_twl(cd* twl, const cd* __restrict__ tw_hi
 // Rows 0 .. 128 are written; with rows_out = 256 the mirrored rows too (plans with full-band
 // scales read the whole spectrum).  grid (ld / 32, slots), dynamic LDS kFwd64Lds
 // ---------------------------------------------------------------------------
+// fold_mean: the workgroup's share of the channel's sum into its slot of the partial sums (kernels.h: kSumParts), in
+// a fixed order -- lanes by butterfly, the four waves in turn.  scratch: four doubles of LDS nobody else is using.
+__device__ __forceinline__ void fold_store(double acc, double* scratch, double* __restrict__ fold_parts, int n_channels,
+                                           int ch, int tid) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((tid & 63) == 0) scratch[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0)
+    fold_parts[(int64_t)n_channels + (int64_t)ch * kSumParts + blockIdx.x] = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
 constexpr int kColsTiles = 4;     // column tiles (32 real columns each) a workgroup walks: the next tile's samples
                                   // are in flight while this one is transformed (2 workgroups = 8 waves per CU are
                                   // all the LDS allows: without the prefetch the waves wait 71 % of their cycles)
@@ -221,15 +233,7 @@ __global__ void __launch_bounds__(256) k_fwd64_cols256_real2(const float* __rest
     }
     __syncthreads();                                 // the tile is read before the next exchange overwrites it
   }
-  if (fold_parts) {
-    // the workgroup's share of the channel's sum, in a fixed order: lanes by butterfly, the four waves in turn
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if ((tid & 63) == 0) ex_re[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0)
-      fold_parts[(int64_t)segs.n_channels + (int64_t)ch * kSumParts + blockIdx.x] = (ex_re[0] + ex_re[1]) + (ex_re[2] + ex_re[3]);
-  }
+  if (fold_parts) fold_store(acc, ex_re, fold_parts, segs.n_channels, ch, tid);      // (kernel-uniform)
 }
 
 // ---------------------------------------------------------------------------
@@ -242,7 +246,8 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
                                                            int lg_p, const cd* __restrict__ tw_hi,
                                                            const cd* __restrict__ tw_lo,
                                                            const double* __restrict__ sums, double inv_n,
-                                                           const SegIn segs, int rows_out, int in_stride, int in_offset) {
+                                                           const SegIn segs, int rows_out, int in_stride, int in_offset,
+                                                           double* __restrict__ fold_parts) {
   // in_stride A, in_offset a: the transform of the subsequence x[A n + a] (long mode: planner.h, EpochPlan::long_a)
   constexpr int q = 1 << LQ, len = 256 * q, np = q / 2;
   static_assert(q == 2 || q == 4, "two or four subsequences");
@@ -259,7 +264,8 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
   const int n_valid = (int)segs.n_valid[g], n_lead = (int)segs.n_lead[g];      // below P <= 2^24
   const SegRamp ramp = seg_ramp(segs, g);
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
-  const double mean = sums[ch] * inv_n;
+  const double mean = fold_parts ? 0.0 : sums[ch] * inv_n;     // (fold_parts: k_fwd64_cols256_real2)
+  double acc = 0.0;
   const int top = n_valid > 0 ? n_valid - 1 : 0;
   cd v[16], u[np > 1 ? 16 : 1];
 #pragma unroll
@@ -278,6 +284,7 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
       const int na = ((q * (t + 16 * j) + 2 * p) * ld + col0 + s) * in_stride + in_offset, nb = na + ld * in_stride;
       if (__any(seg_in_ramp(ramp, na) || seg_in_ramp(ramp, nb)))
         v[j] = make_double2(v[j].x * seg_weight(ramp, na), v[j].y * seg_weight(ramp, nb));
+      acc += v[j].x + v[j].y;
     }
     __syncthreads();                      // twiddle table written / previous exchange read
     d_fft256(v, twl + t, ex_re + s * kDCol, ex_im + s * kDCol, t);
@@ -318,6 +325,10 @@ __global__ void __launch_bounds__(256) k_fwd64_colsq_real2(const float* __restri
     }
     wj = dmul(wj, st16);
   }
+  if (fold_parts) {                       // (kernel-uniform)
+    __syncthreads();                      // the tiles in the planes are read
+    fold_store(acc, ex_re, fold_parts, segs.n_channels, ch, tid);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -329,7 +340,7 @@ __global__ void __launch_bounds__(256) k_fwd64_cols_small(const float* __restric
                                                           int64_t out_cstride, int lg_p,
                                                           const cd* __restrict__ tw_hi, const cd* __restrict__ tw_lo,
                                                           const double* __restrict__ sums, double inv_n,
-                                                          const SegIn segs, int rows_out) {
+                                                          const SegIn segs, int rows_out, double* __restrict__ fold_parts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cd* buf = reinterpret_cast<cd*>(smem);
   const int c = blockIdx.y, col0 = blockIdx.x * 16, total = len * 16;
@@ -337,12 +348,17 @@ __global__ void __launch_bounds__(256) k_fwd64_cols_small(const float* __restric
   const int64_t n_valid = segs.n_valid[g], n_lead = segs.n_lead[g];
   const SegRamp ramp = seg_ramp(segs, g);
   const float* x = in + (int64_t)ch * in_cstride + segs.x_off[g];
-  const double mean = sums[ch] * inv_n;
+  const double mean = fold_parts ? 0.0 : sums[ch] * inv_n;     // (fold_parts: k_fwd64_cols256_real2)
+  double acc = 0.0;
   for (int e = threadIdx.x; e < total; e += 256) {
     const int i = e >> 4, cc = e & 15;
     const int64_t n = (int64_t)i * ld + col0 + cc;
-    buf[e] = make_double2(n >= n_lead && n < n_valid ? ((double)x[n] - mean) * seg_weight(ramp, (int)n) : 0.0, 0.0);
+    const double val = n >= n_lead && n < n_valid ? ((double)x[n] - mean) * seg_weight(ramp, (int)n) : 0.0;
+    acc += val;
+    buf[e] = make_double2(val, 0.0);
   }
+  __shared__ double fold_scratch[4];
+  if (fold_parts) fold_store(acc, fold_scratch, fold_parts, segs.n_channels, ch, threadIdx.x);     // (kernel-uniform)
   __syncthreads();
   const int half_total = 16 * (len >> 1);
   for (int h = len >> 1, st = 0; h >= 1; h >>= 1, ++st) {          // decimation in frequency
@@ -675,27 +691,28 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
   if (in_stride < 1 || in_offset < 0 || in_offset >= in_stride || (in_stride > 1 && p1 != 512 && p1 != 1024))
     return hipErrorInvalidValue;                     // strided input: the 2^21 / 2^22-point kernels only (long mode)
   hipError_t e;
-  static_assert((kRowLenDev / 32 + kColsTiles - 1) / kColsTiles == kFoldParts && kFoldParts <= kSumParts, "partial sums of the folded mean");
-  if (fold_mean && (p1 != 256 || n_segments != 1 || in_stride != 1 || segs.n_lead[0] != 0 || segs.ramp_lo[0] != 0 ||
+  static_assert((kRowLenDev / 32 + kColsTiles - 1) / kColsTiles == fold_parts(256) && kRowLenDev / 16 == fold_parts(512) &&
+                fold_parts(512) <= kSumParts, "partial sums of the folded mean: one per workgroup of the column pass");
+  if (fold_mean && (n_segments != 1 || in_stride != 1 || segs.n_lead[0] != 0 || segs.ramp_lo[0] != 0 ||
                     segs.ramp_hi[0] != 0 || segs.x_off[0] != 0)) return hipErrorInvalidValue;
+  double* const parts = fold_mean ? const_cast<double*>(sums) : nullptr;
   if (p1 == 256) {
     if ((e = allow_lds(k_fwd64_cols256_real2, kFwd64Lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_fwd64_cols256_real2, dim3((ld / 32 + kColsTiles - 1) / kColsTiles, slots), dim3(256), kFwd64Lds, st, in, y, ld,
-                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out,
-                       fold_mean ? const_cast<double*>(sums) : nullptr);
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out, parts);
   } else if (p1 == 512) {
     if ((e = allow_lds(k_fwd64_colsq_real2<1>, kFwd64Lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_fwd64_colsq_real2<1>, dim3(ld / 16, slots), dim3(256), kFwd64Lds, st, in, y, ld,
-                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out, in_stride, in_offset);
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out, in_stride, in_offset, parts);
   } else if (p1 == 1024) {
     const size_t lds = kFwd64Lds + 256 * 17 * sizeof(cd);
     if ((e = allow_lds(k_fwd64_colsq_real2<2>, lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_fwd64_colsq_real2<2>, dim3(ld / 16, slots), dim3(256), lds, st, in, y, ld,
-                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out, in_stride, in_offset);
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out, in_stride, in_offset, parts);
   } else if (p1 >= 1 && p1 <= 128) {
     const size_t lds = (size_t)p1 * 16 * sizeof(cd);
     hipLaunchKernelGGL(k_fwd64_cols_small, dim3(ld / 16, slots), dim3(256), lds, st, in, y, p1, ilog2_64(p1), ld,
-                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out);
+                       in_cstride, y_cstride, lg_p, tw_hi, tw_lo, sums, inv_n, segs, rows_out, parts);
   } else {
     return hipErrorInvalidValue;
   }
@@ -706,7 +723,7 @@ hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_
                              const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st,
                              int comb_a, int comb_n, int64_t p_true, float* hist, int hist_rows,
                              const double* fold_sums, double inv_n, int64_t n_valid, int p1) {
-  if (fold_sums && (comb_n > 1 || p1 < 2 || (p1 & (p1 - 1)) || n_valid < 1 || n_valid > (int64_t)p1 * kRowLenDev)) return hipErrorInvalidValue;
+  if (fold_sums && (comb_n > 1 || p1 < 1 || (p1 & (p1 - 1)) || n_valid < 1 || n_valid > (int64_t)p1 * kRowLenDev)) return hipErrorInvalidValue;
   if (comb_n > 1 && (mirror == 0 || comb_a < 0 || comb_a >= comb_n || ilog2_64(p_true) > 24)) return hipErrorInvalidValue;
   // band sums: every row k1 of the spectrum's positive half once -- from its own workgroup or, reflected, from its twin's
   if (hist && (comb_n > 1 || out_len < kRowLenDev / 2 || hist_rows != (mirror > 0 ? mirror : n_rows))) return hipErrorInvalidValue;

@@ -231,7 +231,8 @@ hipError_t rows_to_host(const float* d_src, int64_t src_pitch, int64_t n_rows, i
 
 // sums: channel_sum_doubles(n_channels) doubles -- the results, then the workgroups' partial
 // sums (kernels.hip: k_channel_sum, k_channel_sum_final)
-constexpr int kSumParts = 64;
+constexpr int kSumParts = 256;        // partial sums kept per channel (k_channel_sum itself cuts a row into kSumPartsOwn at most)
+constexpr int kSumPartsOwn = 64;
 constexpr size_t channel_sum_doubles(size_t n_channels) { return n_channels * (kSumParts + 1); }
 hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,
                               hipStream_t st);
@@ -306,12 +307,14 @@ hipError_t launch_fwd64_cols(const float* in, double2* y, int p1, int64_t in_cst
                              int64_t p, const double2* tables, const double* sums, double inv_n,
                              const SegIn& segs, int n_segments, int rows_out, hipStream_t st, int in_stride = 1,
                              int in_offset = 0, bool fold_mean = false);
-// fold_mean (one segment that IS the recording, p1 = 256, no faded edges: api.cpp decides): the column pass transforms
+// fold_mean (one segment that IS the recording, no faded edges, no interleaved transforms: api.cpp decides): the column pass transforms
 // the samples as they are, leaves its workgroups' partial sums behind sums[C ..] (k_channel_sum's layout; added up by
 // launch_channel_sum_final), and the row pass takes the mean's own transform out of Y as it reads it (fold_sums): the
 // recording is read once for the forward side, not twice (transforms.py:142-143: x - mean(x)).
 hipError_t launch_channel_sum_final(double* sums, int n_channels, int parts, hipStream_t st);
-constexpr int kFoldParts = 32;     // workgroups of k_fwd64_cols256_real2 per channel
+// workgroups per channel of the column pass (= partial sums it leaves): k_fwd64_cols256_real2 walks four 32-column
+// tiles per workgroup, the others take 16 columns each
+constexpr int fold_parts(int p1) { return p1 == 256 ? 32 : 256; }
 // comb_n > 1 (long mode): subsequence comb_a of comb_n, accumulated into x with the twiddle W_p_true^(a k)
 hipError_t launch_fwd64_rows(const double2* y, float2* x, int n_rows, int64_t y_cstride, int64_t x_cstride,
                              const double2* tables, int n_slots, int out_len, int mirror, hipStream_t st,

@@ -1815,7 +1815,7 @@ static int ilog2(int64_t v) { int l = 0; while ((1LL << l) < v) ++l; return l; }
 
 hipError_t launch_channel_sum(const float* x, int64_t n, int n_channels, double* sums,
                               hipStream_t st) {
-  int parts = (int)std::min<int64_t>(kSumParts, (n + 256 * 32 - 1) / (256 * 32));
+  int parts = (int)std::min<int64_t>(kSumPartsOwn, (n + 256 * 32 - 1) / (256 * 32));
   if (parts < 1) parts = 1;
   hipLaunchKernelGGL(k_channel_sum, dim3(parts, n_channels), dim3(256), 0, st, x, n, sums);
   GCWT_LAUNCH_CHECK();

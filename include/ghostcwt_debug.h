@@ -41,7 +41,7 @@ int gcwt_debug_scale_theta_lo(const gcwt_plan* plan, double* theta_lo);
  * instantiated, 0 = none (yet), -1 = capture failed once and the plan runs eagerly. */
 int gcwt_debug_graph_state(const gcwt_plan* plan);
 /* 1 when the plan's last run took the channel sums inside the forward column pass and the mean's transform out of the
- * row pass's input (one segment that is the whole recording, FFT of 2^20 points, every scale spectral; option
+ * row pass's input (one segment that is the whole recording, FFTs up to 2^22 points, every scale spectral; option
  * fold_mean = 0 turns it off), 0 when a pass of its own over x made them (transforms.py:142-143 either way). */
 int gcwt_debug_mean_folded(const gcwt_plan* plan);
 /* precision = auto / high: the two terms of the last execute's prediction for workspace slot 0 of its last batch
