@@ -121,17 +121,20 @@ __global__ void __launch_bounds__(16 * NCOL, NCOL == 32 ? 4 : 3) k_synth7(const 
   constexpr int kGainLoads = kChunk * 64 / kThreads;     // float4 per thread and chunk: 1 (2 for 16 columns)
   static_assert(kGainLoads * kThreads == kChunk * 64, "one chunk = a whole number of loads per thread");
   const float4* const gain_rows = reinterpret_cast<const float4*>(a.gain_lv + (int64_t)lv.scale_offset * 256);
-  float4 g_v[kGainLoads];
+  static_assert(kGainLoads == 1 || kGainLoads == 2, "one or two 16-byte loads per thread and chunk");
+  // (two named registers, not an array: captured by the lambdas below an array of two went to scratch memory -- 48 bytes
+  // of private segment per lane and a scratch set-up for every wave of the 16-column instantiation)
+  float4 g_v0 = make_float4(0.f, 0.f, 0.f, 0.f), g_v1 = g_v0;
   auto load_gains = [&](int b0) {
-#pragma unroll
-    for (int i = 0; i < kGainLoads; ++i) g_v[i] = gain_rows[b0 * 64 + i * kThreads + tid];
+    g_v0 = gain_rows[b0 * 64 + tid];
+    if constexpr (kGainLoads > 1) g_v1 = gain_rows[b0 * 64 + kThreads + tid];
+  };
+  auto park_one = [&](int f, const float4& g) {          // float4 f of the chunk: scale f >> 6, lane (f >> 2) & 15
+    *reinterpret_cast<float4*>(stage + (f >> 6) * kGainRow + ((f >> 2) & 15) * 20 + (f & 3) * 4) = g;
   };
   auto park_gains = [&]() {
-#pragma unroll
-    for (int i = 0; i < kGainLoads; ++i) {
-      const int f = i * kThreads + tid;                  // float4 f of the chunk: scale f >> 6, lane (f >> 2) & 15
-      *reinterpret_cast<float4*>(stage + (f >> 6) * kGainRow + ((f >> 2) & 15) * 20 + (f & 3) * 4) = g_v[i];
-    }
+    park_one(tid, g_v0);
+    if constexpr (kGainLoads > 1) park_one(kThreads + tid, g_v1);
   };
   load_gains(0);
   const bool has_half = lv.n_plain < lv.n_scales;        // workgroup-uniform
