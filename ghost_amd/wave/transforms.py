@@ -67,8 +67,10 @@ class ContinuousWaveletTransform(WaveletTransform):
         sharded over, contiguous blocks, one plan and one host thread each -- ghost_amd/multi.py; the results stay on
         their devices and ``amplitude`` / ``fetch()`` stitch them), ``output`` ('amplitude', 'power', 'complex'), ``dtype``,
         ``lazy`` (default True: the result stays on the device when transform() returns and crosses PCIe on first
-        access to ``amplitude`` / ``power`` / ``coefficients`` -- or piecewise through ``fetch()`` --; False: it is on
-        the host when transform() returns, as in the reference),
+        access to ``amplitude`` / ``power`` / ``coefficients`` -- or piecewise through ``fetch()`` --; the device copy
+        (C x S x N x 4 bytes, 8 for complex) is kept, for ``fetch()`` and for the next call to reuse, until the next
+        transform() of another shape, ``release_device()`` or the object's end: many live objects hold many such
+        buffers; False: the result is on the host when transform() returns, as in the reference),
         ``device`` and ``precision`` ('auto', the default: the forward FFT in float64 like the reference's
         arithmetic, transforms.py:142-143, and the scales a mains line or the like inside their decimation band
         would cost more than 1.5e-6 of their peak are recomputed by exact FFT convolution, logged; 'high': the same
